@@ -1,0 +1,403 @@
+"""NumPy restatement of every tensor op on the hot path (oracle; test infrastructure only).
+
+All tensors are NHWC.  Every function works in the dtype of its inputs (tests use
+float64 for the ground truth and float32 to mimic the reference's CPU path).
+Each function cites the reference call site (paths relative to /root/reference)
+whose TensorFlow/Keras op it restates.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Tuple
+
+import numpy as np
+
+# --------------------------------------------------------------------------- #
+# Conv2D 3x3 / 1x1, stride 1, padding "same", bias
+#   Super_resolution/code/train_adaptive_unet.py:202,207,259,267-274
+#   kernel layout HWIO (Keras), zero padding.
+# --------------------------------------------------------------------------- #
+
+
+def conv2d_same_fwd(x: np.ndarray, w: np.ndarray, b: np.ndarray | None) -> np.ndarray:
+    kh, kw, cin, cout = w.shape
+    n, h, wd, c = x.shape
+    assert c == cin, (x.shape, w.shape)
+    ph, pw = kh // 2, kw // 2
+    xp = np.pad(x, ((0, 0), (ph, ph), (pw, pw), (0, 0)))
+    y = np.zeros((n, h, wd, cout), dtype=x.dtype)
+    for i in range(kh):
+        for j in range(kw):
+            y += xp[:, i:i + h, j:j + wd, :] @ w[i, j]
+    if b is not None:
+        y += b
+    return y
+
+
+def conv2d_same_bwd(x: np.ndarray, w: np.ndarray, dy: np.ndarray, need_dx: bool = True):
+    """Returns (dx, dw, db) -- dgrad, wgrad and bias grad of conv2d_same_fwd."""
+    kh, kw, cin, cout = w.shape
+    n, h, wd, _ = x.shape
+    ph, pw = kh // 2, kw // 2
+    xp = np.pad(x, ((0, 0), (ph, ph), (pw, pw), (0, 0)))
+    dw = np.zeros_like(w)
+    dxp = np.zeros_like(xp) if need_dx else None
+    dy2 = dy.reshape(-1, cout)
+    for i in range(kh):
+        for j in range(kw):
+            patch = xp[:, i:i + h, j:j + wd, :].reshape(-1, cin)
+            dw[i, j] = patch.T @ dy2
+            if need_dx:
+                dxp[:, i:i + h, j:j + wd, :] += dy @ w[i, j].T
+    db = dy2.sum(axis=0)
+    dx = dxp[:, ph:ph + h, pw:pw + wd, :] if need_dx else None
+    return dx, dw, db
+
+
+# --------------------------------------------------------------------------- #
+# LayerNormalization(axis=-1), Keras default epsilon 1e-3, biased variance
+#   Super_resolution/code/train_adaptive_unet.py:203,208
+# --------------------------------------------------------------------------- #
+
+LN_EPS = 1e-3
+
+
+def layernorm_fwd(x, gamma, beta, eps: float = LN_EPS):
+    mu = x.mean(axis=-1, keepdims=True)
+    var = ((x - mu) ** 2).mean(axis=-1, keepdims=True)
+    rstd = 1.0 / np.sqrt(var + eps)
+    xhat = (x - mu) * rstd
+    return xhat * gamma + beta, (xhat, rstd)
+
+
+def layernorm_bwd(dy, gamma, cache):
+    xhat, rstd = cache
+    red = tuple(range(dy.ndim - 1))
+    dgamma = (dy * xhat).sum(axis=red)
+    dbeta = dy.sum(axis=red)
+    g = dy * gamma
+    dx = rstd * (g - g.mean(axis=-1, keepdims=True) - xhat * (g * xhat).mean(axis=-1, keepdims=True))
+    return dx, dgamma, dbeta
+
+
+def relu_fwd(x):
+    return np.maximum(x, 0)
+
+
+def relu_bwd(dy, y):
+    # TF ReluGrad: gradient passes where the feature is strictly positive.
+    return dy * (y > 0)
+
+
+# --------------------------------------------------------------------------- #
+# tf.image.resize(..., method="bilinear", antialias=True)
+#   shared/custom_layers.py:93-103 (ResizeByScale), :121-125 (ResizeToMatch)
+#   = gen_image_ops.scale_and_translate(kernel_type="triangle", antialias=True)
+#   Restated from TF's published ScaleAndTranslate kernel (ComputeSpansCore):
+#   all span/weight arithmetic is float32; weights renormalised per output index.
+# --------------------------------------------------------------------------- #
+
+
+def resize_by_scale_size(h: int, scale: float) -> int:
+    """shared/custom_layers.py:98-101 -- ceil in float32, at least 1."""
+    v = np.float32(h) * np.float32(scale)
+    return max(int(np.ceil(v)), 1)
+
+
+def aa_triangle_spans(in_size: int, out_size: int) -> Tuple[np.ndarray, np.ndarray]:
+    """Per-output span starts and normalised float32 weights.
+
+    Returns (starts[out], weights[out, span]) with zero padding after each span.
+    """
+    f32 = np.float32
+    scale = f32(out_size) / f32(in_size)
+    inv_scale = f32(1.0) / scale
+    kernel_scale = max(inv_scale, f32(1.0))  # antialias=True
+    radius = f32(1.0)
+    span = min(2 * int(math.ceil(float(radius * kernel_scale))) + 1, in_size)
+    starts = np.zeros(out_size, dtype=np.int64)
+    weights = np.zeros((out_size, span), dtype=np.float32)
+    one_over = f32(1.0) / kernel_scale
+    for o in range(out_size):
+        sample = (f32(o) + f32(0.5)) * inv_scale
+        if sample < 0 or sample > in_size:
+            continue
+        s0 = int(math.ceil(float(sample - radius * kernel_scale - f32(0.5))))
+        s1 = int(math.floor(float(sample + radius * kernel_scale - f32(0.5))))
+        s0 = min(max(s0, 0), in_size - 1)
+        s1 = min(max(s1, 0), in_size - 1) + 1
+        ws = []
+        total = f32(0.0)
+        for src in range(s0, s1):
+            pos = (f32(src) + f32(0.5) - sample) * one_over
+            wgt = max(f32(0.0), f32(1.0) - abs(pos))
+            ws.append(wgt)
+            total = f32(total + wgt)
+        if abs(total) >= 1000.0 * np.finfo(np.float32).tiny:
+            for k, wgt in enumerate(ws):
+                weights[o, k] = f32(wgt * (f32(1.0) / total))
+        starts[o] = s0
+    return starts, weights
+
+
+def aa_matrix(in_size: int, out_size: int, dtype=np.float64) -> np.ndarray:
+    """Dense [out, in] interpolation matrix of the 1-D antialiased triangle resize."""
+    starts, weights = aa_triangle_spans(in_size, out_size)
+    m = np.zeros((out_size, in_size), dtype=dtype)
+    for o in range(out_size):
+        for k in range(weights.shape[1]):
+            j = starts[o] + k
+            if j < in_size and weights[o, k] != 0:
+                m[o, j] += weights[o, k]
+    return m
+
+
+def resize_aa_fwd(x: np.ndarray, oh: int, ow: int) -> np.ndarray:
+    n, h, w, c = x.shape
+    my = aa_matrix(h, oh, x.dtype)
+    mx = aa_matrix(w, ow, x.dtype)
+    t = np.einsum("oh,nhwc->nowc", my, x)
+    return np.einsum("pw,nowc->nopc", mx, t)
+
+
+def resize_aa_bwd(dy: np.ndarray, h: int, w: int) -> np.ndarray:
+    n, oh, ow, c = dy.shape
+    my = aa_matrix(h, oh, dy.dtype)
+    mx = aa_matrix(w, ow, dy.dtype)
+    t = np.einsum("pw,nopc->nowc", mx, dy)
+    return np.einsum("oh,nowc->nhwc", my, t)
+
+
+# --------------------------------------------------------------------------- #
+# ClippedResidualAdd  (shared/custom_layers.py:136-139)
+# --------------------------------------------------------------------------- #
+
+
+def clip_add_fwd(inp, res):
+    pre = inp + res
+    return np.clip(pre, 0.0, 1.0), pre
+
+
+def clip_add_bwd(dout, pre):
+    # tf.clip_by_value gradient: zero where pre < 0 or pre > 1 (bounds inclusive pass).
+    return dout * ((pre >= 0.0) & (pre <= 1.0))
+
+
+# --------------------------------------------------------------------------- #
+# Losses / metrics  (Super_resolution/code/train_adaptive_unet.py:308-334)
+# --------------------------------------------------------------------------- #
+
+CHARBONNIER_EPS = 1e-3
+
+
+def charbonnier_fwd(y_true, y_pred, eps: float = CHARBONNIER_EPS):
+    d = y_true - y_pred
+    return np.sqrt(d * d + eps * eps).mean()
+
+
+def charbonnier_bwd(y_true, y_pred, eps: float = CHARBONNIER_EPS):
+    d = y_true - y_pred
+    return -d / np.sqrt(d * d + eps * eps) / d.size
+
+
+def l1_fwd(y_true, y_pred):
+    return np.abs(y_true - y_pred).mean()
+
+
+def l1_bwd(y_true, y_pred):
+    return -np.sign(y_true - y_pred) / y_true.size
+
+
+def psnr_per_image(y_true, y_pred, max_val: float = 1.0):
+    """tf.image.psnr on clip(y_pred): per-image, inf when MSE == 0 (:308-311)."""
+    yp = np.clip(y_pred, 0.0, 1.0)
+    mse = ((y_true - yp) ** 2).reshape(y_true.shape[0], -1).mean(axis=1)
+    with np.errstate(divide="ignore"):
+        return 20.0 * np.log10(max_val) - 10.0 * np.log10(mse)
+
+
+def rgb_to_luma_bt601(image):
+    """Super_resolution/code/train_adaptive_unet.py:144-157."""
+    coeffs = np.array([65.481, 128.553, 24.966], dtype=image.dtype)
+    y = (image * coeffs).sum(axis=-1, keepdims=True) + 16.0
+    return np.clip(y / 255.0, 0.0, 1.0)
+
+
+def infer_eval_shave(scale: float) -> int:
+    """Super_resolution/code/evaluate_model.py:49-54 (2 * round(1/scale))."""
+    if scale <= 0:
+        return 0
+    return max(0, 2 * int(round(1.0 / scale)))
+
+
+# --------------------------------------------------------------------------- #
+# Keras-form Adam (keras 3.3.3 optimizers/adam.py, via train_adaptive_unet.py:489-494)
+# --------------------------------------------------------------------------- #
+
+
+def adam_step(p, g, m, v, step: int, lr=1e-4, b1=0.9, b2=0.999, eps=1e-7):
+    """In-place update; `step` is 1-based (iterations + 1)."""
+    alpha = lr * math.sqrt(1.0 - b2 ** step) / (1.0 - b1 ** step)
+    m += (g - m) * (1.0 - b1)
+    v += (g * g - v) * (1.0 - b2)
+    p -= m * alpha / (np.sqrt(v) + eps)
+
+
+# --------------------------------------------------------------------------- #
+# Depth heuristics (shared/custom_layers.py:10-82), pure Python
+# --------------------------------------------------------------------------- #
+
+
+def infer_depth_from_scale(scale: float, min_depth: int = 1, max_depth: int = 4) -> int:
+    if not (0.05 < scale < 1.0):
+        raise ValueError("Scale should be between 0 and 1 (exclusive).")
+    depth = 1 if scale <= 0.25 else (2 if scale <= 0.45 else 3)
+    return max(min_depth, min(depth, max_depth))
+
+
+def depth_and_sizes(scale, min_res=21, max_depth=7):
+    depth, sizes, res = 1, [256], 256
+    while res > min_res and depth < max_depth:
+        res = math.ceil(res * scale)
+        sizes.append(res)
+        depth += 1
+    return min(depth, max_depth), sizes
+
+
+def custom_depth_from_scale(scale, min_depth=1, max_depth=7, *, base_resolution=256, min_feature=21) -> int:
+    if not (0.05 < scale < 1.0):
+        raise ValueError("Scale should be between 0 and 1 (exclusive).")
+    if min_depth < 1 or max_depth < 1 or base_resolution <= 0 or min_feature < 1:
+        raise ValueError("invalid argument")
+    depth, extent = max(min_depth, 1), base_resolution
+    while depth < max_depth:
+        cand = math.ceil(extent * scale)
+        if cand < min_feature:
+            break
+        extent = cand
+        depth += 1
+    return max(min_depth, min(depth, max_depth))
+
+
+def estimate_bottleneck_size(hr: int, scale: float, depth: int) -> int:
+    size = hr
+    for _ in range(depth):
+        size = max(1, int(round(size * scale)))
+    return size
+
+
+# --------------------------------------------------------------------------- #
+# Tier-2 ops (segmentation models)
+#   Segmenation/code/train_adaptive_unet.py:258-362, Segmenation/code/unet_vinillia.py:42-99
+# --------------------------------------------------------------------------- #
+
+BN_EPS = 1e-3
+BN_MOMENTUM = 0.99
+
+
+def batchnorm_train_fwd(x, gamma, beta, eps: float = BN_EPS):
+    red = (0, 1, 2)
+    mu = x.mean(axis=red)
+    var = ((x - mu) ** 2).mean(axis=red)
+    rstd = 1.0 / np.sqrt(var + eps)
+    xhat = (x - mu) * rstd
+    return xhat * gamma + beta, (xhat, rstd), mu, var
+
+
+def batchnorm_train_bwd(dy, gamma, cache):
+    xhat, rstd = cache
+    red = (0, 1, 2)
+    m = dy.shape[0] * dy.shape[1] * dy.shape[2]
+    dgamma = (dy * xhat).sum(axis=red)
+    dbeta = dy.sum(axis=red)
+    dx = gamma * rstd * (dy - dbeta / m - xhat * dgamma / m)
+    return dx, dgamma, dbeta
+
+
+def batchnorm_infer_fwd(x, gamma, beta, moving_mean, moving_var, eps: float = BN_EPS):
+    return (x - moving_mean) / np.sqrt(moving_var + eps) * gamma + beta
+
+
+def maxpool2_fwd(x):
+    n, h, w, c = x.shape
+    xr = x[:, : h // 2 * 2, : w // 2 * 2, :].reshape(n, h // 2, 2, w // 2, 2, c)
+    return xr.max(axis=(2, 4))
+
+
+def maxpool2_bwd(dy, x):
+    """Gradient goes to the FIRST maximal element of each 2x2 window (TF MaxPoolGrad)."""
+    n, h, w, c = x.shape
+    oh, ow = h // 2, w // 2
+    xr = x[:, : oh * 2, : ow * 2, :].reshape(n, oh, 2, ow, 2, c).transpose(0, 1, 3, 5, 2, 4).reshape(n, oh, ow, c, 4)
+    idx = xr.argmax(axis=-1)
+    g = np.zeros_like(xr)
+    np.put_along_axis(g, idx[..., None], dy[..., None], axis=-1)
+    dx = np.zeros_like(x)
+    dx[:, : oh * 2, : ow * 2, :] = g.reshape(n, oh, ow, c, 2, 2).transpose(0, 1, 4, 2, 5, 3).reshape(n, oh * 2, ow * 2, c)
+    return dx
+
+
+def upsample2_bilinear_fwd(x):
+    """UpSampling2D(2, interpolation='bilinear') = half-pixel bilinear x2 (no antialias needed)."""
+    n, h, w, c = x.shape
+    return resize_aa_fwd(x, 2 * h, 2 * w)
+
+
+def conv_transpose2x2s2_fwd(x, w, b):
+    """Conv2DTranspose(nf, 2, strides=2); Keras kernel layout [kh, kw, Cout, Cin]."""
+    n, h, wd, cin = x.shape
+    kh, kw, cout, cin2 = w.shape
+    assert (kh, kw) == (2, 2) and cin2 == cin
+    y = np.zeros((n, 2 * h, 2 * wd, cout), dtype=x.dtype)
+    for a in range(2):
+        for bb in range(2):
+            y[:, a::2, bb::2, :] = x @ w[a, bb].T
+    return y + b
+
+
+def conv_transpose2x2s2_bwd(x, w, dy):
+    dx = np.zeros_like(x)
+    dw = np.zeros_like(w)
+    for a in range(2):
+        for bb in range(2):
+            g = dy[:, a::2, bb::2, :]
+            dx += g @ w[a, bb]
+            dw[a, bb] = g.reshape(-1, g.shape[-1]).T @ x.reshape(-1, x.shape[-1])
+    db = dy.reshape(-1, dy.shape[-1]).sum(axis=0)
+    return dx, dw, db
+
+
+def sigmoid(x):
+    return 1.0 / (1.0 + np.exp(-x))
+
+
+def bce_from_probs(y_true, p, eps: float = 1e-7):
+    """keras.losses.binary_crossentropy on probabilities (clipped to [eps, 1-eps]), mean over all."""
+    p = np.clip(p, eps, 1.0 - eps)
+    return (-(y_true * np.log(p) + (1.0 - y_true) * np.log(1.0 - p))).mean()
+
+
+def dice_coefficient(y_true, y_pred, smooth: float = 1e-6):
+    """Segmenation/code/train_adaptive_unet.py:258-269 -- per-sample dice, batch mean."""
+    yp = np.clip(y_pred, 1e-7, 1.0 - 1e-7)
+    ax = (1, 2, 3)
+    inter = (y_true * yp).sum(axis=ax)
+    denom = y_true.sum(axis=ax) + yp.sum(axis=ax)
+    return ((2.0 * inter + smooth) / (denom + smooth)).mean()
+
+
+def iou_score(y_true, y_pred, smooth: float = 1e-6):
+    """Segmenation/code/train_adaptive_unet.py:272-281 (soft IoU on clipped probabilities)."""
+    yp = np.clip(y_pred, 1e-7, 1.0 - 1e-7)
+    ax = (1, 2, 3)
+    inter = (y_true * yp).sum(axis=ax)
+    union = (y_true + yp).sum(axis=ax) - inter
+    return ((inter + smooth) / (union + smooth)).mean()
+
+
+def glorot_uniform(rng: np.random.Generator, shape, dtype=np.float32) -> np.ndarray:
+    """Keras GlorotUniform for a conv kernel [kh, kw, cin, cout]."""
+    rf = int(np.prod(shape[:-2])) if len(shape) > 2 else 1
+    fan_in, fan_out = shape[-2] * rf, shape[-1] * rf
+    limit = math.sqrt(6.0 / (fan_in + fan_out))
+    return rng.uniform(-limit, limit, size=shape).astype(dtype)

@@ -1,0 +1,242 @@
+"""NumPy oracle of the adaptive-depth SR U-Net (test infrastructure only).
+
+Restates ``build_super_resolution_unet`` / ``conv_block`` / the Keras train step of
+/root/reference/Super_resolution/code/train_adaptive_unet.py:200-287,308-334,489-494
+with explicit forward and backward passes.  Parameter names follow Keras' automatic
+layer naming (conv2d, conv2d_1, layer_normalization, ..., residual_rgb) so that the
+layer list can be compared line by line with the reference's ``model.summary()`` dumps.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+from . import ops
+
+
+def _uname(counter: Dict[str, int], base: str) -> str:
+    k = counter.get(base, 0)
+    counter[base] = k + 1
+    return base if k == 0 else f"{base}_{k}"
+
+
+class SRUNetOracle:
+    """Float64 (or float32) CPU model with manual backward."""
+
+    def __init__(self, scale: float, depth_override: int | None = None, input_size: int = 256,
+                 base_channels: int = 64, residual_head_channels: int = 64, max_depth: int = 7):
+        # train_adaptive_unet.py:227-231
+        self.scale = float(scale)
+        self.depth = depth_override if depth_override is not None else ops.custom_depth_from_scale(
+            scale, max_depth=max_depth, base_resolution=input_size)
+        self.input_size = input_size
+        self.base = base_channels
+        self.head = residual_head_channels
+        self.name = f"U-Net_SR_scale{scale:.2f}_depth{self.depth}"
+        self.info = {
+            "scale": scale,
+            "depth": self.depth,
+            "bottleneck_size": ops.estimate_bottleneck_size(input_size, scale, self.depth),
+            "base_channels": base_channels,
+            "max_depth": max_depth,
+        }
+        self.layers: List[dict] = []   # Keras summary rows: name, type, shape (H, W, C), params
+        self.param_shapes: Dict[str, Tuple[int, ...]] = {}
+        self._plan: List[tuple] = []
+        self._build()
+
+    # ------------------------------------------------------------------ #
+    def _add(self, name, typ, shape, nparams=0):
+        self.layers.append({"name": name, "type": typ, "shape": tuple(shape), "params": int(nparams)})
+
+    def _conv(self, cnt, cin, cout, hw, k=3, name=None):
+        name = name or _uname(cnt, "conv2d")
+        self.param_shapes[name + "/kernel"] = (k, k, cin, cout)
+        self.param_shapes[name + "/bias"] = (cout,)
+        self._add(name, "Conv2D", (hw, hw, cout), k * k * cin * cout + cout)
+        return name
+
+    def _conv_block(self, cnt, cin, nf, hw):
+        names = []
+        for i in range(2):
+            c = self._conv(cnt, cin if i == 0 else nf, nf, hw)
+            ln = _uname(cnt, "layer_normalization")
+            self.param_shapes[ln + "/gamma"] = (nf,)
+            self.param_shapes[ln + "/beta"] = (nf,)
+            self._add(ln, "LayerNormalization", (hw, hw, nf), 2 * nf)
+            act = _uname(cnt, "activation")
+            self._add(act, "Activation", (hw, hw, nf), 0)
+            names.append((c, ln))
+        return names
+
+    def _build(self):
+        cnt: Dict[str, int] = {}
+        p = self.input_size
+        self._add("low_res_input", "InputLayer", (p, p, 3), 0)
+        nf, hw, cin = self.base, p, 3
+        self.sizes = [p]
+        plan = []
+        enc_down_row = None
+        for _ in range(self.depth):
+            blk = self._conv_block(cnt, cin, nf, hw)
+            plan.append(("block", blk))
+            nhw = ops.resize_by_scale_size(hw, self.scale)
+            plan.append(("down", hw, nhw))
+            if enc_down_row is None:
+                enc_down_row = len(self.layers)
+                self._add("enc_down", "ResizeByScale", (nhw, nhw, nf), 0)
+            else:
+                self.layers[enc_down_row]["shape"] = (nhw, nhw, nf)  # shared layer: summary shows last call
+            hw, cin = nhw, nf
+            self.sizes.append(hw)
+            nf *= 2
+        blk = self._conv_block(cnt, cin, nf, hw)
+        plan.append(("block", blk))
+        dec_up_row = None
+        for lvl in reversed(range(self.depth)):
+            nf //= 2
+            shw = self.sizes[lvl]
+            plan.append(("up", hw, shw))
+            if dec_up_row is None:
+                dec_up_row = len(self.layers)
+                self._add("dec_up", "ResizeToMatch", (shw, shw, 2 * nf), 0)
+            else:
+                self.layers[dec_up_row]["shape"] = (shw, shw, 2 * nf)
+            up = self._conv(cnt, 2 * nf, nf, shw)
+            plan.append(("upconv", up))
+            cat = _uname(cnt, "concatenate")
+            self._add(cat, "Concatenate", (shw, shw, 2 * nf), 0)
+            plan.append(("concat", lvl))
+            blk = self._conv_block(cnt, 2 * nf, nf, shw)
+            plan.append(("block", blk))
+            hw = shw
+        blk = self._conv_block(cnt, nf, self.head, hw)
+        plan.append(("block", blk))
+        self._conv(cnt, self.head, 3, hw, k=1, name="residual_rgb")
+        plan.append(("head",))
+        self._add("enhanced_rgb", "ClippedResidualAdd", (hw, hw, 3), 0)
+        self._plan = plan
+
+    def count_params(self) -> int:
+        return sum(int(np.prod(s)) for s in self.param_shapes.values())
+
+    # ------------------------------------------------------------------ #
+    def init_params(self, rng: np.random.Generator, dtype=np.float64, head_uniform: float = 0.0):
+        """Glorot-uniform kernels, zero biases, LN gamma=1 beta=0, residual_rgb zero
+        (or U(-head_uniform, head_uniform) so that gradients are non-trivial)."""
+        params = {}
+        for name, shape in self.param_shapes.items():
+            if name.endswith("/kernel"):
+                if name.startswith("residual_rgb"):
+                    params[name] = (rng.uniform(-head_uniform, head_uniform, size=shape).astype(dtype)
+                                    if head_uniform > 0 else np.zeros(shape, dtype))
+                else:
+                    params[name] = ops.glorot_uniform(rng, shape, dtype)
+            elif name.endswith("/gamma"):
+                params[name] = np.ones(shape, dtype)
+            elif name.startswith("residual_rgb") and head_uniform > 0:
+                params[name] = rng.uniform(-head_uniform, head_uniform, size=shape).astype(dtype)
+            else:
+                params[name] = np.zeros(shape, dtype)
+        return params
+
+    # ------------------------------------------------------------------ #
+    def forward(self, params, x, keep: bool = True):
+        tape = []
+        skips = []
+        inp = x
+        for step in self._plan:
+            kind = step[0]
+            if kind == "block":
+                for conv, ln in step[1]:
+                    z = ops.conv2d_same_fwd(x, params[conv + "/kernel"], params[conv + "/bias"])
+                    y, cache = ops.layernorm_fwd(z, params[ln + "/gamma"], params[ln + "/beta"])
+                    a = ops.relu_fwd(y)
+                    tape.append(("cla", conv, ln, x, cache, a))
+                    x = a
+            elif kind == "down":
+                h = x.shape[1]
+                tape.append(("down", h, len(skips)))
+                skips.append(x)
+                x = ops.resize_aa_fwd(x, step[2], step[2])
+            elif kind == "up":
+                h = x.shape[1]
+                tape.append(("up", h))
+                x = ops.resize_aa_fwd(x, step[2], step[2])
+            elif kind == "upconv":
+                conv = step[1]
+                a = ops.relu_fwd(ops.conv2d_same_fwd(x, params[conv + "/kernel"], params[conv + "/bias"]))
+                tape.append(("ca", conv, x, a))
+                x = a
+            elif kind == "concat":
+                skip = skips[step[1]]
+                tape.append(("concat", x.shape[-1], step[1]))
+                x = np.concatenate([x, skip], axis=-1)
+            elif kind == "head":
+                r = ops.conv2d_same_fwd(x, params["residual_rgb/kernel"], params["residual_rgb/bias"])
+                out, pre = ops.clip_add_fwd(inp, r)
+                tape.append(("head", x, pre))
+                x = out
+        self._tape = tape if keep else None
+        self._nskips = len(skips)
+        return x
+
+    def backward(self, params, dout):
+        grads = {}
+        dskips = [None] * self._nskips
+        d = dout
+        for rec in reversed(self._tape):
+            kind = rec[0]
+            if kind == "head":
+                _, xh, pre = rec
+                dr = ops.clip_add_bwd(d, pre)
+                d, dw, db = ops.conv2d_same_bwd(xh, params["residual_rgb/kernel"], dr)
+                grads["residual_rgb/kernel"], grads["residual_rgb/bias"] = dw, db
+            elif kind == "cla":
+                _, conv, ln, xin, cache, a = rec
+                dy = ops.relu_bwd(d, a)
+                dz, dg, dbeta = ops.layernorm_bwd(dy, params[ln + "/gamma"], cache)
+                grads[ln + "/gamma"], grads[ln + "/beta"] = dg, dbeta
+                need_dx = xin.shape[-1] != 3 or conv != "conv2d"
+                d, dw, db = ops.conv2d_same_bwd(xin, params[conv + "/kernel"], dz, need_dx=need_dx)
+                grads[conv + "/kernel"], grads[conv + "/bias"] = dw, db
+            elif kind == "ca":
+                _, conv, xin, a = rec
+                dz = ops.relu_bwd(d, a)
+                d, dw, db = ops.conv2d_same_bwd(xin, params[conv + "/kernel"], dz)
+                grads[conv + "/kernel"], grads[conv + "/bias"] = dw, db
+            elif kind == "concat":
+                _, c1, lvl = rec
+                dskips[lvl] = d[..., c1:]
+                d = d[..., :c1]
+            elif kind == "up":
+                d = ops.resize_aa_bwd(d, rec[1], rec[1])
+            elif kind == "down":
+                d = ops.resize_aa_bwd(d, rec[1], rec[1]) + dskips[rec[2]]
+        return grads
+
+    # ------------------------------------------------------------------ #
+    def loss_and_grads(self, params, lr_img, hr_img, loss: str = "charbonnier"):
+        out = self.forward(params, lr_img)
+        if loss == "charbonnier":
+            val = ops.charbonnier_fwd(hr_img, out)
+            dout = ops.charbonnier_bwd(hr_img, out)
+        elif loss == "l1":
+            val = ops.l1_fwd(hr_img, out)
+            dout = ops.l1_bwd(hr_img, out)
+        else:
+            raise ValueError(f"Unknown loss '{loss}'. Expected one of: 'charbonnier', 'l1', 'combined'.")
+        grads = self.backward(params, dout)
+        psnr = float(np.mean(ops.psnr_per_image(hr_img, out)))
+        return float(val), grads, out, psnr
+
+    def train_step(self, params, opt_state, lr_img, hr_img, lr=1e-4, loss: str = "charbonnier"):
+        """One Keras train step (forward, loss, backward, Keras-form Adam). Mutates params/state."""
+        val, grads, out, psnr = self.loss_and_grads(params, lr_img, hr_img, loss)
+        opt_state["step"] = opt_state.get("step", 0) + 1
+        for name in params:
+            m = opt_state.setdefault("m/" + name, np.zeros_like(params[name]))
+            v = opt_state.setdefault("v/" + name, np.zeros_like(params[name]))
+            ops.adam_step(params[name], grads[name], m, v, opt_state["step"], lr=lr)
+        return val, psnr
