@@ -1,0 +1,72 @@
+"""ctypes binding of the C ABI declared in include/adunet.h.
+
+The HIP library is the product: if ``csrc/libadunet_hip.so`` is missing or fails to load, every
+compute entry point raises -- there is no CPU or PyTorch fallback anywhere in this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libadunet_hip.so")
+
+AD_F32, AD_BF16 = 0, 1
+EPI_NONE, EPI_RELU = 0, 1
+
+_vp, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); must list every symbol of include/adunet.h
+SIGNATURES = {
+    "ad_version": (_i, []),
+    "ad_last_error": (C.c_char_p, []),
+    "ad_cin_granule": (_i, [_i]),
+    "ad_pad_channels": (_i, [_vp, _vp, _i64, _i, _i, _i, _vp]),
+    "ad_conv3x3_pack": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp]),
+    "ad_conv3x3_fwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "ad_conv3x3_wgrad_ws_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "ad_conv3x3_wgrad": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _i, _vp]),
+    "ad_layernorm_relu_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _i, _i, _vp]),
+    "ad_layernorm_bwd_ws_bytes": (_sz, [_i64, _i]),
+    "ad_layernorm_relu_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _sz, _i, _vp]),
+    "ad_relu_bwd": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _vp, _sz, _i, _vp]),
+    "ad_resample": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "ad_head_ws_bytes": (_sz, [_i, _i]),
+    "ad_head_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _f, _vp, _sz, _i, _vp]),
+    "ad_head_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _f, _f, _vp, _sz, _i, _vp]),
+    "ad_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _f, _vp]),
+    "ad_cast": (_i, [_vp, _i, _vp, _i, _i64, _vp]),
+}
+
+_lib = None
+
+
+class AdunetError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes handle; raise loudly if the HIP library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AdunetError(
+            f"HIP extension not built: {LIB_PATH} is missing. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    import torch  # noqa: F401  -- load torch's HIP runtime first so both share one libamdhip64
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().ad_last_error().decode("utf-8", "replace")
+        if rc == -1:
+            raise ValueError(f"{what}: {msg}")
+        raise AdunetError(f"{what}: rc={rc}: {msg}")

@@ -1,0 +1,73 @@
+// Error reporting + small utility entry points of the C ABI.
+#include "common.h"
+#include <stdarg.h>
+#include <stdio.h>
+
+static thread_local char g_err[512] = "";
+
+int ad_set_error(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+extern "C" int ad_version(void) { return 1; }
+extern "C" const char* ad_last_error(void) { return g_err; }
+extern "C" int ad_cin_granule(int dtype) { return dtype == AD_BF16 ? 32 : 16; }
+
+template <typename TI, typename TO>
+__global__ void cast_kernel(const TI* __restrict__ x, TO* __restrict__ y, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) y[i] = (TO)(float)x[i];
+}
+
+extern "C" int ad_cast(const void* x, int dtype_in, void* y, int dtype_out, int64_t count, void* stream) {
+    if (count <= 0) return AD_OK;
+    hipStream_t s = (hipStream_t)stream;
+    int blocks = (int)((count + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    if (dtype_in == AD_F32 && dtype_out == AD_BF16)
+        cast_kernel<float, bf16_t><<<blocks, 256, 0, s>>>((const float*)x, (bf16_t*)y, count);
+    else if (dtype_in == AD_BF16 && dtype_out == AD_F32)
+        cast_kernel<bf16_t, float><<<blocks, 256, 0, s>>>((const bf16_t*)x, (float*)y, count);
+    else if (dtype_in == AD_F32 && dtype_out == AD_F32)
+        cast_kernel<float, float><<<blocks, 256, 0, s>>>((const float*)x, (float*)y, count);
+    else if (dtype_in == AD_BF16 && dtype_out == AD_BF16)
+        cast_kernel<bf16_t, bf16_t><<<blocks, 256, 0, s>>>((const bf16_t*)x, (bf16_t*)y, count);
+    else
+        return ad_set_error(AD_ERR_ARG, "ad_cast: bad dtype %d -> %d", dtype_in, dtype_out);
+    AD_LAUNCH_CHECK("ad_cast");
+    return AD_OK;
+}
+
+template <typename T>
+__global__ void pad_channels_kernel(const float* __restrict__ x, T* __restrict__ y, int64_t npix, int c, int cpad) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t total = npix * cpad;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        int64_t p = i / cpad;
+        int ch = (int)(i - p * cpad);
+        y[i] = (T)(ch < c ? x[p * c + ch] : 0.0f);
+    }
+}
+
+extern "C" int ad_pad_channels(const float* x, void* y, int64_t npix, int c, int cpad, int dtype, void* stream) {
+    AD_REQUIRE(c > 0 && cpad >= c, "ad_pad_channels: c=%d cpad=%d", c, cpad);
+    if (npix <= 0) return AD_OK;
+    hipStream_t s = (hipStream_t)stream;
+    int64_t total = npix * cpad;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    if (dtype == AD_BF16)
+        pad_channels_kernel<bf16_t><<<blocks, 256, 0, s>>>(x, (bf16_t*)y, npix, c, cpad);
+    else if (dtype == AD_F32)
+        pad_channels_kernel<float><<<blocks, 256, 0, s>>>(x, (float*)y, npix, c, cpad);
+    else
+        return ad_set_error(AD_ERR_ARG, "ad_pad_channels: bad dtype %d", dtype);
+    AD_LAUNCH_CHECK("ad_pad_channels");
+    return AD_OK;
+}

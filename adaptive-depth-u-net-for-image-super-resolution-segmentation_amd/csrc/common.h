@@ -1,0 +1,71 @@
+// Internal helpers shared by the gfx950 kernels (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/adunet.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short short4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+int ad_set_error(int code, const char* fmt, ...);
+
+#define AD_REQUIRE(cond, ...)                                   \
+    do {                                                        \
+        if (!(cond)) return ad_set_error(AD_ERR_ARG, __VA_ARGS__); \
+    } while (0)
+
+#define AD_LAUNCH_CHECK(name)                                                            \
+    do {                                                                                 \
+        hipError_t e_ = hipGetLastError();                                               \
+        if (e_ != hipSuccess)                                                            \
+            return ad_set_error(AD_ERR_LAUNCH, "%s: %s", name, hipGetErrorString(e_));   \
+    } while (0)
+
+template <typename T> struct ElemTraits;
+template <> struct ElemTraits<float> {
+    static constexpr int EPT = 4;  // elements per 16 bytes
+    static constexpr int DT = AD_F32;
+};
+template <> struct ElemTraits<bf16_t> {
+    static constexpr int EPT = 8;
+    static constexpr int DT = AD_BF16;
+};
+
+// 16-byte vector of T, unpacked to / packed from fp32.
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+    float4 v;
+    __device__ __forceinline__ void load(const void* p) { v = *reinterpret_cast<const float4*>(p); }
+    __device__ __forceinline__ void store(void* p) const { *reinterpret_cast<float4*>(p) = v; }
+    __device__ __forceinline__ void zero() { v = make_float4(0.f, 0.f, 0.f, 0.f); }
+    __device__ __forceinline__ void to_f32(float* f) const { f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w; }
+    __device__ __forceinline__ void from_f32(const float* f) { v = make_float4(f[0], f[1], f[2], f[3]); }
+};
+template <> struct Vec16<bf16_t> {
+    bf16x8 v;
+    __device__ __forceinline__ void load(const void* p) { v = *reinterpret_cast<const bf16x8*>(p); }
+    __device__ __forceinline__ void store(void* p) const { *reinterpret_cast<bf16x8*>(p) = v; }
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (bf16_t)0.0f;
+    }
+    __device__ __forceinline__ void to_f32(float* f) const {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] = (float)v[i];
+    }
+    __device__ __forceinline__ void from_f32(const float* f) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (bf16_t)f[i];
+    }
+};
+
+static inline int ad_ilog2(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+static inline size_t ad_align(size_t v, size_t a) { return (v + a - 1) / a * a; }

@@ -1,0 +1,282 @@
+// Fused residual head: 1x1 Conv2D (64 -> 3, "residual_rgb", train_adaptive_unet.py:267-274)
+// + ClippedResidualAdd (shared/custom_layers.py:136-139) + Charbonnier / L1 loss and the per-image
+// squared error behind tf.image.psnr (train_adaptive_unet.py:308-334), forward and backward.
+// Arithmetic intensity ~3 FLOP/B => HBM-bound: one pass over x_head, G = ch/EPT lanes per pixel.
+#include "common.h"
+
+namespace {
+
+constexpr int BPI_MAX = 64;  // blocks per image
+
+template <int G>
+__device__ __forceinline__ float gsum(float v) {
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <typename T, int G>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ xh, const float* __restrict__ w,
+                                                       const float* __restrict__ b, const float* __restrict__ inp,
+                                                       const float* __restrict__ target, float* __restrict__ out,
+                                                       float* __restrict__ part, int64_t ppi, int ch, int loss_kind,
+                                                       float eps) {
+    constexpr int EPT = ElemTraits<T>::EPT;
+    constexpr int PPB = 256 / G;
+    __shared__ float sm[2][4];
+    const int tid = threadIdx.x, gl = tid % G, gp = tid / G;
+    const int img = blockIdx.y;
+    float wl[EPT][3];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e)
+#pragma unroll
+        for (int o = 0; o < 3; ++o) wl[e][o] = w[(gl * EPT + e) * 3 + o];
+    const float bo = gl < 3 ? b[gl] : 0.f;
+    float lsum = 0.f, qsum = 0.f;
+    for (int64_t q = (int64_t)blockIdx.x * PPB + gp; q < ppi; q += (int64_t)gridDim.x * PPB) {
+        const int64_t pix = (int64_t)img * ppi + q;
+        Vec16<T> ld;
+        float x[EPT];
+        ld.load(xh + pix * ch + gl * EPT);
+        ld.to_f32(x);
+        float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            r0 += x[e] * wl[e][0];
+            r1 += x[e] * wl[e][1];
+            r2 += x[e] * wl[e][2];
+        }
+        r0 = gsum<G>(r0); r1 = gsum<G>(r1); r2 = gsum<G>(r2);
+        if (gl < 3) {
+            float r = (gl == 0 ? r0 : (gl == 1 ? r1 : r2)) + bo;
+            float pre = inp[pix * 3 + gl] + r;
+            float o = fminf(fmaxf(pre, 0.f), 1.f);
+            out[pix * 3 + gl] = o;
+            if (target) {
+                float d = target[pix * 3 + gl] - o;
+                lsum += loss_kind == 0 ? sqrtf(d * d + eps * eps) : fabsf(d);
+                qsum += d * d;
+            }
+        }
+    }
+    lsum = wave_sum(lsum);
+    qsum = wave_sum(qsum);
+    if ((tid & 63) == 0) { sm[0][tid >> 6] = lsum; sm[1][tid >> 6] = qsum; }
+    __syncthreads();
+    if (tid == 0 && part) {
+        size_t slot = (size_t)img * gridDim.x + blockIdx.x;
+        part[slot * 2 + 0] = sm[0][0] + sm[0][1] + sm[0][2] + sm[0][3];
+        part[slot * 2 + 1] = sm[1][0] + sm[1][1] + sm[1][2] + sm[1][3];
+    }
+}
+
+// stats[0] = sum of all loss partials; sqerr[img] = sum of that image's squared-error partials
+__global__ __launch_bounds__(256) void head_stats_kernel(const float* __restrict__ part, int n, int bpi,
+                                                         float* __restrict__ stats, float* __restrict__ sqerr) {
+    __shared__ float sm[256];
+    const int tid = threadIdx.x;
+    float s = 0.f;
+    for (int i = tid; i < n * bpi; i += 256) s += part[(size_t)i * 2];
+    sm[tid] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) sm[tid] += sm[tid + o];
+        __syncthreads();
+    }
+    if (tid == 0 && stats) stats[0] = sm[0];
+    if (sqerr)
+        for (int img = tid; img < n; img += 256) {
+            float q = 0.f;
+            for (int k = 0; k < bpi; ++k) q += part[((size_t)img * bpi + k) * 2 + 1];
+            sqerr[img] = q;
+        }
+}
+
+template <typename T, int G>
+__global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ xh, const float* __restrict__ w,
+                                                       const float* __restrict__ b, const float* __restrict__ inp,
+                                                       const float* __restrict__ target, T* __restrict__ dxh,
+                                                       float* __restrict__ part, int64_t ppi, int ch, int loss_kind,
+                                                       float eps, float gscale) {
+    constexpr int EPT = ElemTraits<T>::EPT;
+    constexpr int PPB = 256 / G;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = reinterpret_cast<float*>(smem);  // [PPB][ch*3+3]
+    const int ncol = ch * 3 + 3;
+    const int tid = threadIdx.x, gl = tid % G, gp = tid / G;
+    const int img = blockIdx.y;
+    float wl[EPT][3], aw[EPT][3], ab[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < EPT; ++e)
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            wl[e][o] = w[(gl * EPT + e) * 3 + o];
+            aw[e][o] = 0.f;
+        }
+    const float b0 = b[0], b1 = b[1], b2 = b[2];
+    for (int64_t q = (int64_t)blockIdx.x * PPB + gp; q < ppi; q += (int64_t)gridDim.x * PPB) {
+        const int64_t pix = (int64_t)img * ppi + q;
+        Vec16<T> ld;
+        float x[EPT];
+        ld.load(xh + pix * ch + gl * EPT);
+        ld.to_f32(x);
+        float r[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            r[0] += x[e] * wl[e][0];
+            r[1] += x[e] * wl[e][1];
+            r[2] += x[e] * wl[e][2];
+        }
+        r[0] = gsum<G>(r[0]) + b0; r[1] = gsum<G>(r[1]) + b1; r[2] = gsum<G>(r[2]) + b2;
+        float g[3];
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            float pre = inp[pix * 3 + o] + r[o];
+            float ov = fminf(fmaxf(pre, 0.f), 1.f);
+            float d = target[pix * 3 + o] - ov;
+            float dl = loss_kind == 0 ? -d * rsqrtf(d * d + eps * eps) : (d > 0.f ? -1.f : (d < 0.f ? 1.f : 0.f));
+            g[o] = (pre >= 0.f && pre <= 1.f) ? dl * gscale : 0.f;
+        }
+        float dx[EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            dx[e] = g[0] * wl[e][0] + g[1] * wl[e][1] + g[2] * wl[e][2];
+#pragma unroll
+            for (int o = 0; o < 3; ++o) aw[e][o] += x[e] * g[o];
+        }
+#pragma unroll
+        for (int o = 0; o < 3; ++o) ab[o] += g[o];
+        Vec16<T> st;
+        st.from_f32(dx);
+        st.store(dxh + pix * ch + gl * EPT);
+    }
+#pragma unroll
+    for (int e = 0; e < EPT; ++e)
+#pragma unroll
+        for (int o = 0; o < 3; ++o) red[gp * ncol + (gl * EPT + e) * 3 + o] = aw[e][o];
+    if (gl == 0)
+#pragma unroll
+        for (int o = 0; o < 3; ++o) red[gp * ncol + ch * 3 + o] = ab[o];
+    __syncthreads();
+    for (int i = tid; i < ncol; i += 256) {
+        float s = 0.f;
+        for (int p = 0; p < PPB; ++p) s += red[p * ncol + i];
+        part[((size_t)img * gridDim.x + blockIdx.x) * ncol + i] = s;
+    }
+}
+
+// out[col] = sum over rows of part[row][col], fixed order (16 columns x 16 row-groups per block)
+__global__ __launch_bounds__(256) void rows_reduce_kernel(const float* __restrict__ part, int nrows, int ncols,
+                                                          float* __restrict__ o0, int n0, float* __restrict__ o1) {
+    __shared__ float sm[16][17];
+    const int tid = threadIdx.x, cl = tid & 15, rg = tid >> 4;
+    const int i = blockIdx.x * 16 + cl;
+    float s = 0.f;
+    if (i < ncols)
+        for (int r = rg; r < nrows; r += 16) s += part[(size_t)r * ncols + i];
+    sm[rg][cl] = s;
+    __syncthreads();
+    if (rg == 0 && i < ncols) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += sm[r][cl];
+        if (i < n0) o0[i] = t; else o1[i - n0] = t;
+    }
+}
+
+static int head_bpi(int64_t ppi, int g) {
+    int64_t ppb = 256 / g;
+    int64_t nb = (ppi + ppb - 1) / ppb;
+    return (int)(nb < BPI_MAX ? nb : BPI_MAX);
+}
+
+#define HEAD_DISPATCH(...)                                         \
+    switch (g) {                                                   \
+        case 4: { constexpr int G_ = 4; __VA_ARGS__ } break;       \
+        case 8: { constexpr int G_ = 8; __VA_ARGS__ } break;       \
+        case 16: { constexpr int G_ = 16; __VA_ARGS__ } break;     \
+        case 32: { constexpr int G_ = 32; __VA_ARGS__ } break;     \
+        default: { constexpr int G_ = 64; __VA_ARGS__ } break;     \
+    }
+
+static bool head_group(int ch, int ept, int* g) {
+    if (ch <= 0 || ch % ept) return false;
+    int v = ch / ept;
+    if (v != 4 && v != 8 && v != 16 && v != 32 && v != 64) return false;
+    *g = v;
+    return true;
+}
+
+}  // namespace
+
+extern "C" size_t ad_head_ws_bytes(int n, int ch) {
+    return (size_t)n * BPI_MAX * (ch * 3 + 3) * sizeof(float);
+}
+
+extern "C" int ad_head_fwd(const void* xh, const float* w, const float* b, const float* inp, const float* target,
+                           float* out, float* stats, float* sqerr, int n, int64_t pix_per_img, int ch, int loss_kind,
+                           float eps, void* ws, size_t ws_bytes, int dtype, void* stream) {
+    AD_REQUIRE(dtype == AD_BF16 || dtype == AD_F32, "ad_head_fwd: bad dtype %d", dtype);
+    AD_REQUIRE(n > 0 && pix_per_img > 0, "ad_head_fwd: bad shape");
+    AD_REQUIRE(loss_kind == 0 || loss_kind == 1, "ad_head_fwd: loss_kind=%d", loss_kind);
+    int g;
+    AD_REQUIRE(head_group(ch, dtype == AD_BF16 ? 8 : 4, &g), "ad_head_fwd: unsupported ch=%d", ch);
+    const int bpi = head_bpi(pix_per_img, g);
+    float* part = nullptr;
+    if (target) {
+        size_t need = (size_t)n * bpi * 2 * sizeof(float);
+        if (!ws || ws_bytes < need) return ad_set_error(AD_ERR_WS, "ad_head_fwd: workspace %zu < %zu", ws_bytes, need);
+        part = (float*)ws;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(bpi, n);
+    if (dtype == AD_BF16) {
+        HEAD_DISPATCH(head_fwd_kernel<bf16_t, G_><<<grid, 256, 0, s>>>((const bf16_t*)xh, w, b, inp, target, out, part,
+                                                                       pix_per_img, ch, loss_kind, eps);)
+    } else {
+        HEAD_DISPATCH(head_fwd_kernel<float, G_><<<grid, 256, 0, s>>>((const float*)xh, w, b, inp, target, out, part,
+                                                                      pix_per_img, ch, loss_kind, eps);)
+    }
+    AD_LAUNCH_CHECK("ad_head_fwd");
+    if (target) {
+        head_stats_kernel<<<1, 256, 0, s>>>(part, n, bpi, stats, sqerr);
+        AD_LAUNCH_CHECK("head_stats");
+    }
+    return AD_OK;
+}
+
+extern "C" int ad_head_bwd(const void* xh, const float* w, const float* b, const float* inp, const float* target,
+                           void* dxh, float* dw, float* db, int n, int64_t pix_per_img, int ch, int loss_kind, float eps,
+                           float grad_scale, void* ws, size_t ws_bytes, int dtype, void* stream) {
+    AD_REQUIRE(dtype == AD_BF16 || dtype == AD_F32, "ad_head_bwd: bad dtype %d", dtype);
+    AD_REQUIRE(n > 0 && pix_per_img > 0 && target, "ad_head_bwd: bad shape / missing target");
+    AD_REQUIRE(loss_kind == 0 || loss_kind == 1, "ad_head_bwd: loss_kind=%d", loss_kind);
+    int g;
+    AD_REQUIRE(head_group(ch, dtype == AD_BF16 ? 8 : 4, &g), "ad_head_bwd: unsupported ch=%d", ch);
+    const int bpi = head_bpi(pix_per_img, g);
+    const int ncol = ch * 3 + 3;
+    size_t need = (size_t)n * bpi * ncol * sizeof(float);
+    if (!ws || ws_bytes < need) return ad_set_error(AD_ERR_WS, "ad_head_bwd: workspace %zu < %zu", ws_bytes, need);
+    size_t lds = (size_t)(256 / g) * ncol * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(bpi, n);
+    if (dtype == AD_BF16) {
+        HEAD_DISPATCH(head_bwd_kernel<bf16_t, G_><<<grid, 256, lds, s>>>((const bf16_t*)xh, w, b, inp, target, (bf16_t*)dxh,
+                                                                         (float*)ws, pix_per_img, ch, loss_kind, eps,
+                                                                         grad_scale);)
+    } else {
+        HEAD_DISPATCH(head_bwd_kernel<float, G_><<<grid, 256, lds, s>>>((const float*)xh, w, b, inp, target, (float*)dxh,
+                                                                        (float*)ws, pix_per_img, ch, loss_kind, eps,
+                                                                        grad_scale);)
+    }
+    AD_LAUNCH_CHECK("ad_head_bwd");
+    rows_reduce_kernel<<<(ncol + 15) / 16, 256, 0, s>>>((const float*)ws, n * bpi, ncol, dw, ch * 3, db);
+    AD_LAUNCH_CHECK("head rows_reduce");
+    return AD_OK;
+}

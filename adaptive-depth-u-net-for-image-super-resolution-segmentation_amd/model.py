@@ -1,0 +1,612 @@
+"""Adaptive-depth SR U-Net on MI355X: model builder + Keras-shaped Model object.
+
+Mirrors ``build_super_resolution_unet`` / ``conv_block`` / ``build_losses_and_metrics`` and the
+``model.compile / fit / evaluate / __call__ / summary / load_weights`` surface used by
+/root/reference/Super_resolution/code/train_adaptive_unet.py (:200-287, :294-373, :479-494,
+:622-632, :677) and evaluate_model.py (:85-90, :107).  The graph is static (depth is a build-time
+integer, exactly as in the reference); every tensor op runs in a hand-written HIP kernel through the
+C ABI (include/adunet.h).  There is no CPU / PyTorch compute fallback.
+
+HBM layout: activations NHWC in the compute dtype (bf16 or fp32); all trainable parameters live in
+ONE flat fp32 buffer (plus flat gradient / Adam m / Adam v buffers of the same shape) so that the
+optimizer is a single launch and data-parallel gradient exchange is a few large RCCL all-reduces;
+conv kernels additionally keep MFMA-operand packs of their weights in the compute dtype.
+"""
+from __future__ import annotations
+
+import math
+import time
+from collections import OrderedDict
+from dataclasses import dataclass, field
+from typing import Callable, Dict, Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import ops
+from .custom_layers import (ClippedResidualAdd, ResizeByScale, ResizeToMatch, custom_depth_from_scale,
+                            estimate_bottleneck_size)
+
+DEFAULT_BASE_CHANNELS = 64            # train_adaptive_unet.py:56
+DEFAULT_RESIDUAL_HEAD_CHANNELS = 64   # train_adaptive_unet.py:57
+
+
+# --------------------------------------------------------------------------- #
+# Losses / metrics / optimizer descriptors (train_adaptive_unet.py:294-373, :489-494)
+# --------------------------------------------------------------------------- #
+class _Loss:
+    def __init__(self, name: str, kind: int, eps: float):
+        self.__name__ = name
+        self.name = name
+        self.kind = kind
+        self.eps = eps
+
+
+class _Metric:
+    def __init__(self, name: str):
+        self.__name__ = name
+        self.name = name
+
+
+def build_losses_and_metrics(loss_name: str):
+    """Same contract as train_adaptive_unet.py:294-373: returns (loss, [psnr_metric])."""
+    key = loss_name.lower()
+    if key == "charbonnier":
+        return _Loss("charbonnier_loss", 0, 1e-3), [_Metric("psnr")]
+    if key == "l1":
+        return _Loss("l1_loss", 1, 0.0), [_Metric("psnr")]
+    if key == "combined":
+        raise NotImplementedError(
+            "loss 'combined' needs VGG19(weights='imagenet') (train_adaptive_unet.py:337), a remote fetch; "
+            "it is out of scope for the offline MI355X build")
+    raise ValueError(f"Unknown loss '{loss_name}'. Expected one of: 'charbonnier', 'l1', 'combined'.")
+
+
+class Adam:
+    """tf.keras.optimizers.Adam defaults (epsilon 1e-7 outside the bias correction)."""
+
+    def __init__(self, learning_rate: float = 1e-3, beta_1: float = 0.9, beta_2: float = 0.999, epsilon: float = 1e-7):
+        self.learning_rate = learning_rate
+        self.beta_1, self.beta_2, self.epsilon = beta_1, beta_2, epsilon
+        self.iterations = 0
+
+    def lr_at(self, step: int) -> float:
+        lr = self.learning_rate
+        return float(lr(step)) if callable(lr) else float(lr)
+
+
+class History:
+    def __init__(self):
+        self.epoch: List[int] = []
+        self.history: Dict[str, List[float]] = {}
+
+
+# --------------------------------------------------------------------------- #
+# Static graph description
+# --------------------------------------------------------------------------- #
+@dataclass
+class ConvSpec:
+    name: str
+    cin: int
+    cout: int
+    hw: int
+    k: int = 3
+    ln: Optional[str] = None   # name of the LayerNormalization that follows (None: conv+ReLU or head)
+    need_dgrad: bool = True
+
+
+@dataclass
+class LayerRow:
+    name: str
+    type: str
+    shape: Tuple[int, int, int]
+    params: int
+    inbound: List[str] = field(default_factory=list)
+
+
+def _uname(cnt: Dict[str, int], base: str) -> str:
+    k = cnt.get(base, 0)
+    cnt[base] = k + 1
+    return base if k == 0 else f"{base}_{k}"
+
+
+class Model:
+    """Keras-Model-shaped object around the static SR U-Net graph."""
+
+    def __init__(self, scale: float, depth: int, input_size: int, base_channels: int, head_channels: int,
+                 dtype: torch.dtype = torch.bfloat16, device=None, seed: int = 1234):
+        if depth < 1:
+            raise ValueError("depth must be at least 1")
+        if input_size <= 0:
+            raise ValueError("input_size must be positive")
+        self.scale, self.depth, self.input_size = float(scale), int(depth), int(input_size)
+        self.base, self.head = int(base_channels), int(head_channels)
+        self.name = f"U-Net_SR_scale{scale:.2f}_depth{depth}"          # train_adaptive_unet.py:279
+        self.dtype = dtype
+        self.device = torch.device(device) if device is not None else None
+        self.seed = seed
+        # ONE shared down layer and ONE shared up layer, as in the reference (:233-234)
+        self.enc_down = ResizeByScale(scale, name="enc_down")
+        self.dec_up = ResizeToMatch(name="dec_up")
+        self.clip_add = ClippedResidualAdd(name="enhanced_rgb")
+        self.layers: List[LayerRow] = []
+        self.index: "OrderedDict[str, Tuple[int, Tuple[int, ...]]]" = OrderedDict()
+        self.convs: Dict[str, ConvSpec] = {}
+        self._plan: List[tuple] = []
+        self._nparams = 0
+        self._build_graph()
+        # runtime state (allocated on first use)
+        self.P = self.G = self.M = self.V = None
+        self._packs: Dict[str, Tuple[torch.Tensor, Optional[torch.Tensor]]] = {}
+        self._ws: Optional[ops.Workspace] = None
+        self.optimizer: Optional[Adam] = None
+        self.loss = None
+        self.metrics_names: List[str] = []
+        self.stop_training = False
+        self.grad_sync: Optional[Callable[["Model"], float]] = None   # data-parallel hook (parallel.py)
+        self.grad_ready: Optional[Callable[[int], None]] = None       # called with the low offset of finished grads
+
+    # ------------------------------------------------------------------ graph
+    def _register(self, name: str, shape: Tuple[int, ...]):
+        n = int(np.prod(shape))
+        self.index[name] = (self._nparams, tuple(shape))
+        self._nparams += n
+
+    def _add_conv(self, cnt, cin, cout, hw, inbound, k=3, name=None, ln=False, need_dgrad=True) -> ConvSpec:
+        name = name or _uname(cnt, "conv2d")
+        self._register(name + "/kernel", (k, k, cin, cout))
+        self._register(name + "/bias", (cout,))
+        self.layers.append(LayerRow(name, "Conv2D", (hw, hw, cout), k * k * cin * cout + cout, inbound))
+        cs = ConvSpec(name, cin, cout, hw, k=k, need_dgrad=need_dgrad)
+        self.convs[name] = cs
+        return cs
+
+    def _add_block(self, cnt, cin, nf, hw, inbound, first_needs_dgrad=True) -> Tuple[List[ConvSpec], str]:
+        specs = []
+        prev = inbound
+        for i in range(2):
+            cs = self._add_conv(cnt, cin if i == 0 else nf, nf, hw, prev,
+                                need_dgrad=first_needs_dgrad if i == 0 else True)
+            ln = _uname(cnt, "layer_normalization")
+            self._register(ln + "/gamma", (nf,))
+            self._register(ln + "/beta", (nf,))
+            self.layers.append(LayerRow(ln, "LayerNormalization", (hw, hw, nf), 2 * nf, [cs.name]))
+            act = _uname(cnt, "activation")
+            self.layers.append(LayerRow(act, "Activation", (hw, hw, nf), 0, [ln]))
+            cs.ln = ln
+            specs.append(cs)
+            prev = [act]
+        return specs, prev[0]
+
+    def _build_graph(self):
+        cnt: Dict[str, int] = {}
+        p = self.input_size
+        self.layers.append(LayerRow("low_res_input", "InputLayer", (p, p, 3), 0, []))
+        nf, hw, cin, prev = self.base, p, 3, "low_res_input"
+        self.sizes = [p]
+        skip_names: List[str] = []
+        plan: List[tuple] = []
+        down_row = up_row = None
+        for lvl in range(self.depth):                                   # encoder (:245-250)
+            blk, prev = self._add_block(cnt, cin, nf, hw, [prev], first_needs_dgrad=lvl > 0)
+            plan.append(("block", blk, None))
+            skip_names.append(prev)
+            nhw = self.enc_down.output_hw(hw, hw)[0]
+            plan.append(("down", lvl, hw, nhw))
+            if down_row is None:
+                down_row = LayerRow("enc_down", "ResizeByScale", (nhw, nhw, nf), 0, [prev])
+                self.layers.append(down_row)
+            else:
+                down_row.shape = (nhw, nhw, nf)
+                down_row.inbound.append(prev)
+            prev, hw, cin = "enc_down", nhw, nf
+            self.sizes.append(hw)
+            nf *= 2
+        blk, prev = self._add_block(cnt, cin, nf, hw, [prev])            # bottleneck (:253)
+        plan.append(("block", blk, None))
+        for lvl in reversed(range(self.depth)):                         # decoder (:256-262)
+            nf //= 2
+            shw = self.sizes[lvl]
+            plan.append(("up", lvl, hw, shw))
+            if up_row is None:
+                up_row = LayerRow("dec_up", "ResizeToMatch", (shw, shw, 2 * nf), 0, [prev, skip_names[lvl]])
+                self.layers.append(up_row)
+            else:
+                up_row.shape = (shw, shw, 2 * nf)
+                up_row.inbound += [prev, skip_names[lvl]]
+            up = self._add_conv(cnt, 2 * nf, nf, shw, ["dec_up"])
+            plan.append(("upconv", up))
+            cat = _uname(cnt, "concatenate")
+            self.layers.append(LayerRow(cat, "Concatenate", (shw, shw, 2 * nf), 0, [up.name, skip_names[lvl]]))
+            blk, prev = self._add_block(cnt, 2 * nf, nf, shw, [cat])
+            plan.append(("block", blk, lvl))
+            hw = shw
+        blk, prev = self._add_block(cnt, nf, self.head, hw, [prev])      # residual head (:265)
+        plan.append(("block", blk, None))
+        self._add_conv(cnt, self.head, 3, hw, [prev], k=1, name="residual_rgb")
+        plan.append(("head",))
+        self.layers.append(LayerRow("enhanced_rgb", "ClippedResidualAdd", (hw, hw, 3), 0,
+                                    ["low_res_input", "residual_rgb"]))
+        self._plan = plan
+
+    # ------------------------------------------------------------------ Keras-shaped accessors
+    def count_params(self) -> int:
+        return self._nparams
+
+    def summary(self, print_fn: Callable[[str], None] = print, line_length: int = 98):
+        """Text table with the same columns as Keras' functional-model summary."""
+        print_fn(f'Model: "{self.name}"')
+        print_fn("_" * line_length)
+        print_fn(f"{'Layer (type)':<38}{'Output Shape':<24}{'Param #':>12}  Connected to")
+        print_fn("=" * line_length)
+        for row in self.layers:
+            shape = "(None, " + ", ".join(str(v) for v in row.shape) + ")"
+            print_fn(f"{(row.name + ' (' + row.type + ')'):<38}{shape:<24}{row.params:>12,}  {', '.join(row.inbound)}")
+        print_fn("=" * line_length)
+        mb = self._nparams * 4 / 2 ** 20
+        print_fn(f" Total params: {self._nparams:,} ({mb:.2f} MB)")
+        print_fn(f" Trainable params: {self._nparams:,} ({mb:.2f} MB)")
+        print_fn(" Non-trainable params: 0 (0.00 B)")
+
+    # ------------------------------------------------------------------ parameters
+    def _require_device(self):
+        if self.P is not None:
+            return
+        from . import _lib
+        _lib.load()  # raises loudly when the HIP library is missing
+        if not torch.cuda.is_available():
+            raise RuntimeError("adunet_amd needs an MI355X (no GPU visible); there is no CPU fallback")
+        if self.device is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.P = torch.zeros(self._nparams, dtype=torch.float32, device=self.device)
+        self.G = torch.zeros_like(self.P)
+        self.M = torch.zeros_like(self.P)
+        self.V = torch.zeros_like(self.P)
+        self._ws = ops.Workspace(self.device)
+        self.set_weights(self.initial_weights(np.random.default_rng(self.seed)))
+
+    def initial_weights(self, rng: np.random.Generator, head_uniform: float = 0.0) -> Dict[str, np.ndarray]:
+        """Keras initialisers: glorot-uniform kernels, zero biases, gamma 1 / beta 0, zero residual_rgb (:267-274)."""
+        out = {}
+        for name, (_, shape) in self.index.items():
+            if name.endswith("/kernel"):
+                if name.startswith("residual_rgb"):
+                    out[name] = (rng.uniform(-head_uniform, head_uniform, size=shape).astype(np.float32)
+                                 if head_uniform > 0 else np.zeros(shape, np.float32))
+                else:
+                    rf = shape[0] * shape[1]
+                    limit = math.sqrt(6.0 / (shape[2] * rf + shape[3] * rf))
+                    out[name] = rng.uniform(-limit, limit, size=shape).astype(np.float32)
+            elif name.endswith("/gamma"):
+                out[name] = np.ones(shape, np.float32)
+            elif name.startswith("residual_rgb") and head_uniform > 0:
+                out[name] = rng.uniform(-head_uniform, head_uniform, size=shape).astype(np.float32)
+            else:
+                out[name] = np.zeros(shape, np.float32)
+        return out
+
+    def _view(self, buf: torch.Tensor, name: str) -> torch.Tensor:
+        off, shape = self.index[name]
+        return buf[off:off + int(np.prod(shape))].view(shape)
+
+    def param(self, name: str) -> torch.Tensor:
+        return self._view(self.P, name)
+
+    def grad(self, name: str) -> torch.Tensor:
+        return self._view(self.G, name)
+
+    def set_weights(self, weights: Dict[str, np.ndarray]):
+        self._require_device()
+        missing = [k for k in self.index if k not in weights]
+        if missing:
+            raise ValueError(f"missing weights: {missing[:4]}{'...' if len(missing) > 4 else ''}")
+        host = np.empty(self._nparams, np.float32)
+        for name, (off, shape) in self.index.items():
+            w = np.asarray(weights[name], dtype=np.float32)
+            if tuple(w.shape) != shape:
+                raise ValueError(f"{name}: expected shape {shape}, got {tuple(w.shape)}")
+            host[off:off + w.size] = w.reshape(-1)
+        self.P.copy_(torch.from_numpy(host))
+        self._repack()
+
+    def get_weights(self) -> Dict[str, np.ndarray]:
+        self._require_device()
+        host = self.P.cpu().numpy()
+        return OrderedDict((n, host[o:o + int(np.prod(s))].reshape(s).copy()) for n, (o, s) in self.index.items())
+
+    def get_grads(self) -> Dict[str, np.ndarray]:
+        host = self.G.cpu().numpy()
+        return OrderedDict((n, host[o:o + int(np.prod(s))].reshape(s).copy()) for n, (o, s) in self.index.items())
+
+    def save_weights(self, path: str):
+        from safetensors.numpy import save_file
+        save_file({k: np.ascontiguousarray(v) for k, v in self.get_weights().items()}, str(path),
+                  metadata={"model": self.name, "format": "adunet_amd-flat-v1"})
+
+    def load_weights(self, path: str):
+        path = str(path)
+        if path.endswith(".safetensors"):
+            from safetensors.numpy import load_file
+            self.set_weights(load_file(path))
+        elif path.endswith(".npz"):
+            with np.load(path, allow_pickle=False) as z:
+                self.set_weights({k: z[k] for k in z.files})
+        elif path.endswith(".keras") or path.endswith(".h5"):
+            raise RuntimeError("Keras .keras/.h5 archives need h5py, which is not available in this image; "
+                               "convert to .safetensors/.npz with the Keras layer names as keys")
+        else:
+            raise RuntimeError(f"unsupported checkpoint format: {path}")
+
+    def _cin_pad(self, cs: ConvSpec) -> int:
+        g = ops.cin_granule(self.dtype)
+        return (cs.cin + g - 1) // g * g
+
+    def _repack(self):
+        """Refresh the MFMA operand packs (compute dtype) from the fp32 master weights."""
+        for cs in self.convs.values():
+            if cs.k != 3:
+                continue
+            self._packs[cs.name] = ops.conv3x3_pack(self.param(cs.name + "/kernel"), self._cin_pad(cs), self.dtype,
+                                                    want_dgrad=cs.need_dgrad)
+
+    # ------------------------------------------------------------------ forward / backward
+    def _to_dev(self, a) -> torch.Tensor:
+        t = torch.as_tensor(np.asarray(a, dtype=np.float32)) if not isinstance(a, torch.Tensor) else a
+        if t.dim() != 4 or t.shape[-1] != 3:
+            raise ValueError(f"expected a [B,H,W,3] batch, got {tuple(t.shape)}")
+        return t.to(device=self.device, dtype=torch.float32).contiguous()
+
+    def _forward(self, x: torch.Tensor, target: Optional[torch.Tensor], keep: bool):
+        loss_kind = self.loss.kind if self.loss is not None else 0
+        eps = self.loss.eps if self.loss is not None else 1e-3
+        tape: List[tuple] = []
+        cur1, cur2 = ops.pad_channels(x, ops.cin_granule(self.dtype), self.dtype), None
+        skips: List[torch.Tensor] = []
+        for step in self._plan:
+            kind = step[0]
+            if kind == "block":
+                for cs in step[1]:
+                    z = ops.conv3x3_fwd(cur1, cur2, self._packs[cs.name][0], self.param(cs.name + "/bias"), cs.cout)
+                    a, mean, rstd = ops.layernorm_relu_fwd(z, self.param(cs.ln + "/gamma"), self.param(cs.ln + "/beta"))
+                    if keep:
+                        tape.append(("cla", cs, cur1, cur2, z, mean, rstd, step[2]))
+                    cur1, cur2 = a, None
+            elif kind == "down":
+                skips.append(cur1)
+                if keep:
+                    tape.append(("down", step[1], cur1.shape[1], cur1.shape[2]))
+                cur1 = self.enc_down(cur1)
+            elif kind == "up":
+                if keep:
+                    tape.append(("up", cur1.shape[1], cur1.shape[2]))
+                cur1 = self.dec_up((cur1, skips[step[1]]))
+                cur2 = None
+            elif kind == "upconv":
+                cs = step[1]
+                u = ops.conv3x3_fwd(cur1, None, self._packs[cs.name][0], self.param(cs.name + "/bias"), cs.cout, relu=True)
+                if keep:
+                    tape.append(("ca", cs, cur1, u))
+                cur1 = u
+                cur2 = skips[[s for s in self._plan if s[0] == "up" and s[3] == cs.hw][0][1]] if False else None
+                # the skip joins as the second operand of the next block's first conv (virtual concat)
+                lvl = next(s[2] for s in self._plan[self._plan.index(step):] if s[0] == "block")
+                cur2 = skips[lvl]
+            elif kind == "head":
+                w = self.param("residual_rgb/kernel").view(self.head, 3)
+                b = self.param("residual_rgb/bias")
+                out, stats, sqerr = ops.head_fwd(cur1, w, b, x, target, self._ws, loss_kind=loss_kind, eps=eps)
+                if keep:
+                    tape.append(("head", cur1))
+                return out, stats, sqerr, tape
+        raise AssertionError("plan without head")
+
+    def _backward(self, tape: List[tuple], x: torch.Tensor, target: torch.Tensor, grad_scale: float):
+        ws = self._ws
+        dskips: Dict[int, torch.Tensor] = {}
+        d = None
+        while tape:
+            rec = tape.pop()
+            kind = rec[0]
+            if kind == "head":
+                w = self.param("residual_rgb/kernel").view(self.head, 3)
+                d = ops.head_bwd(rec[1], w, self.param("residual_rgb/bias"), x, target,
+                                 self.grad("residual_rgb/kernel").view(self.head, 3), self.grad("residual_rgb/bias"),
+                                 grad_scale, ws, loss_kind=self.loss.kind, eps=self.loss.eps)
+                self._done("residual_rgb/kernel")
+            elif kind == "cla":
+                _, cs, x1, x2, z, mean, rstd, lvl = rec
+                dz = ops.layernorm_relu_bwd(d, z, mean, rstd, self.param(cs.ln + "/gamma"), self.param(cs.ln + "/beta"),
+                                            self.grad(cs.ln + "/gamma"), self.grad(cs.ln + "/beta"),
+                                            self.grad(cs.name + "/bias"), ws)
+                ops.conv3x3_wgrad(x1, x2, dz, self.grad(cs.name + "/kernel"), cs.cin, ws)
+                self._done(cs.name + "/kernel")
+                if not cs.need_dgrad:
+                    d = None
+                elif x2 is not None:
+                    d, dskips[lvl] = ops.conv3x3_fwd(dz, None, self._packs[cs.name][1], None, cs.cin, split=x1.shape[-1])
+                else:
+                    d = ops.conv3x3_fwd(dz, None, self._packs[cs.name][1], None, self._cin_pad(cs))
+            elif kind == "ca":
+                _, cs, xin, u = rec
+                dz = ops.relu_bwd(d, u, self.grad(cs.name + "/bias"), ws)
+                ops.conv3x3_wgrad(xin, None, dz, self.grad(cs.name + "/kernel"), cs.cin, ws)
+                self._done(cs.name + "/kernel")
+                d = ops.conv3x3_fwd(dz, None, self._packs[cs.name][1], None, cs.cin)
+            elif kind == "up":
+                d = self.dec_up.resize_grad(d, rec[1], rec[2])
+            elif kind == "down":
+                _, lvl, h, w = rec
+                d = self.enc_down.resize_grad(d, h, w, out=dskips.pop(lvl))
+
+    def _done(self, name: str):
+        if self.grad_ready is not None:
+            self.grad_ready(self.index[name][0])
+
+    # ------------------------------------------------------------------ Keras call surface
+    def __call__(self, x, training: bool = False):
+        """model(lr, training=False) -> enhanced RGB [B,P,P,3] float32 (same container type as the input)."""
+        self._require_device()
+        as_numpy = not isinstance(x, torch.Tensor)
+        out, _, _, _ = self._forward(self._to_dev(x), None, keep=False)
+        return out.cpu().numpy() if as_numpy else out
+
+    predict_on_batch = __call__
+
+    def compile(self, optimizer=None, loss=None, metrics: Optional[Sequence] = None, jit_compile: bool = False):
+        """model.compile(optimizer=Adam(lr), loss=..., metrics=[psnr], jit_compile=False) (:489-494)."""
+        if jit_compile:
+            raise ValueError("jit_compile=True is not supported (the reference disables XLA as well)")
+        if isinstance(loss, str):
+            loss, default_metrics = build_losses_and_metrics(loss)
+            metrics = metrics if metrics is not None else default_metrics
+        if loss is None or not hasattr(loss, "kind"):
+            raise ValueError("loss must come from build_losses_and_metrics ('charbonnier' or 'l1')")
+        self.optimizer = optimizer if optimizer is not None else Adam()
+        self.loss = loss
+        self.metrics_names = ["loss"] + [getattr(m, "__name__", str(m)) for m in (metrics or [])]
+
+    def forward_loss(self, lr_img, hr_img, keep: bool = False):
+        """Forward + fused loss.  Returns (out, loss_mean [device scalar], psnr_mean [device scalar], tape)."""
+        self._require_device()
+        if self.loss is None:
+            raise RuntimeError("call compile() first")
+        x, t = self._to_dev(lr_img), self._to_dev(hr_img)
+        if x.shape != t.shape:
+            raise ValueError(f"input/target shape mismatch: {tuple(x.shape)} vs {tuple(t.shape)}")
+        out, stats, sqerr, tape = self._forward(x, t, keep=keep)
+        per_img = x.shape[1] * x.shape[2] * 3
+        loss = stats[0] / float(x.shape[0] * per_img)
+        psnr = (-10.0 * torch.log10(sqerr / float(per_img))).mean()    # tf.image.psnr, inf at MSE 0 (:308-311)
+        return out, loss, psnr, (tape, x, t)
+
+    def train_on_batch(self, lr_img, hr_img):
+        """One Keras train step: forward, loss, backward, (gradient all-reduce), Keras-form Adam."""
+        if self.optimizer is None:
+            raise RuntimeError("call compile() first")
+        out, loss, psnr, (tape, x, t) = self.forward_loss(lr_img, hr_img, keep=True)
+        count = float(x.numel())
+        self._backward(tape, x, t, 1.0 / count)
+        gscale = self.grad_sync(self) if self.grad_sync is not None else 1.0
+        opt = self.optimizer
+        opt.iterations += 1
+        ops.adam_step(self.P, self.G, self.M, self.V, opt.iterations, lr=opt.lr_at(opt.iterations - 1),
+                      b1=opt.beta_1, b2=opt.beta_2, eps=opt.epsilon, gscale=gscale)
+        self._repack()
+        return loss, psnr
+
+    def test_on_batch(self, lr_img, hr_img):
+        _, loss, psnr, _ = self.forward_loss(lr_img, hr_img, keep=False)
+        return loss, psnr
+
+    def evaluate(self, dataset: Iterable, steps: Optional[int] = None, return_dict: bool = False, verbose: int = 0):
+        tot_l = tot_p = None
+        nb = 0
+        for batch in dataset:
+            lr_img, hr_img = batch[0], batch[1]
+            l, p = self.test_on_batch(lr_img, hr_img)
+            tot_l = l if tot_l is None else tot_l + l
+            tot_p = p if tot_p is None else tot_p + p
+            nb += 1
+            if steps is not None and nb >= steps:
+                break
+        if nb == 0:
+            raise ValueError("evaluate() received an empty dataset")
+        res = {"loss": float(tot_l) / nb, "psnr": float(tot_p) / nb}
+        return res if return_dict else [res["loss"], res["psnr"]]
+
+    def fit(self, dataset: Iterable, epochs: int = 1, initial_epoch: int = 0, steps_per_epoch: Optional[int] = None,
+            validation_data: Optional[Iterable] = None, validation_steps: Optional[int] = None,
+            callbacks: Optional[Sequence] = None, verbose: int = 2) -> History:
+        """model.fit(train_ds, epochs, initial_epoch, steps_per_epoch, validation_data, validation_steps,
+        callbacks, verbose) (:622-632).  `dataset` is any iterable of (lr, hr) float32 NHWC batches; it is
+        consumed continuously across epochs when steps_per_epoch is given (as tf.data's infinite stream is)."""
+        if self.optimizer is None:
+            raise RuntimeError("call compile() first")
+        callbacks = list(callbacks or [])
+        hist = History()
+        self.stop_training = False
+        for cb in callbacks:
+            if hasattr(cb, "set_model"):
+                cb.set_model(self)
+            if hasattr(cb, "on_train_begin"):
+                cb.on_train_begin({})
+        it = iter(dataset)
+        val_it = iter(validation_data) if validation_data is not None and validation_steps else None
+        for epoch in range(initial_epoch, epochs):
+            if verbose:
+                print(f"Epoch {epoch + 1}/{epochs}", flush=True)
+            t0 = time.time()
+            tot_l = tot_p = None
+            nb = 0
+            while steps_per_epoch is None or nb < steps_per_epoch:
+                try:
+                    batch = next(it)
+                except StopIteration:
+                    if steps_per_epoch is None or nb == 0 and epoch > initial_epoch:
+                        if steps_per_epoch is None:
+                            break
+                    it = iter(dataset)
+                    if steps_per_epoch is None:
+                        break
+                    continue
+                l, p = self.train_on_batch(batch[0], batch[1])
+                tot_l = l if tot_l is None else tot_l + l
+                tot_p = p if tot_p is None else tot_p + p
+                nb += 1
+            if steps_per_epoch is None:
+                it = iter(dataset)
+            if nb == 0:
+                raise ValueError("fit() received an empty dataset")
+            logs = {"loss": float(tot_l) / nb, "psnr": float(tot_p) / nb}
+            if validation_data is not None:
+                if val_it is not None:
+                    vl = [self.test_on_batch(*next(val_it)[:2]) for _ in range(validation_steps)]
+                    logs["val_loss"] = float(sum(v[0] for v in vl)) / len(vl)
+                    logs["val_psnr"] = float(sum(v[1] for v in vl)) / len(vl)
+                else:
+                    res = self.evaluate(validation_data, return_dict=True)
+                    logs["val_loss"], logs["val_psnr"] = res["loss"], res["psnr"]
+            dt = time.time() - t0
+            if verbose:
+                ms = dt * 1000.0 / nb
+                step_txt = f"{ms:.0f}ms/step" if ms >= 1 else f"{ms * 1000:.0f}us/step"
+                print(f"{nb}/{nb} - {dt:.0f}s - {step_txt} - " + " - ".join(f"{k}: {v:.4f}" for k, v in logs.items()),
+                      flush=True)
+            hist.epoch.append(epoch)
+            for k, v in logs.items():
+                hist.history.setdefault(k, []).append(v)
+            for cb in callbacks:
+                if hasattr(cb, "on_epoch_end"):
+                    cb.on_epoch_end(epoch, logs)
+            if self.stop_training:
+                break
+        for cb in callbacks:
+            if hasattr(cb, "on_train_end"):
+                cb.on_train_end({})
+        return hist
+
+
+def conv_block_spec(nf: int) -> str:
+    """The reference's conv_block (:200-210): [Conv3x3 same + bias -> LayerNorm(axis=-1) -> ReLU] x 2."""
+    return f"[Conv2D({nf},3,same) -> LayerNormalization(axis=-1) -> ReLU] x2"
+
+
+def build_super_resolution_unet(scale: float, base_channels: int = DEFAULT_BASE_CHANNELS,
+                                residual_head_channels: int = DEFAULT_RESIDUAL_HEAD_CHANNELS,
+                                depth_override: Optional[int] = None, input_size: int = 256, max_depth: int = 7, *,
+                                dtype: torch.dtype = torch.bfloat16, device=None, seed: int = 1234):
+    """Same signature and return value as train_adaptive_unet.py:217-287: (model, info).
+
+    Extra keyword-only arguments choose the compute dtype (bf16 throughput path / fp32 parity path),
+    the device and the initialiser seed."""
+    depth = (depth_override if depth_override is not None
+             else custom_depth_from_scale(scale, max_depth=max_depth, base_resolution=input_size))
+    model = Model(scale, depth, input_size, base_channels, residual_head_channels, dtype=dtype, device=device, seed=seed)
+    info = {
+        "scale": scale,
+        "depth": depth,
+        "bottleneck_size": estimate_bottleneck_size(input_size, scale, depth),
+        "base_channels": base_channels,
+        "max_depth": max_depth,
+    }
+    return model, info

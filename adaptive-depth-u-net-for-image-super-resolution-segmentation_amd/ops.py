@@ -1,0 +1,200 @@
+"""Thin torch-tensor wrappers over the C ABI (include/adunet.h).
+
+PyTorch is used only to own device memory and streams; every computation below is a HIP kernel of
+csrc/.  All activations are NHWC, dtype torch.bfloat16 (throughput) or torch.float32 (parity).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import AD_BF16, AD_F32, EPI_NONE, EPI_RELU, check
+
+LN_EPS = 1e-3          # Keras LayerNormalization default (train_adaptive_unet.py:203)
+CHARBONNIER_EPS = 1e-3  # train_adaptive_unet.py:314
+
+
+def dt(t: torch.dtype) -> int:
+    if t == torch.bfloat16:
+        return AD_BF16
+    if t == torch.float32:
+        return AD_F32
+    raise ValueError(f"unsupported activation dtype {t}")
+
+
+def _p(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "device, contiguous tensors only"
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def cin_granule(dtype: torch.dtype) -> int:
+    return _lib.load().ad_cin_granule(dt(dtype))
+
+
+class Workspace:
+    """One scratch buffer reused by every call (the ABI never allocates)."""
+
+    def __init__(self, device, nbytes: int = 64 << 20):
+        self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+    def ensure(self, nbytes: int):
+        if self.buf.numel() < nbytes:
+            self.buf = torch.empty(int(nbytes * 1.25), dtype=torch.uint8, device=self.buf.device)
+
+    @property
+    def ptr(self):
+        return self.buf.data_ptr()
+
+    @property
+    def nbytes(self):
+        return self.buf.numel()
+
+
+def pad_channels(x: torch.Tensor, cpad: int, dtype: torch.dtype) -> torch.Tensor:
+    n, h, w, c = x.shape
+    assert x.dtype == torch.float32
+    y = torch.empty((n, h, w, cpad), dtype=dtype, device=x.device)
+    check(_lib.load().ad_pad_channels(_p(x), _p(y), n * h * w, c, cpad, dt(dtype), _stream()), "ad_pad_channels")
+    return y
+
+
+def conv3x3_pack(w_hwio: torch.Tensor, cin_pad: int, dtype: torch.dtype, want_dgrad: bool = True):
+    """fp32 Keras kernel [3,3,cin,cout] -> (w_fwd, w_dgrad) operand tensors."""
+    kh, kw, cin, cout = w_hwio.shape
+    assert (kh, kw) == (3, 3) and w_hwio.dtype == torch.float32
+    wf = torch.empty(9 * cin_pad * cout, dtype=dtype, device=w_hwio.device)
+    wd = torch.empty(9 * cout * cin_pad, dtype=dtype, device=w_hwio.device) if want_dgrad else None
+    check(_lib.load().ad_conv3x3_pack(_p(w_hwio), cin, cout, cin_pad, _p(wf), _p(wd), dt(dtype), _stream()),
+          "ad_conv3x3_pack")
+    return wf, wd
+
+
+def conv3x3_fwd(x1: torch.Tensor, x2: Optional[torch.Tensor], w_packed: torch.Tensor, bias: Optional[torch.Tensor],
+                cout: int, relu: bool = False, split: Optional[int] = None):
+    """y = conv3x3_same(concat(x1, x2)) (+bias) (+ReLU).  With `split`, returns (y[..., :split], y[..., split:])
+    as two separate tensors (dgrad of a concatenated input)."""
+    n, h, w, c1 = x1.shape
+    c2 = x2.shape[-1] if x2 is not None else 0
+    cy1 = split if split is not None else cout
+    y1 = torch.empty((n, h, w, cy1), dtype=x1.dtype, device=x1.device)
+    y2 = torch.empty((n, h, w, cout - cy1), dtype=x1.dtype, device=x1.device) if cy1 < cout else None
+    check(_lib.load().ad_conv3x3_fwd(_p(x1), c1, _p(x2), c2, _p(w_packed), _p(bias), _p(y1), cy1, _p(y2),
+                                     n, h, w, cout, EPI_RELU if relu else EPI_NONE, dt(x1.dtype), _stream()),
+          "ad_conv3x3_fwd")
+    return (y1, y2) if split is not None else y1
+
+
+def conv3x3_wgrad(x1: torch.Tensor, x2: Optional[torch.Tensor], dz: torch.Tensor, dw_out: torch.Tensor, cin_real: int,
+                  ws: Workspace):
+    """dw_out: fp32 [3,3,cin_real,cout] view (e.g. a slice of the flat gradient buffer)."""
+    n, h, w, c1 = x1.shape
+    c2 = x2.shape[-1] if x2 is not None else 0
+    cout = dz.shape[-1]
+    lib = _lib.load()
+    need = lib.ad_conv3x3_wgrad_ws_bytes(n, h, w, c1 + c2, cout, dt(x1.dtype))
+    ws.ensure(need)
+    check(lib.ad_conv3x3_wgrad(_p(x1), c1, _p(x2), c2, _p(dz), _p(dw_out), cin_real, n, h, w, cout,
+                               ws.ptr, ws.nbytes, dt(x1.dtype), _stream()), "ad_conv3x3_wgrad")
+
+
+def layernorm_relu_fwd(z: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, relu: bool = True,
+                       eps: float = LN_EPS):
+    c = z.shape[-1]
+    npix = z.numel() // c
+    y = torch.empty_like(z)
+    mean = torch.empty(npix, dtype=torch.float32, device=z.device)
+    rstd = torch.empty(npix, dtype=torch.float32, device=z.device)
+    check(_lib.load().ad_layernorm_relu_fwd(_p(z), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), npix, c, eps,
+                                            int(relu), dt(z.dtype), _stream()), "ad_layernorm_relu_fwd")
+    return y, mean, rstd
+
+
+def layernorm_relu_bwd(dy, z, mean, rstd, gamma, beta, dgamma, dbeta, dbias, ws: Workspace, relu: bool = True):
+    c = z.shape[-1]
+    npix = z.numel() // c
+    dz = torch.empty_like(z)
+    lib = _lib.load()
+    ws.ensure(lib.ad_layernorm_bwd_ws_bytes(npix, c))
+    check(lib.ad_layernorm_relu_bwd(_p(dy), _p(z), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dz), _p(dgamma),
+                                    _p(dbeta), _p(dbias), npix, c, int(relu), ws.ptr, ws.nbytes, dt(z.dtype),
+                                    _stream()), "ad_layernorm_relu_bwd")
+    return dz
+
+
+def relu_bwd(dy, y, dbias, ws: Workspace):
+    c = y.shape[-1]
+    npix = y.numel() // c
+    dz = torch.empty_like(y)
+    lib = _lib.load()
+    ws.ensure(lib.ad_layernorm_bwd_ws_bytes(npix, c))
+    check(lib.ad_relu_bwd(_p(dy), _p(y), _p(dz), _p(dbias), npix, c, ws.ptr, ws.nbytes, dt(y.dtype), _stream()),
+          "ad_relu_bwd")
+    return dz
+
+
+class ResampleTables:
+    """Device copies of the per-axis tap tables of one separable banded map."""
+
+    def __init__(self, starts_y, weights_y, starts_x, weights_x, device):
+        self.ky, self.kx = weights_y.shape[1], weights_x.shape[1]
+        self.oh, self.ow = weights_y.shape[0], weights_x.shape[0]
+        self.sy = torch.tensor(np.ascontiguousarray(starts_y, dtype=np.int32), device=device)
+        self.sx = torch.tensor(np.ascontiguousarray(starts_x, dtype=np.int32), device=device)
+        self.wy = torch.tensor(np.ascontiguousarray(weights_y, dtype=np.float32), device=device)
+        self.wx = torch.tensor(np.ascontiguousarray(weights_x, dtype=np.float32), device=device)
+
+
+def resample(x: torch.Tensor, tab: ResampleTables, out: Optional[torch.Tensor] = None, accumulate: bool = False):
+    n, h, w, c = x.shape
+    if out is None:
+        assert not accumulate
+        out = torch.empty((n, tab.oh, tab.ow, c), dtype=x.dtype, device=x.device)
+    check(_lib.load().ad_resample(_p(x), _p(out), _p(tab.sy), _p(tab.wy), tab.ky, _p(tab.sx), _p(tab.wx), tab.kx,
+                                  n, h, w, tab.oh, tab.ow, c, int(accumulate), dt(x.dtype), _stream()), "ad_resample")
+    return out
+
+
+def head_fwd(xh, w, b, inp, target, ws: Workspace, loss_kind: int = 0, eps: float = CHARBONNIER_EPS):
+    """Returns (out[n,h,w,3] fp32, stats[1] loss SUM or None, sqerr[n] or None)."""
+    n, h, wd, ch = xh.shape
+    out = torch.empty((n, h, wd, 3), dtype=torch.float32, device=xh.device)
+    stats = sqerr = None
+    if target is not None:
+        stats = torch.empty(1, dtype=torch.float32, device=xh.device)
+        sqerr = torch.empty(n, dtype=torch.float32, device=xh.device)
+    lib = _lib.load()
+    ws.ensure(lib.ad_head_ws_bytes(n, ch))
+    check(lib.ad_head_fwd(_p(xh), _p(w), _p(b), _p(inp), _p(target), _p(out), _p(stats), _p(sqerr), n, h * wd, ch,
+                          loss_kind, eps, ws.ptr, ws.nbytes, dt(xh.dtype), _stream()), "ad_head_fwd")
+    return out, stats, sqerr
+
+
+def head_bwd(xh, w, b, inp, target, dw, db, grad_scale: float, ws: Workspace, loss_kind: int = 0,
+             eps: float = CHARBONNIER_EPS):
+    n, h, wd, ch = xh.shape
+    dxh = torch.empty_like(xh)
+    lib = _lib.load()
+    ws.ensure(lib.ad_head_ws_bytes(n, ch))
+    check(lib.ad_head_bwd(_p(xh), _p(w), _p(b), _p(inp), _p(target), _p(dxh), _p(dw), _p(db), n, h * wd, ch, loss_kind,
+                          eps, grad_scale, ws.ptr, ws.nbytes, dt(xh.dtype), _stream()), "ad_head_bwd")
+    return dxh
+
+
+def adam_step(p, g, m, v, step: int, lr=1e-4, b1=0.9, b2=0.999, eps=1e-7, gscale: float = 1.0):
+    check(_lib.load().ad_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, b1, b2, eps, step, gscale, _stream()),
+          "ad_adam_step")
+
+
+def cast(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    y = torch.empty(x.shape, dtype=dtype, device=x.device)
+    check(_lib.load().ad_cast(_p(x), dt(x.dtype), _p(y), dt(dtype), x.numel(), _stream()), "ad_cast")
+    return y

@@ -1,0 +1,169 @@
+/*
+ * adunet.h -- C ABI of the MI355X (gfx950) adaptive-depth U-Net hot path.
+ *
+ * This is the drop-in boundary.  The reference
+ * (KunalNN/Adaptive-Depth-U-Net-for-Image-Super-Resolution-Segmentation) has no
+ * FFI of its own: its seam is the Keras Layer/Model call surface, below which sit
+ * TensorFlow ops (cuDNN / Eigen kernels).  Each entry point below replaces one of
+ * those TensorFlow ops at the reference call site cited next to it.
+ *
+ * Conventions
+ *  - All tensor pointers are DEVICE pointers owned by the caller, NHWC, dense.
+ *  - `dtype` selects the activation element type: AD_F32 (parity path) or
+ *    AD_BF16 (throughput path; fp32 accumulation, fp32 statistics).
+ *    Parameters, gradients, statistics and reduction outputs are always fp32.
+ *  - `stream` is a hipStream_t passed as void*; every call is asynchronous on it.
+ *  - No allocation, no synchronisation, no hidden state: scratch memory is passed
+ *    in as (`ws`, `ws_bytes`); ad_*_ws_bytes() says how much a call needs.
+ *  - Return value: 0 = ok, negative = error (AD_ERR_*); ad_last_error() returns a
+ *    thread-local message.  No exceptions cross the boundary.
+ *  - One caller thread per device (the reference drives the model from a single
+ *    Python thread: SURVEY 8b).
+ */
+#ifndef ADUNET_H
+#define ADUNET_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AD_F32 0
+#define AD_BF16 1
+
+#define AD_OK 0
+#define AD_ERR_ARG (-1)      /* bad shape / unsupported configuration */
+#define AD_ERR_WS (-2)       /* workspace too small */
+#define AD_ERR_LAUNCH (-3)   /* HIP launch error */
+
+#define AD_EPI_NONE 0
+#define AD_EPI_RELU 1
+
+int ad_version(void);
+const char* ad_last_error(void);
+
+/* Channel granularity of the conv kernels for `dtype`: Cin of every conv input
+ * tensor must be a multiple of this (32 for bf16, 16 for f32); the 3-channel network
+ * input is zero-padded to it by ad_pad_channels(). */
+int ad_cin_granule(int dtype);
+
+/* ---------------------------------------------------------------- packing -- */
+
+/* x[npix, c] fp32 -> y[npix, cpad] (dtype), zero channel padding.
+ * Feeds the first Conv2D (train_adaptive_unet.py:202 on `low_res_input`). */
+int ad_pad_channels(const float* x, void* y, int64_t npix, int c, int cpad, int dtype, void* stream);
+
+/* Keras HWIO fp32 kernel [3,3,cin,cout] -> MFMA operand layouts (dtype):
+ *   w_fwd  : [9][cin_pad/KV][cout][KV]            (KV = 16 B / sizeof(dtype))
+ *   w_dgrad: [9 (taps rotated 180)][cout_pad/KV][cin_pad][KV]  (may be NULL)
+ * cout must be a multiple of 64 for w_dgrad (it becomes the contraction axis). */
+int ad_conv3x3_pack(const float* w_hwio, int cin, int cout, int cin_pad,
+                    void* w_fwd, void* w_dgrad, int dtype, void* stream);
+
+/* ------------------------------------------------------------ convolution -- */
+
+/* Conv2D 3x3, stride 1, padding "same" (+bias, +optional ReLU):
+ *   L.Conv2D(nf, 3, padding="same")            train_adaptive_unet.py:202,207
+ *   L.Conv2D(nf, 3, ..., activation="relu")    train_adaptive_unet.py:259
+ * Input is the *virtual concatenation* of x1[n,h,w,c1] and x2[n,h,w,c2] along
+ * channels (L.Concatenate, :261); pass x2 = NULL, c2 = 0 for a single input.
+ * Output channels [0,cy1) go to y1[n,h,w,cy1], the rest to y2[n,h,w,cout-cy1]
+ * (used when the same kernel runs as dgrad of a concatenated input); pass
+ * y2 = NULL, cy1 = cout normally.  cout % 64 == 0, c1 % granule == 0, c2 % granule == 0,
+ * cy1 % 64 == 0. */
+int ad_conv3x3_fwd(const void* x1, int c1, const void* x2, int c2,
+                   const void* w_packed, const float* bias,
+                   void* y1, int cy1, void* y2,
+                   int n, int h, int w, int cout, int epilogue,
+                   int dtype, void* stream);
+
+/* Weight gradient of the same convolution (TF Conv2DBackpropFilter):
+ *   dw_hwio[3,3,c1+c2,cout] (fp32, Keras layout) = sum_pixels x(+tap) * dz
+ * Only the first `cin_real` input channels are written (3 for the padded first layer).
+ * Deterministic: per-workgroup partial slabs in `ws`, summed in a fixed order. */
+size_t ad_conv3x3_wgrad_ws_bytes(int n, int h, int w, int cin, int cout, int dtype);
+int ad_conv3x3_wgrad(const void* x1, int c1, const void* x2, int c2, const void* dz,
+                     float* dw_hwio, int cin_real,
+                     int n, int h, int w, int cout,
+                     void* ws, size_t ws_bytes, int dtype, void* stream);
+
+/* ---------------------------------------------------- LayerNorm (+ ReLU) -- */
+
+/* L.LayerNormalization(axis=-1) (eps 1e-3) followed by L.Activation("relu"):
+ * train_adaptive_unet.py:203-204,208-209.  Statistics in fp32; mean/rstd [npix] are
+ * saved for the backward pass.  relu = 0 gives plain LayerNorm. */
+int ad_layernorm_relu_fwd(const void* z, const float* gamma, const float* beta,
+                          void* y, float* mean, float* rstd,
+                          int64_t npix, int c, float eps, int relu, int dtype, void* stream);
+
+/* Backward of the pair above.  dy = gradient w.r.t. the ReLU output.
+ * Produces dz (same dtype) and overwrites fp32 dgamma[c], dbeta[c] and dbias[c]
+ * (= column sums of dz: the gradient of the preceding conv's bias); deterministic. */
+size_t ad_layernorm_bwd_ws_bytes(int64_t npix, int c);
+int ad_layernorm_relu_bwd(const void* dy, const void* z, const float* mean, const float* rstd,
+                          const float* gamma, const float* beta,
+                          void* dz, float* dgamma, float* dbeta, float* dbias,
+                          int64_t npix, int c, int relu,
+                          void* ws, size_t ws_bytes, int dtype, void* stream);
+
+/* ReLU backward for the conv+ReLU up-convolution (train_adaptive_unet.py:259):
+ * dz = dy * (y > 0); dbias[c] = column sums of dz. */
+int ad_relu_bwd(const void* dy, const void* y, void* dz, float* dbias,
+                int64_t npix, int c, void* ws, size_t ws_bytes, int dtype, void* stream);
+
+/* ----------------------------------------------------------------- resize -- */
+
+/* tf.image.resize(..., "bilinear", antialias=True) and its gradient
+ * (shared/custom_layers.py:102 ResizeByScale, :124 ResizeToMatch), as a separable
+ * banded linear map with host-precomputed per-axis tap tables:
+ *   y[n,oy,ox,c] (+)= sum_{a<ky, b<kx} wy[oy*ky+a] * wx[ox*kx+b] * x[n, sy[oy]+a, sx[ox]+b, c]
+ * Taps beyond the band carry weight 0 and a clamped index, so the same entry point
+ * computes the forward map and (with transposed tables) the backward map.
+ * Arithmetic is fp32 regardless of dtype, as in the reference. */
+int ad_resample(const void* x, void* y,
+                const int* sy, const float* wy, int ky,
+                const int* sx, const float* wx, int kx,
+                int n, int h, int w, int oh, int ow, int c,
+                int accumulate, int dtype, void* stream);
+
+/* -------------------------------------------------------------- head+loss -- */
+
+/* residual_rgb 1x1 Conv2D (train_adaptive_unet.py:267-274) + ClippedResidualAdd
+ * (shared/custom_layers.py:136-139) [+ Charbonnier / L1 loss and squared error
+ * (:308-334) when `target` != NULL], fused in one pass over xh[npix, ch]:
+ *   out = clip(inp + xh @ w[ch,3] + b, 0, 1)           (fp32, [npix,3])
+ *   stats[0] = sum sqrt((t-out)^2 + eps^2)   (loss_kind 0, Charbonnier)
+ *            | sum |t-out|                   (loss_kind 1, L1)
+ *   sqerr[img] = sum over the image of (t-out)^2   (PSNR / MSE numerator)
+ * stats/sqerr are overwritten (deterministic two-stage reduction through ws). */
+size_t ad_head_ws_bytes(int n, int ch);
+int ad_head_fwd(const void* xh, const float* w, const float* b, const float* inp,
+                const float* target, float* out, float* stats, float* sqerr,
+                int n, int64_t pix_per_img, int ch, int loss_kind, float eps,
+                void* ws, size_t ws_bytes, int dtype, void* stream);
+
+/* Backward of the fused head: with g = dLoss/dout * [0 <= inp+r <= 1] * grad_scale
+ *   dxh[npix,ch] = g @ w^T ; dw[ch,3] = xh^T @ g ; db[3] = sum g          */
+int ad_head_bwd(const void* xh, const float* w, const float* b, const float* inp,
+                const float* target, void* dxh, float* dw, float* db,
+                int n, int64_t pix_per_img, int ch, int loss_kind, float eps, float grad_scale,
+                void* ws, size_t ws_bytes, int dtype, void* stream);
+
+/* -------------------------------------------------------------- optimizer -- */
+
+/* Keras-form Adam (tf.keras.optimizers.Adam, train_adaptive_unet.py:489-494):
+ *   m += (g-m)(1-b1); v += (g*g-v)(1-b2); p -= lr*sqrt(1-b2^t)/(1-b1^t) * m/(sqrt(v)+eps)
+ * over flat fp32 buffers; `gscale` multiplies g first (1/world_size after all-reduce). */
+int ad_adam_step(float* p, const float* g, float* m, float* v, int64_t count,
+                 float lr, float b1, float b2, float eps, int step, float gscale, void* stream);
+
+/* -------------------------------------------------------------- utilities -- */
+
+int ad_cast(const void* x, int dtype_in, void* y, int dtype_out, int64_t count, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADUNET_H */

@@ -1,0 +1,258 @@
+"""GPU parity tests, op by op: HIP kernels (through the C ABI) vs the NumPy oracle.
+
+Tolerances
+* float32 path: 1e-3 relative to the tensor's max magnitude (north_star's bar); observed ~1e-6.
+* bfloat16 path: inputs/weights are rounded to bf16 *before* the oracle runs, so the remaining error
+  is fp32 accumulation order plus one bf16 rounding of the stored result: 2^-8 relative per element
+  -> we allow 1.5e-2 of the tensor's max magnitude (stated per test).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ops as ref
+
+pytestmark = pytest.mark.gpu
+
+F32, BF16 = torch.float32, torch.bfloat16
+TOL = {F32: 1e-3, BF16: 1.5e-2}
+
+
+def to_dev(a, dtype, device):
+    return torch.tensor(np.ascontiguousarray(a), dtype=torch.float32, device=device).to(dtype).contiguous()
+
+
+def rnd(a, dtype):
+    """Round a float64 array through the storage dtype (so that the oracle sees what the kernel sees)."""
+    return torch.tensor(a, dtype=torch.float32).to(dtype).to(torch.float64).numpy()
+
+
+def relerr(got, want):
+    got = got.detach().to(torch.float64).cpu().numpy()
+    return float(np.abs(got - want).max() / (np.abs(want).max() + 1e-30))
+
+
+CONV_SHAPES = [
+    # n, h, w, c1, c2, cout
+    (2, 16, 16, 32, 0, 64),
+    (1, 37, 29, 64, 0, 64),     # ragged tiles
+    (3, 8, 8, 64, 0, 128),      # 4 images per tile
+    (5, 4, 4, 64, 64, 64),      # 16 images per tile + virtual concat
+    (7, 2, 2, 128, 0, 64),      # 64 images per tile
+    (9, 1, 1, 64, 0, 128),      # 1x1 maps: centre tap only
+    (2, 20, 20, 64, 64, 64),    # virtual concat
+    (1, 3, 5, 32, 0, 64),
+]
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("shape", CONV_SHAPES)
+def test_conv3x3_fwd(device, dtype, shape):
+    from adunet_amd import ops
+    n, h, w, c1, c2, cout = shape
+    rng = np.random.default_rng(hash(shape) % 2**31)
+    x = rnd(rng.standard_normal((n, h, w, c1 + c2)), dtype)
+    wk = rnd(rng.standard_normal((3, 3, c1 + c2, cout)) * 0.1, dtype)
+    b = rng.standard_normal(cout).astype(np.float32).astype(np.float64)
+    want = ref.conv2d_same_fwd(x, wk, b)
+    x1 = to_dev(x[..., :c1], dtype, device)
+    x2 = to_dev(x[..., c1:], dtype, device) if c2 else None
+    wf, _ = ops.conv3x3_pack(torch.tensor(wk, dtype=F32, device=device), c1 + c2, dtype, want_dgrad=False)
+    bias = torch.tensor(b, dtype=F32, device=device)
+    y = ops.conv3x3_fwd(x1, x2, wf, bias, cout, relu=False)
+    assert relerr(y, want) < TOL[dtype]
+    y = ops.conv3x3_fwd(x1, x2, wf, bias, cout, relu=True)
+    assert relerr(y, np.maximum(want, 0)) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("shape", [(2, 16, 16, 64, 0, 64), (1, 21, 13, 64, 64, 128), (5, 4, 4, 128, 0, 64), (9, 1, 1, 64, 0, 64)])
+def test_conv3x3_dgrad(device, dtype, shape):
+    """dgrad = the same kernel on the rotated/transposed weight pack, with split outputs."""
+    from adunet_amd import ops
+    n, h, w, c1, c2, cout = shape
+    cin = c1 + c2
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((n, h, w, cin))
+    wk = rnd(rng.standard_normal((3, 3, cin, cout)) * 0.1, dtype)
+    dz = rnd(rng.standard_normal((n, h, w, cout)), dtype)
+    want, _, _ = ref.conv2d_same_bwd(x, wk, dz)
+    _, wd = ops.conv3x3_pack(torch.tensor(wk, dtype=F32, device=device), cin, dtype)
+    dzd = to_dev(dz, dtype, device)
+    if c2:
+        d1, d2 = ops.conv3x3_fwd(dzd, None, wd, None, cin, split=c1)
+        assert relerr(d1, want[..., :c1]) < TOL[dtype]
+        assert relerr(d2, want[..., c1:]) < TOL[dtype]
+    else:
+        d1 = ops.conv3x3_fwd(dzd, None, wd, None, cin)
+        assert relerr(d1, want) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("shape", CONV_SHAPES + [(4, 48, 48, 64, 0, 64)])
+def test_conv3x3_wgrad(device, ws, dtype, shape):
+    from adunet_amd import ops
+    n, h, w, c1, c2, cout = shape
+    cin = c1 + c2
+    rng = np.random.default_rng(2)
+    x = rnd(rng.standard_normal((n, h, w, cin)), dtype)
+    dz = rnd(rng.standard_normal((n, h, w, cout)), dtype)
+    _, want, _ = ref.conv2d_same_bwd(x, np.zeros((3, 3, cin, cout)), dz, need_dx=False)
+    x1 = to_dev(x[..., :c1], dtype, device)
+    x2 = to_dev(x[..., c1:], dtype, device) if c2 else None
+    dw = torch.full((3, 3, cin, cout), float("nan"), dtype=F32, device=device)
+    ops.conv3x3_wgrad(x1, x2, to_dev(dz, dtype, device), dw, cin, ws)
+    assert relerr(dw, want) < 1e-3   # fp32 accumulation of exactly-representable inputs in both paths
+    dw2 = torch.full((3, 3, cin, cout), float("nan"), dtype=F32, device=device)
+    ops.conv3x3_wgrad(x1, x2, to_dev(dz, dtype, device), dw2, cin, ws)
+    assert torch.equal(dw, dw2), "wgrad must be bitwise deterministic"
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_first_layer_padded_channels(device, ws, dtype):
+    """3-channel network input zero-padded to the conv granule; wgrad writes only the 3 real rows."""
+    from adunet_amd import ops
+    rng = np.random.default_rng(3)
+    n, h, w, cout = 2, 24, 24, 64
+    x = rng.random((n, h, w, 3)).astype(np.float32)
+    wk = rnd(rng.standard_normal((3, 3, 3, cout)) * 0.2, dtype)
+    g = ops.cin_granule(dtype)
+    xp = ops.pad_channels(torch.tensor(x, device=device), g, dtype)
+    xr = xp.to(torch.float64).cpu().numpy()[..., :3]
+    assert float(xp.to(F32)[..., 3:].abs().max()) == 0.0
+    wf, _ = ops.conv3x3_pack(torch.tensor(wk, dtype=F32, device=device), g, dtype, want_dgrad=False)
+    y = ops.conv3x3_fwd(xp, None, wf, None, cout)
+    assert relerr(y, ref.conv2d_same_fwd(xr, wk, None)) < TOL[dtype]
+    dz = rnd(rng.standard_normal((n, h, w, cout)), dtype)
+    _, want, _ = ref.conv2d_same_bwd(xr, wk, dz, need_dx=False)
+    dw = torch.empty((3, 3, 3, cout), dtype=F32, device=device)
+    ops.conv3x3_wgrad(xp, None, to_dev(dz, dtype, device), dw, 3, ws)
+    assert relerr(dw, want) < 1e-3
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("c", [64, 128, 256, 512, 1024, 2048])
+@pytest.mark.parametrize("relu", [True, False])
+def test_layernorm_relu(device, ws, dtype, c, relu):
+    from adunet_amd import ops
+    rng = np.random.default_rng(c)
+    npix = 3 * 7 * 5
+    z = rnd(rng.standard_normal((3, 7, 5, c)) * 2 + 0.3, dtype)
+    gamma = rng.uniform(0.5, 1.5, c).astype(np.float32).astype(np.float64)
+    beta = rng.uniform(-0.5, 0.5, c).astype(np.float32).astype(np.float64)
+    y, cache = ref.layernorm_fwd(z, gamma, beta)
+    a = ref.relu_fwd(y) if relu else y
+    zd = to_dev(z, dtype, device)
+    gd, bd = torch.tensor(gamma, dtype=F32, device=device), torch.tensor(beta, dtype=F32, device=device)
+    got, mean, rstd = ops.layernorm_relu_fwd(zd, gd, bd, relu=relu)
+    assert relerr(got, a) < TOL[dtype]
+    assert relerr(mean, z.mean(-1).reshape(-1)) < 1e-5
+    assert relerr(rstd, cache[1].reshape(-1)) < 1e-5
+    dy = rnd(rng.standard_normal(z.shape), dtype)
+    dyl = ref.relu_bwd(dy, a) if relu else dy
+    dz, dg, db = ref.layernorm_bwd(dyl, gamma, cache)
+    dgam = torch.empty(c, dtype=F32, device=device)
+    dbet = torch.empty(c, dtype=F32, device=device)
+    dbias = torch.empty(c, dtype=F32, device=device)
+    gz = ops.layernorm_relu_bwd(to_dev(dy, dtype, device), zd, mean, rstd, gd, bd, dgam, dbet, dbias, ws, relu=relu)
+    assert relerr(gz, dz) < TOL[dtype]
+    assert relerr(dgam, dg) < 1e-3
+    assert relerr(dbet, db) < 1e-3
+    assert relerr(dbias, dz.reshape(-1, c).sum(0)) < (1e-3 if dtype == F32 else 3e-2)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_relu_bwd(device, ws, dtype):
+    from adunet_amd import ops
+    rng = np.random.default_rng(5)
+    y = np.maximum(rnd(rng.standard_normal((2, 9, 11, 128)), dtype), 0)
+    dy = rnd(rng.standard_normal(y.shape), dtype)
+    want = ref.relu_bwd(dy, y)
+    dbias = torch.empty(128, dtype=F32, device=device)
+    dz = ops.relu_bwd(to_dev(dy, dtype, device), to_dev(y, dtype, device), dbias, ws)
+    assert relerr(dz, want) == 0.0
+    assert relerr(dbias, want.reshape(-1, 128).sum(0)) < 1e-3
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("sizes", [(32, 16), (37, 23), (64, 16), (16, 4), (4, 1), (1, 4), (4, 16), (23, 37), (52, 11), (11, 52)])
+def test_resize_aa_fwd_bwd(device, dtype, sizes):
+    from adunet_amd import ops, resize_tables as rt
+    hin, hout = sizes
+    rng = np.random.default_rng(hin * 100 + hout)
+    c = 64
+    x = rnd(rng.standard_normal((2, hin, hin, c)), dtype)
+    want = ref.resize_aa_fwd(x, hout, hout)
+    s, wgt = rt.aa_spans(hin, hout)
+    tab = ops.ResampleTables(s, wgt, s, wgt, device)
+    y = ops.resample(to_dev(x, dtype, device), tab)
+    assert relerr(y, want) < (1e-5 if dtype == F32 else TOL[BF16])
+    dy = rnd(rng.standard_normal(want.shape), dtype)
+    wantb = ref.resize_aa_bwd(dy, hin, hin)
+    st, wt = rt.aa_spans_transposed(hin, hout)
+    tabt = ops.ResampleTables(st, wt, st, wt, device)
+    base = rnd(rng.standard_normal(x.shape), dtype)
+    acc = to_dev(base, dtype, device)
+    ops.resample(to_dev(dy, dtype, device), tabt, out=acc, accumulate=True)
+    assert relerr(acc, wantb + base) < (1e-5 if dtype == F32 else TOL[BF16])
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("loss_kind", [0, 1])
+def test_head_fwd_bwd(device, ws, dtype, loss_kind):
+    from adunet_amd import ops
+    rng = np.random.default_rng(7 + loss_kind)
+    n, h, w, ch = 3, 19, 17, 64
+    xh = rnd(np.maximum(rng.standard_normal((n, h, w, ch)), 0), dtype)
+    wk = rng.uniform(-0.05, 0.05, (1, 1, ch, 3)).astype(np.float32).astype(np.float64)
+    b = rng.uniform(-0.05, 0.05, 3).astype(np.float32).astype(np.float64)
+    hr = rng.random((n, h, w, 3)).astype(np.float32).astype(np.float64)
+    lr = np.clip(hr + 0.3 * rng.standard_normal(hr.shape), -0.2, 1.2).astype(np.float32).astype(np.float64)  # exercise the clip
+    r = ref.conv2d_same_fwd(xh, wk, b)
+    out, pre = ref.clip_add_fwd(lr, r)
+    loss = ref.charbonnier_fwd(hr, out) if loss_kind == 0 else ref.l1_fwd(hr, out)
+    dout = ref.charbonnier_bwd(hr, out) if loss_kind == 0 else ref.l1_bwd(hr, out)
+    dr = ref.clip_add_bwd(dout, pre)
+    dxh, dw, db = ref.conv2d_same_bwd(xh, wk, dr)
+    f = lambda a: torch.tensor(a, dtype=F32, device=device)
+    xd = to_dev(xh, dtype, device)
+    wd_, bd_ = f(wk.reshape(ch, 3)), f(b)
+    got, stats, sqerr = ops.head_fwd(xd, wd_, bd_, f(lr), f(hr), ws, loss_kind=loss_kind)
+    assert relerr(got, out) < 1e-5
+    assert abs(float(stats[0]) / hr.size - loss) < 1e-5 * max(1.0, abs(loss))
+    assert relerr(sqerr, ((hr - out) ** 2).reshape(n, -1).sum(1)) < 1e-4
+    got2, _, _ = ops.head_fwd(xd, wd_, bd_, f(lr), None, ws)
+    assert torch.equal(got, got2)
+    gw = torch.empty((ch, 3), dtype=F32, device=device)
+    gb = torch.empty(3, dtype=F32, device=device)
+    gx = ops.head_bwd(xd, wd_, bd_, f(lr), f(hr), gw, gb, 1.0 / hr.size, ws, loss_kind=loss_kind)
+    assert relerr(gx, dxh) < TOL[dtype]
+    assert relerr(gw, dw.reshape(ch, 3)) < 1e-3
+    assert relerr(gb, db) < 1e-3
+
+
+def test_adam_matches_keras_form(device):
+    from adunet_amd import ops
+    rng = np.random.default_rng(11)
+    cnt = 10007
+    p = rng.standard_normal(cnt).astype(np.float32)
+    m = np.zeros(cnt, np.float32)
+    v = np.zeros(cnt, np.float32)
+    pd, md, vd = (torch.tensor(a, device=device) for a in (p, m, v))
+    p64, m64, v64 = p.astype(np.float64), m.astype(np.float64), v.astype(np.float64)
+    for step in range(1, 6):
+        g = (rng.standard_normal(cnt) * 10 ** rng.uniform(-6, 0, cnt)).astype(np.float32)
+        ref.adam_step(p64, g.astype(np.float64), m64, v64, step, lr=1e-3)
+        ops.adam_step(pd, torch.tensor(g, device=device), md, vd, step, lr=1e-3)
+    assert relerr(pd, p64) < 1e-6
+    assert relerr(md, m64) < 1e-4 and relerr(vd, v64) < 1e-4  # fp32 state vs float64 oracle
+
+
+def test_bad_arguments_raise(device):
+    from adunet_amd import ops
+    x = torch.zeros((1, 4, 4, 24), dtype=BF16, device=device)  # 24 is not a multiple of the bf16 granule
+    with pytest.raises(ValueError):
+        ops.conv3x3_fwd(x, None, x, None, 64)
+    with pytest.raises(ValueError):
+        ops.layernorm_relu_fwd(torch.zeros((4, 24), dtype=BF16, device=device).reshape(1, 2, 2, 24),
+                               torch.ones(24, device=device), torch.zeros(24, device=device))
