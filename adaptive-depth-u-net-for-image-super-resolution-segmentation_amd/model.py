@@ -215,7 +215,7 @@ class Model:
                 up_row.shape = (shw, shw, 2 * nf)
                 up_row.inbound += [prev, skip_names[lvl]]
             up = self._add_conv(cnt, 2 * nf, nf, shw, ["dec_up"])
-            plan.append(("upconv", up))
+            plan.append(("upconv", up, lvl))
             cat = _uname(cnt, "concatenate")
             self.layers.append(LayerRow(cat, "Concatenate", (shw, shw, 2 * nf), 0, [up.name, skip_names[lvl]]))
             blk, prev = self._add_block(cnt, 2 * nf, nf, shw, [cat])
@@ -382,15 +382,12 @@ class Model:
                 cur1 = self.dec_up((cur1, skips[step[1]]))
                 cur2 = None
             elif kind == "upconv":
-                cs = step[1]
+                cs, lvl = step[1], step[2]
                 u = ops.conv3x3_fwd(cur1, None, self._packs[cs.name][0], self.param(cs.name + "/bias"), cs.cout, relu=True)
                 if keep:
                     tape.append(("ca", cs, cur1, u))
-                cur1 = u
-                cur2 = skips[[s for s in self._plan if s[0] == "up" and s[3] == cs.hw][0][1]] if False else None
-                # the skip joins as the second operand of the next block's first conv (virtual concat)
-                lvl = next(s[2] for s in self._plan[self._plan.index(step):] if s[0] == "block")
-                cur2 = skips[lvl]
+                # L.Concatenate()([x, skip]) (:261) is virtual: the skip joins as the second operand of the next conv
+                cur1, cur2 = u, skips[lvl]
             elif kind == "head":
                 w = self.param("residual_rgb/kernel").view(self.head, 3)
                 b = self.param("residual_rgb/bias")
@@ -542,13 +539,13 @@ class Model:
                 try:
                     batch = next(it)
                 except StopIteration:
-                    if steps_per_epoch is None or nb == 0 and epoch > initial_epoch:
-                        if steps_per_epoch is None:
-                            break
-                    it = iter(dataset)
                     if steps_per_epoch is None:
-                        break
-                    continue
+                        break                      # one pass over a finite dataset = one epoch
+                    it = iter(dataset)             # keep streaming across epochs
+                    try:
+                        batch = next(it)
+                    except StopIteration:
+                        raise ValueError("fit() received an empty dataset") from None
                 l, p = self.train_on_batch(batch[0], batch[1])
                 tot_l = l if tot_l is None else tot_l + l
                 tot_p = p if tot_p is None else tot_p + p

@@ -36,6 +36,48 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+class KernelTimer:
+    """Optional per-op-family timing with HIP events on the launch stream (used by bench.py).
+
+    Every wrapper below brackets its launches with a pair of events when a timer is installed; the events
+    sit on torch's current stream, which is the stream the kernels are launched on."""
+
+    def __init__(self):
+        self.records = {}
+
+    def add(self, name, e0, e1):
+        self.records.setdefault(name, []).append((e0, e1))
+
+    def summary(self):
+        """name -> (launches, total_ms); call after torch.cuda.synchronize()."""
+        return {k: (len(v), sum(a.elapsed_time(b) for a, b in v)) for k, v in self.records.items()}
+
+
+_timer: Optional[KernelTimer] = None
+
+
+def set_timer(t: Optional[KernelTimer]):
+    global _timer
+    _timer = t
+
+
+class _timed:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if _timer is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *exc):
+        if _timer is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            _timer.add(self.name, self.e0, e1)
+        return False
+
+
 def cin_granule(dtype: torch.dtype) -> int:
     return _lib.load().ad_cin_granule(dt(dtype))
 
@@ -63,7 +105,8 @@ def pad_channels(x: torch.Tensor, cpad: int, dtype: torch.dtype) -> torch.Tensor
     n, h, w, c = x.shape
     assert x.dtype == torch.float32
     y = torch.empty((n, h, w, cpad), dtype=dtype, device=x.device)
-    check(_lib.load().ad_pad_channels(_p(x), _p(y), n * h * w, c, cpad, dt(dtype), _stream()), "ad_pad_channels")
+    with _timed("pad_channels"):
+        check(_lib.load().ad_pad_channels(_p(x), _p(y), n * h * w, c, cpad, dt(dtype), _stream()), "ad_pad_channels")
     return y
 
 
@@ -73,8 +116,9 @@ def conv3x3_pack(w_hwio: torch.Tensor, cin_pad: int, dtype: torch.dtype, want_dg
     assert (kh, kw) == (3, 3) and w_hwio.dtype == torch.float32
     wf = torch.empty(9 * cin_pad * cout, dtype=dtype, device=w_hwio.device)
     wd = torch.empty(9 * cout * cin_pad, dtype=dtype, device=w_hwio.device) if want_dgrad else None
-    check(_lib.load().ad_conv3x3_pack(_p(w_hwio), cin, cout, cin_pad, _p(wf), _p(wd), dt(dtype), _stream()),
-          "ad_conv3x3_pack")
+    with _timed("conv3x3_pack"):
+        check(_lib.load().ad_conv3x3_pack(_p(w_hwio), cin, cout, cin_pad, _p(wf), _p(wd), dt(dtype), _stream()),
+              "ad_conv3x3_pack")
     return wf, wd
 
 
@@ -87,9 +131,10 @@ def conv3x3_fwd(x1: torch.Tensor, x2: Optional[torch.Tensor], w_packed: torch.Te
     cy1 = split if split is not None else cout
     y1 = torch.empty((n, h, w, cy1), dtype=x1.dtype, device=x1.device)
     y2 = torch.empty((n, h, w, cout - cy1), dtype=x1.dtype, device=x1.device) if cy1 < cout else None
-    check(_lib.load().ad_conv3x3_fwd(_p(x1), c1, _p(x2), c2, _p(w_packed), _p(bias), _p(y1), cy1, _p(y2),
-                                     n, h, w, cout, EPI_RELU if relu else EPI_NONE, dt(x1.dtype), _stream()),
-          "ad_conv3x3_fwd")
+    with _timed("conv3x3_fwd"):
+        check(_lib.load().ad_conv3x3_fwd(_p(x1), c1, _p(x2), c2, _p(w_packed), _p(bias), _p(y1), cy1, _p(y2),
+                                         n, h, w, cout, EPI_RELU if relu else EPI_NONE, dt(x1.dtype), _stream()),
+              "ad_conv3x3_fwd")
     return (y1, y2) if split is not None else y1
 
 
@@ -102,8 +147,9 @@ def conv3x3_wgrad(x1: torch.Tensor, x2: Optional[torch.Tensor], dz: torch.Tensor
     lib = _lib.load()
     need = lib.ad_conv3x3_wgrad_ws_bytes(n, h, w, c1 + c2, cout, dt(x1.dtype))
     ws.ensure(need)
-    check(lib.ad_conv3x3_wgrad(_p(x1), c1, _p(x2), c2, _p(dz), _p(dw_out), cin_real, n, h, w, cout,
-                               ws.ptr, ws.nbytes, dt(x1.dtype), _stream()), "ad_conv3x3_wgrad")
+    with _timed("conv3x3_wgrad"):
+        check(lib.ad_conv3x3_wgrad(_p(x1), c1, _p(x2), c2, _p(dz), _p(dw_out), cin_real, n, h, w, cout,
+                                   ws.ptr, ws.nbytes, dt(x1.dtype), _stream()), "ad_conv3x3_wgrad")
 
 
 def layernorm_relu_fwd(z: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, relu: bool = True,
@@ -113,8 +159,9 @@ def layernorm_relu_fwd(z: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
     y = torch.empty_like(z)
     mean = torch.empty(npix, dtype=torch.float32, device=z.device)
     rstd = torch.empty(npix, dtype=torch.float32, device=z.device)
-    check(_lib.load().ad_layernorm_relu_fwd(_p(z), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), npix, c, eps,
-                                            int(relu), dt(z.dtype), _stream()), "ad_layernorm_relu_fwd")
+    with _timed("layernorm_relu_fwd"):
+        check(_lib.load().ad_layernorm_relu_fwd(_p(z), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), npix, c, eps,
+                                                int(relu), dt(z.dtype), _stream()), "ad_layernorm_relu_fwd")
     return y, mean, rstd
 
 
@@ -124,9 +171,10 @@ def layernorm_relu_bwd(dy, z, mean, rstd, gamma, beta, dgamma, dbeta, dbias, ws:
     dz = torch.empty_like(z)
     lib = _lib.load()
     ws.ensure(lib.ad_layernorm_bwd_ws_bytes(npix, c))
-    check(lib.ad_layernorm_relu_bwd(_p(dy), _p(z), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dz), _p(dgamma),
-                                    _p(dbeta), _p(dbias), npix, c, int(relu), ws.ptr, ws.nbytes, dt(z.dtype),
-                                    _stream()), "ad_layernorm_relu_bwd")
+    with _timed("layernorm_relu_bwd"):
+        check(lib.ad_layernorm_relu_bwd(_p(dy), _p(z), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dz), _p(dgamma),
+                                        _p(dbeta), _p(dbias), npix, c, int(relu), ws.ptr, ws.nbytes, dt(z.dtype),
+                                        _stream()), "ad_layernorm_relu_bwd")
     return dz
 
 
@@ -136,8 +184,9 @@ def relu_bwd(dy, y, dbias, ws: Workspace):
     dz = torch.empty_like(y)
     lib = _lib.load()
     ws.ensure(lib.ad_layernorm_bwd_ws_bytes(npix, c))
-    check(lib.ad_relu_bwd(_p(dy), _p(y), _p(dz), _p(dbias), npix, c, ws.ptr, ws.nbytes, dt(y.dtype), _stream()),
-          "ad_relu_bwd")
+    with _timed("relu_bwd"):
+        check(lib.ad_relu_bwd(_p(dy), _p(y), _p(dz), _p(dbias), npix, c, ws.ptr, ws.nbytes, dt(y.dtype), _stream()),
+              "ad_relu_bwd")
     return dz
 
 
@@ -158,8 +207,9 @@ def resample(x: torch.Tensor, tab: ResampleTables, out: Optional[torch.Tensor] =
     if out is None:
         assert not accumulate
         out = torch.empty((n, tab.oh, tab.ow, c), dtype=x.dtype, device=x.device)
-    check(_lib.load().ad_resample(_p(x), _p(out), _p(tab.sy), _p(tab.wy), tab.ky, _p(tab.sx), _p(tab.wx), tab.kx,
-                                  n, h, w, tab.oh, tab.ow, c, int(accumulate), dt(x.dtype), _stream()), "ad_resample")
+    with _timed("resample"):
+        check(_lib.load().ad_resample(_p(x), _p(out), _p(tab.sy), _p(tab.wy), tab.ky, _p(tab.sx), _p(tab.wx), tab.kx,
+                                      n, h, w, tab.oh, tab.ow, c, int(accumulate), dt(x.dtype), _stream()), "ad_resample")
     return out
 
 
@@ -173,8 +223,9 @@ def head_fwd(xh, w, b, inp, target, ws: Workspace, loss_kind: int = 0, eps: floa
         sqerr = torch.empty(n, dtype=torch.float32, device=xh.device)
     lib = _lib.load()
     ws.ensure(lib.ad_head_ws_bytes(n, ch))
-    check(lib.ad_head_fwd(_p(xh), _p(w), _p(b), _p(inp), _p(target), _p(out), _p(stats), _p(sqerr), n, h * wd, ch,
-                          loss_kind, eps, ws.ptr, ws.nbytes, dt(xh.dtype), _stream()), "ad_head_fwd")
+    with _timed("head_fwd"):
+        check(lib.ad_head_fwd(_p(xh), _p(w), _p(b), _p(inp), _p(target), _p(out), _p(stats), _p(sqerr), n, h * wd, ch,
+                              loss_kind, eps, ws.ptr, ws.nbytes, dt(xh.dtype), _stream()), "ad_head_fwd")
     return out, stats, sqerr
 
 
@@ -184,14 +235,16 @@ def head_bwd(xh, w, b, inp, target, dw, db, grad_scale: float, ws: Workspace, lo
     dxh = torch.empty_like(xh)
     lib = _lib.load()
     ws.ensure(lib.ad_head_ws_bytes(n, ch))
-    check(lib.ad_head_bwd(_p(xh), _p(w), _p(b), _p(inp), _p(target), _p(dxh), _p(dw), _p(db), n, h * wd, ch, loss_kind,
-                          eps, grad_scale, ws.ptr, ws.nbytes, dt(xh.dtype), _stream()), "ad_head_bwd")
+    with _timed("head_bwd"):
+        check(lib.ad_head_bwd(_p(xh), _p(w), _p(b), _p(inp), _p(target), _p(dxh), _p(dw), _p(db), n, h * wd, ch, loss_kind,
+                              eps, grad_scale, ws.ptr, ws.nbytes, dt(xh.dtype), _stream()), "ad_head_bwd")
     return dxh
 
 
 def adam_step(p, g, m, v, step: int, lr=1e-4, b1=0.9, b2=0.999, eps=1e-7, gscale: float = 1.0):
-    check(_lib.load().ad_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, b1, b2, eps, step, gscale, _stream()),
-          "ad_adam_step")
+    with _timed("adam_step"):
+        check(_lib.load().ad_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, b1, b2, eps, step, gscale, _stream()),
+              "ad_adam_step")
 
 
 def cast(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
