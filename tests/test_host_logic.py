@@ -1,0 +1,119 @@
+"""CPU tests of the host logic: depth heuristics (known answers from SURVEY 8 a7), layer configs, resize tap
+tables, bucket planning, and that the C-ABI library loads and exports every symbol of include/adunet.h."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from adunet_amd import _lib
+    header = open(os.path.join(ROOT, "include", "adunet.h")).read()
+    declared = set(re.findall(r"\b(ad_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = _lib.load()           # no GPU needed to load; AttributeError if a symbol is missing
+    assert lib.ad_version() >= 1
+    assert lib.ad_cin_granule(_lib.AD_BF16) == 32 and lib.ad_cin_granule(_lib.AD_F32) == 16
+    assert lib.ad_conv3x3_wgrad_ws_bytes(2, 16, 16, 64, 64, _lib.AD_BF16) > 0
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from adunet_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libadunet_hip.so")
+    with pytest.raises(_lib.AdunetError):
+        _lib.load()
+
+
+KNOWN_256 = {0.2: 2, 0.25: 2, 0.3: 3, 0.4: 3, 0.45: 4, 0.5: 4, 0.6: 6, 0.7: 7, 0.8: 7, 0.9: 7}
+
+
+@pytest.mark.parametrize("mod", ["product", "oracle"])
+def test_depth_heuristics_known_answers(mod):
+    if mod == "product":
+        from adunet_amd import custom_layers as m
+    else:
+        from oracle import ops as m
+    for s, d in KNOWN_256.items():
+        assert m.custom_depth_from_scale(s) == d, s
+    assert m.custom_depth_from_scale(0.25, base_resolution=64) == 1
+    assert m.custom_depth_from_scale(0.5, base_resolution=64) == 2
+    assert m.custom_depth_from_scale(0.25, base_resolution=128) == 2
+    assert m.custom_depth_from_scale(0.5, base_resolution=128) == 3
+    assert m.custom_depth_from_scale(0.25, base_resolution=512) == 3
+    assert m.custom_depth_from_scale(0.5, base_resolution=512) == 5
+    assert [m.infer_depth_from_scale(s) for s in (0.1, 0.25, 0.3, 0.45, 0.5, 0.9)] == [1, 1, 2, 2, 3, 3]
+    assert m.infer_depth_from_scale(0.9, max_depth=2) == 2
+    assert m.estimate_bottleneck_size(256, 0.6, 4) == 33          # round, not ceil: differs from the real pyramid (34)
+    assert m.depth_and_sizes(0.5)[1][:4] == [256, 128, 64, 32]
+    for bad in (0.05, 1.0, -1, 0.0):
+        with pytest.raises(ValueError):
+            m.custom_depth_from_scale(bad)
+        with pytest.raises(ValueError):
+            m.infer_depth_from_scale(bad)
+    with pytest.raises(ValueError):
+        m.custom_depth_from_scale(0.5, min_depth=0)
+
+
+def test_layer_configs_mirror_reference():
+    from adunet_amd.custom_layers import ClipAdd, ClippedResidualAdd, ResizeByScale, ResizeToMatch, SERIALIZED_NAMES
+    l = ResizeByScale(0.6, name="enc_down")
+    cfg = l.get_config()
+    assert cfg["scale"] == 0.6 and cfg["method"] == "bilinear" and cfg["antialias"] is True and cfg["name"] == "enc_down"
+    assert ResizeToMatch(name="dec_up").get_config()["antialias"] is True
+    assert ClipAdd is ClippedResidualAdd
+    assert SERIALIZED_NAMES["ResizeByScale"] == "resize>ResizeByScale"
+    # pyramid chains pinned by the reference summaries (float32 ceil)
+    for scale, chain in [(0.6, [256, 154, 93, 56, 34]), (0.7, [256, 180, 126, 89, 63, 45]), (0.2, [256, 52, 11]),
+                         (0.3, [256, 77, 24, 8]), (0.4, [256, 103, 42, 17]), (0.8, [256, 205, 164, 132]),
+                         (0.9, [256, 231, 208, 188])]:
+        lay = ResizeByScale(scale)
+        h = 256
+        for want in chain[1:]:
+            h = lay.output_hw(h, h)[0]
+            assert h == want, (scale, chain)
+
+
+@pytest.mark.parametrize("sizes", [(256, 154), (154, 93), (256, 64), (64, 16), (16, 4), (4, 1), (1, 4), (4, 16),
+                                   (93, 154), (256, 52), (52, 11), (11, 52), (17, 42), (256, 231), (128, 26)])
+def test_resize_tables_match_oracle_bit_for_bit(sizes):
+    from adunet_amd import resize_tables as rt
+    from oracle import ops
+    i, o = sizes
+    s, w = rt.aa_spans(i, o)
+    s2, w2 = ops.aa_triangle_spans(i, o)
+    assert np.array_equal(s, s2) and np.array_equal(w, w2)
+    assert np.allclose(w.sum(1), 1.0, atol=1e-6)
+    st, wt = rt.aa_spans_transposed(i, o)
+    dense_t = np.zeros((i, o), np.float32)
+    for j in range(i):
+        for k in range(wt.shape[1]):
+            if st[j] + k < o:
+                dense_t[j, st[j] + k] += wt[j, k]
+    assert np.array_equal(dense_t, ops.aa_matrix(i, o, np.float32).T)
+
+
+def test_bucket_plan_covers_buffer_from_the_end():
+    from adunet_amd.model import build_super_resolution_unet
+    from adunet_amd.parallel import plan_buckets
+    model, _ = build_super_resolution_unet(0.5, depth_override=3)
+    total = model.count_params()
+    buckets = plan_buckets(model.index, total, (8 << 20) // 4)
+    assert buckets[0][1] == total and buckets[-1][0] == 0
+    for (lo, hi), (lo2, hi2) in zip(buckets, buckets[1:]):
+        assert hi2 == lo and lo2 < hi2
+    offsets = {off for off, _ in model.index.values()}
+    assert all(lo in offsets for lo, _ in buckets)
+    assert sum(hi - lo for lo, hi in buckets) == total
+
+
+def test_losses_contract():
+    from adunet_amd.model import build_losses_and_metrics
+    loss, metrics = build_losses_and_metrics("Charbonnier")
+    assert loss.__name__ == "charbonnier_loss" and [m.__name__ for m in metrics] == ["psnr"]
+    assert build_losses_and_metrics("l1")[0].__name__ == "l1_loss"
+    with pytest.raises(ValueError, match="Unknown loss"):
+        build_losses_and_metrics("mse")
