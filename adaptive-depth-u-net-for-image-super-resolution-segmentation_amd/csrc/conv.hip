@@ -1,15 +1,22 @@
 // 3x3 "same" convolution on gfx950 as an LDS-tiled implicit GEMM on the matrix cores.
 //
-//   forward / dgrad : M = pixels of a spatial tile (256), N = 64 output channels, K = 9 * Cin
-//   wgrad           : M = input channels, N = 64 output channels, K = pixels (split over workgroups)
+//   forward / dgrad : rows = 64 output channels, cols = pixels of a 256-pixel spatial tile, K = 9 * Cin
+//   wgrad           : rows = input channels, cols = 64 output channels, K = pixels (split over workgroups)
 //
 // Replaces the TensorFlow Conv2D / Conv2DBackpropInput / Conv2DBackpropFilter ops reached from
 // L.Conv2D(nf, 3, padding="same") at Super_resolution/code/train_adaptive_unet.py:202,207,259.
 //
 // Data layout: activations NHWC; per workgroup a halo tile [(TH+2)x(TW+2) pixels][64-byte channel
 // chunk] lives in LDS with an 80-byte pixel stride (conflict-free ds_read_b128 for 16 consecutive
-// pixels), so one HBM read of the tile feeds all nine taps.  Weights are pre-packed to
-// [tap][Cin/KV][Cout][KV] (KV = 16 B) so that every MFMA B fragment is one 16-byte LDS read.
+// pixels), so one read of the tile feeds all nine taps.  Weights are pre-packed to
+// [tap][Cin/KV][Cout][KV] (KV = 16 B) so that every MFMA weight fragment is one 16-byte LDS read.
+// The MFMA is oriented D[cout][pixel] = W^T * X^T: each lane then owns 4 CONSECUTIVE output channels
+// of one pixel, so the epilogue writes 8/16-byte pieces of NHWC rows (and per-pixel reductions over
+// channels stay inside 4 registers x 4 lane groups).
+//
+// Both kernels are persistent (grid ~ 2 workgroups per CU, strided over work items) and software
+// pipelined through registers: the global loads of the next (tile, channel chunk) are issued before
+// the MFMA phase of the current one and written to LDS after it, so HBM/L2 latency hides under compute.
 //
 // Tile geometry is a runtime (TI images x TH x TW) split of 256 pixels so that tiny feature maps
 // (4x4, 2x2, 1x1 at the bottleneck) pack many images into one tile instead of wasting the MFMA.
@@ -23,12 +30,15 @@ namespace {
 constexpr int PIXB = 80;        // LDS bytes per halo pixel: 64-byte chunk + 16-byte pad
 constexpr int TM = 256;         // pixels per workgroup tile
 constexpr int BN = 64;          // output channels per workgroup
+constexpr int WSLOTS = 9 * 4 * BN / 256;   // 16-byte weight slots per thread and channel chunk (= 9)
 constexpr int WT_BYTES = 9 * 4 * BN * 16;  // one channel chunk of packed weights, all taps
+constexpr int NUM_CU = 256;
 
 struct Geo {
     int lti, lth, ltw;  // log2 of images / rows / cols per tile
     int ph, pw;         // halo present along h / w (0 when that extent is 1)
     int HH, HW, NPH;    // halo rows, cols, pixels
+    int NPHP;           // NPH rounded up to the staging granule of the kernel variant (slots/4)
     int tiles_x, tiles_y, tiles_i;
 };
 
@@ -48,29 +58,31 @@ static bool pick_geo(int n, int h, int w, Geo* g) {
     g->ph = h > 1; g->pw = w > 1;
     g->HH = th + 2 * g->ph; g->HW = tw + 2 * g->pw;
     g->NPH = ti * g->HH * g->HW;
+    g->NPHP = g->NPH;
     g->tiles_x = (w + tw - 1) / tw; g->tiles_y = (h + th - 1) / th; g->tiles_i = (n + ti - 1) / ti;
     return true;
 }
 
 // ------------------------------------------------------------------ element policies
+// mma_tap: acc[mt][nt] += W_tap^T (rows: 16 couts of n-tile nt) x X (cols: 16 pixels of m-tile mt)
 struct PolBF16 {
     typedef bf16_t T;
     static constexpr int CK = 32;   // channels per 64-byte chunk
     static constexpr int KV = 8;    // channels per 16 bytes
-    // forward: one 16x16x32 MFMA per (m-tile, n-tile, tap, chunk)
     static __device__ __forceinline__ int a_lane_off(int lane) { return (lane >> 4) * 16; }
-    static __device__ __forceinline__ void mma_tap(f32x4 (&acc)[4][4], const char* xt, const int (&abase)[4],
+    template <int MT>
+    static __device__ __forceinline__ void mma_tap(f32x4 (&acc)[MT][4], const char* xt, const int (&abase)[MT],
                                                    int toff, const char* wtap, int lane) {
-        bf16x8 bfr[4];
+        bf16x8 wf[4];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
-            bfr[nt] = *reinterpret_cast<const bf16x8*>(wtap + (((lane >> 4) * BN) + nt * 16 + (lane & 15)) * 16);
+            wf[nt] = *reinterpret_cast<const bf16x8*>(wtap + (((lane >> 4) * BN) + nt * 16 + (lane & 15)) * 16);
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            bf16x8 af = *reinterpret_cast<const bf16x8*>(xt + abase[mt] + toff);
+        for (int mt = 0; mt < MT; ++mt) {
+            bf16x8 xf = *reinterpret_cast<const bf16x8*>(xt + abase[mt] + toff);
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[nt], acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf, acc[mt][nt], 0, 0, 0);
         }
     }
 };
@@ -80,20 +92,21 @@ struct PolF32 {
     static constexpr int CK = 16;
     static constexpr int KV = 4;
     static __device__ __forceinline__ int a_lane_off(int lane) { return (lane >> 4) * 4; }
-    static __device__ __forceinline__ void mma_tap(f32x4 (&acc)[4][4], const char* xt, const int (&abase)[4],
+    template <int MT>
+    static __device__ __forceinline__ void mma_tap(f32x4 (&acc)[MT][4], const char* xt, const int (&abase)[MT],
                                                    int toff, const char* wtap, int lane) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            float bfr[4];
+            float wf[4];
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
-                bfr[nt] = *reinterpret_cast<const float*>(wtap + ((ks * BN) + nt * 16 + (lane & 15)) * 16 + (lane >> 4) * 4);
+                wf[nt] = *reinterpret_cast<const float*>(wtap + ((ks * BN) + nt * 16 + (lane & 15)) * 16 + (lane >> 4) * 4);
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                float af = *reinterpret_cast<const float*>(xt + abase[mt] + toff + ks * 16);
+            for (int mt = 0; mt < MT; ++mt) {
+                float xf = *reinterpret_cast<const float*>(xt + abase[mt] + toff + ks * 16);
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bfr[nt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt], xf, acc[mt][nt], 0, 0, 0);
             }
         }
     }
@@ -115,14 +128,15 @@ __device__ __forceinline__ TileCtx decode_tile(int tile, const Geo& g) {
 }
 
 // gtab[hp] = flat pixel index (n*H + y)*W + x of halo pixel hp, or -1 outside the image / batch.
+template <int NTHR = 256>
 __device__ __forceinline__ void build_gtab(int* gtab, const Geo& g, const TileCtx& t, int n, int h, int w, int tid) {
-    for (int hp = tid; hp < g.NPH; hp += 256) {
+    for (int hp = tid; hp < g.NPHP; hp += NTHR) {
         int hx = hp % g.HW;
         int r = hp / g.HW;
         int hy = r % g.HH;
         int img = r / g.HH;
         int nn = t.n0 + img, y = t.y0 + hy - g.ph, x = t.x0 + hx - g.pw;
-        bool ok = nn < n && y >= 0 && y < h && x >= 0 && x < w;
+        bool ok = hp < g.NPH && nn < n && y >= 0 && y < h && x >= 0 && x < w;
         gtab[hp] = ok ? (nn * h + y) * w + x : -1;
     }
 }
@@ -135,16 +149,36 @@ __device__ __forceinline__ int halo_of(int m, const Geo& g) {
     return (img * g.HH + ty + g.ph) * g.HW + tx + g.pw;
 }
 
-// Stage one 64-byte channel chunk of the halo tile: global -> LDS, zero outside the image.
-__device__ __forceinline__ void stage_halo(char* xt, const int* gtab, const char* src, int row_bytes, int off_bytes,
-                                           int nph, int tid) {
-    for (int s = tid; s < nph * 4; s += 256) {
-        int hp = s >> 2, part = s & 3;
-        int gp = gtab[hp];
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (gp >= 0) v = *reinterpret_cast<const uint4*>(src + (size_t)gp * row_bytes + off_bytes + part * 16);
-        *reinterpret_cast<uint4*>(xt + hp * PIXB + part * 16) = v;
+// Register-staged halo chunk: XS 16-byte slots per thread (slot s = tid + NTHR*i -> pixel s>>2, part s&3).
+// Branch-free: padding pixels read pixel 0 (always a valid address) and are zeroed by a select; the LDS
+// regions are sized for XS*NTHR slots, so no bounds test is needed either.
+template <int XS, int NTHR = 256>
+__device__ __forceinline__ void load_halo(uint4 (&xr)[XS], const int* gtab, const char* src, int row_bytes,
+                                          int off_bytes, int tid) {
+#pragma unroll
+    for (int i = 0; i < XS; ++i) {
+        const int s = tid + NTHR * i;
+        const int gp = gtab[s >> 2];
+        const uint4 v = *reinterpret_cast<const uint4*>(src + (size_t)max(gp, 0) * row_bytes + off_bytes + (s & 3) * 16);
+        xr[i] = gp >= 0 ? v : make_uint4(0, 0, 0, 0);
     }
+}
+
+template <int XS, int NTHR = 256>
+__device__ __forceinline__ void store_halo(const uint4 (&xr)[XS], char* xt, int tid) {
+#pragma unroll
+    for (int i = 0; i < XS; ++i) {
+        const int s = tid + NTHR * i;
+        *reinterpret_cast<uint4*>(xt + (s >> 2) * PIXB + (s & 3) * 16) = xr[i];
+    }
+}
+
+// One 16-byte slot of a packed weight chunk (9 taps x 4 kc x 64 co x 16 B); slots past the end re-read slot 0
+// and land in the LDS padding.  Slots are held in named scalars (not an array) so they stay in registers.
+__device__ __forceinline__ uint4 load_w_slot(const char* wp, int kc_total, int ch, int cout, int nb, int s) {
+    s = s < 9 * 4 * BN ? s : 0;
+    const int co = s & 63, kc = (s >> 6) & 3, tap = s >> 8;
+    return *reinterpret_cast<const uint4*>(wp + ((size_t)(tap * kc_total + ch * 4 + kc) * cout + nb * BN + co) * 16);
 }
 
 struct ConvArgs {
@@ -152,100 +186,169 @@ struct ConvArgs {
     const char* wp; const float* bias;
     char* y1; char* y2; int cy1;
     int n, h, w, cout, epilogue;
+    int ntiles;
     Geo g;
 };
 
-template <typename P>
-__global__ __launch_bounds__(256) void conv3x3_fwd_kernel(ConvArgs a) {
+// Persistent forward / dgrad kernel.  Work item = (tile, 64-channel output block); the item's channel
+// chunks form the K loop.  LDS: [gtab0][gtab1][halo chunk][weight chunk]; the output tile aliases the
+// halo+weight region during the epilogue.
+// 512 threads: 8 waves, each 32 pixels x 64 output channels (2 x 4 accumulator tiles of 16x16).
+constexpr int FT = 512;                        // threads of the forward kernel
+constexpr int FWS = (9 * 4 * BN + FT - 1) / FT;  // weight slots per thread (= 5, last one partial)
+constexpr int FMT = TM / (FT / 64) / 16;       // m-tiles per wave (= 2)
+
+template <typename P, int XS>
+__global__ __launch_bounds__(FT, XS <= 3 ? 4 : 2) void conv3x3_fwd_kernel(ConvArgs a) {
     typedef typename P::T T;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Geo& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int gtab_bytes = (g.NPH * 4 + 15) & ~15;
-    int* gtab = reinterpret_cast<int*>(smem);
-    char* xt = smem + gtab_bytes;
-    char* wt = xt + g.NPH * PIXB;
+    const int gtab_bytes = g.NPHP * 4;
+    int* gtab0 = reinterpret_cast<int*>(smem);
+    int* gtab1 = reinterpret_cast<int*>(smem + gtab_bytes);
+    char* xt = smem + 2 * gtab_bytes;
+    char* wt = xt + g.NPHP * PIXB;
+    char* ot = xt;
 
-    const TileCtx t = decode_tile(blockIdx.x, g);
-    const int nb = blockIdx.y;
-    build_gtab(gtab, g, t, a.n, a.h, a.w, tid);
+    const int nblk = a.cout / BN;
+    const int nitems = a.ntiles * nblk;
+    const int cin = a.c1 + a.c2;
+    const int nch = cin / P::CK;
+    const int kc_total = cin / P::KV;
+    constexpr int TSZ = (int)sizeof(T);
 
-    int abase[4];
+    int abase[FMT];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        int m = wave * 64 + mt * 16 + (lane & 15);
+    for (int mt = 0; mt < FMT; ++mt) {
+        int m = wave * (16 * FMT) + mt * 16 + (lane & 15);
         abase[mt] = halo_of(m, g) * PIXB + P::a_lane_off(lane);
     }
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int cin = a.c1 + a.c2;
-    const int nchunks = cin / P::CK;
-    const int kc_total = cin / P::KV;
-    __syncthreads();
+    uint4 xr[XS];
+    static_assert(FWS == 5, "weight slots are held in five named registers");
+    uint4 w0, w1, w2, w3, w4;
 
-    for (int ch = 0; ch < nchunks; ++ch) {
-        const int c0 = ch * P::CK;
-        const char* src; int row_bytes, off_bytes;
-        if (c0 < a.c1) { src = a.x1; row_bytes = a.c1 * (int)sizeof(T); off_bytes = c0 * (int)sizeof(T); }
-        else { src = a.x2; row_bytes = a.c2 * (int)sizeof(T); off_bytes = (c0 - a.c1) * (int)sizeof(T); }
-        stage_halo(xt, gtab, src, row_bytes, off_bytes, g.NPH, tid);
-        for (int s = tid; s < 9 * 4 * BN; s += 256) {
-            int co = s & 63, kc = (s >> 6) & 3, tap = s >> 8;
-            const char* p = a.wp + ((size_t)(tap * kc_total + ch * 4 + kc) * a.cout + nb * BN + co) * 16;
-            *reinterpret_cast<uint4*>(wt + s * 16) = *reinterpret_cast<const uint4*>(p);
-        }
+    // issue the global loads of (tile described by gt, channel chunk ch, output block nb) into registers
+#define FWD_ISSUE(GT, CH, NB)                                                                         \
+    do {                                                                                              \
+        const int c0_ = (CH) * P::CK;                                                                 \
+        const bool first_ = c0_ < a.c1;                                                               \
+        const char* src_ = first_ ? a.x1 : a.x2;                                                      \
+        const int rb_ = (first_ ? a.c1 : a.c2) * TSZ;                                                 \
+        const int ob_ = (first_ ? c0_ : c0_ - a.c1) * TSZ;                                            \
+        load_halo<XS, FT>(xr, (GT), src_, rb_, ob_, tid);                                             \
+        w0 = load_w_slot(a.wp, kc_total, (CH), a.cout, (NB), tid);                                    \
+        w1 = load_w_slot(a.wp, kc_total, (CH), a.cout, (NB), tid + FT);                               \
+        w2 = load_w_slot(a.wp, kc_total, (CH), a.cout, (NB), tid + 2 * FT);                           \
+        w3 = load_w_slot(a.wp, kc_total, (CH), a.cout, (NB), tid + 3 * FT);                           \
+        w4 = load_w_slot(a.wp, kc_total, (CH), a.cout, (NB), tid + 4 * FT);                           \
+    } while (0)
+
+    int item = blockIdx.x;
+    int cur = 0;
+    if (item < nitems) {
+        const TileCtx t0 = decode_tile(item / nblk, g);
+        build_gtab<FT>(gtab0, g, t0, a.n, a.h, a.w, tid);
         __syncthreads();
+        FWD_ISSUE(gtab0, 0, item % nblk);
+    }
+
+    for (; item < nitems; item += gridDim.x) {
+        const int tile = item / nblk, nb = item % nblk;
+        const TileCtx t = decode_tile(tile, g);
+        const int next = item + gridDim.x;
+        const bool has_next = next < nitems;
+        int* gt_cur = cur ? gtab1 : gtab0;
+        int* gt_nxt = cur ? gtab0 : gtab1;
+
+        f32x4 acc[FMT][4];
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-            if (!g.ph && kh != 1) continue;
+        for (int i = 0; i < FMT; ++i)
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                if (!g.pw && kw != 1) continue;
-                const int toff = ((kh - 1) * g.HW + (kw - 1)) * PIXB;
-                P::mma_tap(acc, xt, abase, toff, wt + (kh * 3 + kw) * (4 * BN * 16), lane);
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        for (int ch = 0; ch < nch; ++ch) {
+            // registers hold (item, ch): publish them to LDS (previous readers are past their barrier)
+            store_halo<XS, FT>(xr, xt, tid);
+            *reinterpret_cast<uint4*>(wt + tid * 16) = w0;
+            *reinterpret_cast<uint4*>(wt + (tid + FT) * 16) = w1;
+            *reinterpret_cast<uint4*>(wt + (tid + 2 * FT) * 16) = w2;
+            *reinterpret_cast<uint4*>(wt + (tid + 3 * FT) * 16) = w3;
+            *reinterpret_cast<uint4*>(wt + (tid + 4 * FT) * 16) = w4;
+            const bool last = ch == nch - 1;
+            if (last && has_next) {
+                const TileCtx tn = decode_tile(next / nblk, g);
+                build_gtab<FT>(gt_nxt, g, tn, a.n, a.h, a.w, tid);
+            }
+            __syncthreads();
+            // prefetch the next chunk (or the next item's first chunk) while this one is multiplied
+            if (!last || has_next) {
+                const int* gt_p = last ? gt_nxt : gt_cur;
+                const int ch_p = last ? 0 : ch + 1;
+                const int nb_p = last ? next % nblk : nb;
+                FWD_ISSUE(gt_p, ch_p, nb_p);
+            }
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                if (!g.ph && kh != 1) continue;
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    if (!g.pw && kw != 1) continue;
+                    const int toff = ((kh - 1) * g.HW + (kw - 1)) * PIXB;
+                    P::template mma_tap<FMT>(acc, xt, abase, toff, wt + (kh * 3 + kw) * (4 * BN * 16), lane);
+                }
+            }
+            __syncthreads();
+        }
+
+        // ---- epilogue: bias (+ReLU), convert; each lane owns 4 consecutive couts of a pixel
+        constexpr int OS = BN * TSZ + 16;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int co = nt * 16 + (lane >> 4) * 4;
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.bias) bv = *reinterpret_cast<const float4*>(a.bias + nb * BN + co);
+#pragma unroll
+            for (int mt = 0; mt < FMT; ++mt) {
+                const int pix = wave * (16 * FMT) + mt * 16 + (lane & 15);
+                float v[4] = {acc[mt][nt][0] + bv.x, acc[mt][nt][1] + bv.y, acc[mt][nt][2] + bv.z, acc[mt][nt][3] + bv.w};
+                if (a.epilogue == AD_EPI_RELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                }
+                T* dst = reinterpret_cast<T*>(ot + pix * OS + co * TSZ);
+                if constexpr (sizeof(T) == 2) {
+                    bf16x4 pk = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+                    *reinterpret_cast<bf16x4*>(dst) = pk;
+                } else {
+                    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                }
             }
         }
         __syncthreads();
-    }
-
-    // ---- epilogue: bias (+ReLU), convert, transpose through LDS, coalesced 16-byte stores
-    constexpr int OS = BN * (int)sizeof(T) + 16;
-    char* ot = smem;
+        constexpr int PARTS = BN * TSZ / 16;
+        char* yp; int cy, coff;
+        if (nb * BN < a.cy1) { yp = a.y1; cy = a.cy1; coff = nb * BN; }
+        else { yp = a.y2; cy = a.cout - a.cy1; coff = nb * BN - a.cy1; }
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        const int col = nt * 16 + (lane & 15);
-        const float bv = a.bias ? a.bias[nb * BN + col] : 0.f;
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                int pix = wave * 64 + mt * 16 + (lane >> 4) * 4 + r;
-                float v = acc[mt][nt][r] + bv;
-                if (a.epilogue == AD_EPI_RELU) v = fmaxf(v, 0.f);
-                *reinterpret_cast<T*>(ot + pix * OS + col * (int)sizeof(T)) = (T)v;
+        for (int i = 0; i < TM * PARTS / FT; ++i) {
+            const int s = tid + FT * i;
+            const int pix = s / PARTS, part = s % PARTS;
+            const int tx = pix & ((1 << g.ltw) - 1);
+            const int ty = (pix >> g.ltw) & ((1 << g.lth) - 1);
+            const int img = pix >> (g.ltw + g.lth);
+            const int nn = t.n0 + img, y = t.y0 + ty, x = t.x0 + tx;
+            if (nn < a.n && y < a.h && x < a.w) {
+                const size_t gp = ((size_t)nn * a.h + y) * a.w + x;
+                *reinterpret_cast<uint4*>(yp + (gp * cy + coff) * TSZ + part * 16) =
+                    *reinterpret_cast<const uint4*>(ot + pix * OS + part * 16);
             }
-    }
-    __syncthreads();
-    constexpr int PARTS = BN * (int)sizeof(T) / 16;
-    char* yp; int cy, coff;
-    if (nb * BN < a.cy1) { yp = a.y1; cy = a.cy1; coff = nb * BN; }
-    else { yp = a.y2; cy = a.cout - a.cy1; coff = nb * BN - a.cy1; }
-    for (int s = tid; s < TM * PARTS; s += 256) {
-        int pix = s / PARTS, part = s % PARTS;
-        int tx = pix & ((1 << g.ltw) - 1);
-        int ty = (pix >> g.ltw) & ((1 << g.lth) - 1);
-        int img = pix >> (g.ltw + g.lth);
-        int nn = t.n0 + img, y = t.y0 + ty, x = t.x0 + tx;
-        if (nn < a.n && y < a.h && x < a.w) {
-            size_t gp = ((size_t)nn * a.h + y) * a.w + x;
-            *reinterpret_cast<uint4*>(yp + (gp * cy + coff) * sizeof(T) + part * 16) =
-                *reinterpret_cast<const uint4*>(ot + pix * OS + part * 16);
         }
+        __syncthreads();   // the output tile aliases the staging buffers of the next item
+        cur ^= 1;
     }
+#undef FWD_ISSUE
 }
 
 // ------------------------------------------------------------------ wgrad
@@ -263,6 +366,7 @@ template <typename P> struct WgradPol;
 template <> struct WgradPol<PolBF16> {
     static constexpr int NACC = 2;   // n-tiles per wave (one m-tile of 16 input channels)
     static constexpr int DZS = BN * 2 + 16;
+    static constexpr int DSLOTS = BN * 2 / 16;   // 16-byte dz slots per thread (one pixel row each)
     static __device__ __forceinline__ bf16x8 tr_pair(const char* p0, const char* p1) {
         typedef __attribute__((address_space(3))) short4_t* lds_p;
         short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p0));
@@ -276,6 +380,7 @@ template <> struct WgradPol<PolBF16> {
                                                 const Geo& g, int lane, int wave) {
         const int grp = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
         const int mt = wave & 1, nt0 = (wave >> 1) * 2;
+#pragma unroll 2
         for (int ks = 0; ks < TM / 32; ++ks) {
             const int m = ks * 32 + grp * 8 + q;
             const int hb0 = hbase[m] * PIXB + mt * 32 + p * 8;
@@ -307,6 +412,7 @@ template <> struct WgradPol<PolBF16> {
 template <> struct WgradPol<PolF32> {
     static constexpr int NACC = 1;
     static constexpr int DZS = BN * 4 + 16;
+    static constexpr int DSLOTS = BN * 4 / 16;
     static __device__ __forceinline__ void tile(f32x4 (&acc)[9][NACC], const char* xt, const char* dzt, const int* hbase,
                                                 const Geo& g, int lane, int wave) {
         const int kk = lane >> 4, i = lane & 15;
@@ -333,26 +439,33 @@ template <> struct WgradPol<PolF32> {
 
 // grid: x = K split, y = input-channel block (P::CK channels), z = output-channel block (64)
 // ws slab layout: [split][cib][cob][tap][P::CK][64] fp32
-template <typename P>
-__global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs a) {
+// LDS: [gtab0][gtab1][hbase 256][x halo chunk][dz tile]; next tile's data waits in registers.
+template <typename P, int XS>
+__global__ __launch_bounds__(256, XS <= 6 ? 2 : 1) void conv3x3_wgrad_kernel(WgradArgs a) {
     typedef typename P::T T;
     typedef WgradPol<P> WP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Geo& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int gtab_bytes = (g.NPH * 4 + 15) & ~15;
-    int* gtab = reinterpret_cast<int*>(smem);
-    int* hbase = reinterpret_cast<int*>(smem + gtab_bytes);
-    char* xt = smem + gtab_bytes + TM * 4;
-    char* dzt = xt + ((g.NPH * PIXB + 15) & ~15);
+    const int gtab_bytes = g.NPHP * 4;
+    int* gtab0 = reinterpret_cast<int*>(smem);
+    int* gtab1 = reinterpret_cast<int*>(smem + gtab_bytes);
+    int* hbase = reinterpret_cast<int*>(smem + 2 * gtab_bytes);
+    char* xt = smem + 2 * gtab_bytes + TM * 4;
+    char* dzt = xt + g.NPHP * PIXB;
+    constexpr int TSZ = (int)sizeof(T);
 
     const int split = blockIdx.x, cib = blockIdx.y, cob = blockIdx.z;
     const int c0 = cib * P::CK;
     const char* src; int row_bytes, off_bytes;
-    if (c0 < a.c1) { src = a.x1; row_bytes = a.c1 * (int)sizeof(T); off_bytes = c0 * (int)sizeof(T); }
-    else { src = a.x2; row_bytes = a.c2 * (int)sizeof(T); off_bytes = (c0 - a.c1) * (int)sizeof(T); }
+    if (c0 < a.c1) { src = a.x1; row_bytes = a.c1 * TSZ; off_bytes = c0 * TSZ; }
+    else { src = a.x2; row_bytes = a.c2 * TSZ; off_bytes = (c0 - a.c1) * TSZ; }
 
     for (int m = tid; m < TM; m += 256) hbase[m] = halo_of(m, g);
+    // dz slot s = tid + 256*i -> pixel s / DSLOTS, part s % DSLOTS; its halo index is tile independent
+    int dz_hb[WP::DSLOTS];
+#pragma unroll
+    for (int i = 0; i < WP::DSLOTS; ++i) dz_hb[i] = halo_of((tid + 256 * i) / WP::DSLOTS, g);
 
     f32x4 acc[9][WP::NACC];
 #pragma unroll
@@ -360,27 +473,46 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs a) {
 #pragma unroll
         for (int j = 0; j < WP::NACC; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    uint4 xr[XS];
+    uint4 dr[WP::DSLOTS];
+#define WG_ISSUE(GT)                                                                                           \
+    do {                                                                                                       \
+        load_halo<XS, 256>(xr, (GT), src, row_bytes, off_bytes, tid);                                          \
+        _Pragma("unroll") for (int i = 0; i < WP::DSLOTS; ++i) {                                               \
+            const int s_ = tid + 256 * i;                                                                      \
+            const int gp_ = (GT)[dz_hb[i]];                                                                    \
+            const uint4 v_ = *reinterpret_cast<const uint4*>(                                                  \
+                a.dz + ((size_t)max(gp_, 0) * a.cout + cob * BN) * TSZ + (s_ % WP::DSLOTS) * 16);              \
+            dr[i] = gp_ >= 0 ? v_ : make_uint4(0, 0, 0, 0);                                                    \
+        }                                                                                                      \
+    } while (0)
+
     const int t_begin = split * a.tiles_per_split;
     const int t_end = min(a.ntiles, t_begin + a.tiles_per_split);
-    constexpr int PARTS = BN * (int)sizeof(T) / 16;
+    int cur = 0;
+    if (t_begin < t_end) {
+        build_gtab(gtab0, g, decode_tile(t_begin, g), a.n, a.h, a.w, tid);
+        __syncthreads();
+        WG_ISSUE(gtab0);
+    }
     for (int tile = t_begin; tile < t_end; ++tile) {
-        const TileCtx t = decode_tile(tile, g);
-        __syncthreads();  // previous tile's LDS reads done (also orders hbase on the first pass)
-        build_gtab(gtab, g, t, a.n, a.h, a.w, tid);
-        __syncthreads();
-        stage_halo(xt, gtab, src, row_bytes, off_bytes, g.NPH, tid);
-        for (int s = tid; s < TM * PARTS; s += 256) {
-            int pix = s / PARTS, part = s % PARTS;
-            int gp = gtab[hbase[pix]];
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (gp >= 0)
-                v = *reinterpret_cast<const uint4*>(a.dz + ((size_t)gp * a.cout + cob * BN) * sizeof(T) + part * 16);
-            *reinterpret_cast<uint4*>(dzt + pix * WP::DZS + part * 16) = v;
+        int* gt_nxt = cur ? gtab0 : gtab1;
+        store_halo<XS, 256>(xr, xt, tid);
+#pragma unroll
+        for (int i = 0; i < WP::DSLOTS; ++i) {
+            const int s = tid + 256 * i;
+            *reinterpret_cast<uint4*>(dzt + (s / WP::DSLOTS) * WP::DZS + (s % WP::DSLOTS) * 16) = dr[i];
         }
+        const bool has_next = tile + 1 < t_end;
+        if (has_next) build_gtab(gt_nxt, g, decode_tile(tile + 1, g), a.n, a.h, a.w, tid);
         __syncthreads();
+        if (has_next) WG_ISSUE(gt_nxt);
         WP::tile(acc, xt, dzt, hbase, g, lane, wave);
+        __syncthreads();
+        cur ^= 1;
     }
 
+#undef WG_ISSUE
     float* slab = a.ws + ((size_t)(split * a.ncib + cib) * a.ncob + cob) * (9 * P::CK * BN);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
@@ -394,21 +526,29 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs a) {
             }
 }
 
-// dw_hwio[tap][ci][co] = sum over splits of the slabs (fixed order => deterministic)
-__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nsplit, int ncib, int ncob,
-                                    int ck, int cin_real, int cout) {
-    int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    int total = 9 * cin_real * cout;
-    if (idx >= total) return;
-    int co = idx % cout;
-    int r = idx / cout;
-    int ci = r % cin_real;
-    int tap = r / cin_real;
-    int cib = ci / ck, cil = ci % ck, cob = co / BN, col = co % BN;
+// dw_hwio[tap][ci][co] = sum over splits of the slabs, fixed order (deterministic).
+// block = 64 consecutive (tap, ci, co) columns x 4 split groups.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
+                                                           int nsplit, int ncib, int ncob, int ck, int cin_real,
+                                                           int cout) {
+    __shared__ float sm[4][64];
+    const int tid = threadIdx.x, cl = tid & 63, rg = tid >> 6;
+    const int idx = blockIdx.x * 64 + cl;
+    const int total = 9 * cin_real * cout;
     float s = 0.f;
-    for (int sp = 0; sp < nsplit; ++sp)
-        s += ws[(((size_t)(sp * ncib + cib) * ncob + cob) * 9 + tap) * (ck * BN) + cil * BN + col];
-    dw[idx] = s;
+    if (idx < total) {
+        const int co = idx % cout;
+        const int r = idx / cout;
+        const int ci = r % cin_real;
+        const int tap = r / cin_real;
+        const int cib = ci / ck, cil = ci % ck, cob = co / BN, col = co % BN;
+        const size_t base = (((size_t)cib * ncob + cob) * 9 + tap) * (ck * BN) + cil * BN + col;
+        const size_t stride = (size_t)ncib * ncob * 9 * ck * BN;
+        for (int sp = rg; sp < nsplit; sp += 4) s += ws[base + sp * stride];
+    }
+    sm[rg][cl] = s;
+    __syncthreads();
+    if (rg == 0 && idx < total) dw[idx] = (sm[0][cl] + sm[1][cl]) + (sm[2][cl] + sm[3][cl]);
 }
 
 // ------------------------------------------------------------------ weight packing
@@ -444,21 +584,34 @@ __global__ void pack_kernel(const float* __restrict__ w, int cin, int cout, int 
     }
 }
 
+template <typename K>
+static void allow_big_lds(K kern) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
 template <typename P>
-int launch_fwd(const ConvArgs& a, hipStream_t s) {
-    const Geo& g = a.g;
-    size_t stage = ((g.NPH * 4 + 15) & ~15) + (size_t)g.NPH * PIXB + WT_BYTES;
-    size_t outb = (size_t)TM * (BN * sizeof(typename P::T) + 16);
+int launch_fwd(ConvArgs a, hipStream_t s) {
+    Geo& g = a.g;
+    const int xs = g.NPH * 4 <= 3 * FT ? 3 : 8;
+    g.NPHP = xs * FT / 4;
+    size_t stage = 2 * (size_t)g.NPHP * 4 + (size_t)g.NPHP * PIXB + (size_t)FWS * FT * 16;
+    size_t outb = 2 * (size_t)g.NPHP * 4 + (size_t)TM * (BN * sizeof(typename P::T) + 16);
     size_t lds = stage > outb ? stage : outb;
     if (lds > 160 * 1024) return ad_set_error(AD_ERR_ARG, "conv3x3_fwd: LDS %zu too large", lds);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_fwd_kernel<P>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        allow_big_lds(conv3x3_fwd_kernel<P, 3>);
+        allow_big_lds(conv3x3_fwd_kernel<P, 8>);
         attr_set = true;
     }
-    dim3 grid(g.tiles_x * g.tiles_y * g.tiles_i, a.cout / BN);
-    conv3x3_fwd_kernel<P><<<grid, 256, lds, s>>>(a);
+    const int nitems = a.ntiles * (a.cout / BN);
+    const int per_cu = lds <= 80 * 1024 ? 2 : 1;
+    int grid = NUM_CU * per_cu;
+    if (grid > nitems) grid = nitems;
+    if (xs == 3)
+        conv3x3_fwd_kernel<P, 3><<<grid, FT, lds, s>>>(a);
+    else
+        conv3x3_fwd_kernel<P, 8><<<grid, FT, lds, s>>>(a);
     AD_LAUNCH_CHECK("conv3x3_fwd");
     return AD_OK;
 }
@@ -475,7 +628,7 @@ static void plan_wgrad(int n, int h, int w, int cin, int cout, int dtype, WgradP
     p->ncib = cin / p->ck;
     p->ncob = cout / BN;
     p->ntiles = p->g.tiles_x * p->g.tiles_y * p->g.tiles_i;
-    int want = 1024 / (p->ncib * p->ncob);
+    int want = (2 * NUM_CU) / (p->ncib * p->ncob);   // ~2 workgroups per CU in total
     if (want < 1) want = 1;
     if (want > p->ntiles) want = p->ntiles;
     p->tiles_per_split = (p->ntiles + want - 1) / want;
@@ -484,19 +637,24 @@ static void plan_wgrad(int n, int h, int w, int cin, int cout, int dtype, WgradP
 }
 
 template <typename P>
-int launch_wgrad(const WgradArgs& a, const WgradPlan& p, hipStream_t s) {
+int launch_wgrad(WgradArgs a, const WgradPlan& p, hipStream_t s) {
     typedef WgradPol<P> WP;
-    const Geo& g = a.g;
-    size_t lds = ((g.NPH * 4 + 15) & ~15) + TM * 4 + (((size_t)g.NPH * PIXB + 15) & ~15) + (size_t)TM * WP::DZS;
+    Geo& g = a.g;
+    const int xs = g.NPH * 4 <= 6 * 256 ? 6 : 16;
+    g.NPHP = xs * 256 / 4;
+    size_t lds = 2 * (size_t)g.NPHP * 4 + TM * 4 + (size_t)g.NPHP * PIXB + (size_t)TM * WP::DZS;
     if (lds > 160 * 1024) return ad_set_error(AD_ERR_ARG, "conv3x3_wgrad: LDS %zu too large", lds);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_kernel<P>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        allow_big_lds(conv3x3_wgrad_kernel<P, 6>);
+        allow_big_lds(conv3x3_wgrad_kernel<P, 16>);
         attr_set = true;
     }
     dim3 grid(p.nsplit, p.ncib, p.ncob);
-    conv3x3_wgrad_kernel<P><<<grid, 256, lds, s>>>(a);
+    if (xs == 6)
+        conv3x3_wgrad_kernel<P, 6><<<grid, 256, lds, s>>>(a);
+    else
+        conv3x3_wgrad_kernel<P, 16><<<grid, 256, lds, s>>>(a);
     AD_LAUNCH_CHECK("conv3x3_wgrad");
     return AD_OK;
 }
@@ -536,12 +694,14 @@ extern "C" int ad_conv3x3_fwd(const void* x1, int c1, const void* x2, int c2, co
     AD_REQUIRE(cy1 > 0 && cy1 <= cout && cy1 % BN == 0 && ((cy1 == cout) == (y2 == nullptr)),
                "ad_conv3x3_fwd: bad output split cy1=%d cout=%d", cy1, cout);
     AD_REQUIRE(epilogue == AD_EPI_NONE || epilogue == AD_EPI_RELU, "ad_conv3x3_fwd: bad epilogue %d", epilogue);
+    AD_REQUIRE(bias == nullptr || ((uintptr_t)bias % 16) == 0, "ad_conv3x3_fwd: bias must be 16-byte aligned");
     ConvArgs a;
     a.x1 = (const char*)x1; a.x2 = (const char*)x2; a.c1 = c1; a.c2 = c2;
     a.wp = (const char*)w_packed; a.bias = bias;
     a.y1 = (char*)y1; a.y2 = (char*)y2; a.cy1 = cy1;
     a.n = n; a.h = h; a.w = w; a.cout = cout; a.epilogue = epilogue;
     pick_geo(n, h, w, &a.g);
+    a.ntiles = a.g.tiles_x * a.g.tiles_y * a.g.tiles_i;
     hipStream_t s = (hipStream_t)stream;
     return dtype == AD_BF16 ? launch_fwd<PolBF16>(a, s) : launch_fwd<PolF32>(a, s);
 }
@@ -579,8 +739,8 @@ extern "C" int ad_conv3x3_wgrad(const void* x1, int c1, const void* x2, int c2, 
     int rc = dtype == AD_BF16 ? launch_wgrad<PolBF16>(a, p, s) : launch_wgrad<PolF32>(a, p, s);
     if (rc) return rc;
     int total = 9 * cin_real * cout;
-    wgrad_reduce_kernel<<<(total + 255) / 256, 256, 0, s>>>((const float*)ws, dw_hwio, p.nsplit, p.ncib, p.ncob, p.ck,
-                                                           cin_real, cout);
+    wgrad_reduce_kernel<<<(total + 63) / 64, 256, 0, s>>>((const float*)ws, dw_hwio, p.nsplit, p.ncib, p.ncob, p.ck,
+                                                         cin_real, cout);
     AD_LAUNCH_CHECK("wgrad_reduce");
     return AD_OK;
 }
