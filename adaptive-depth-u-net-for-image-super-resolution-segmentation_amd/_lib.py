@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libadunet_hip.so")
+# ADUNET_LIB overrides the path (diagnostic / ablation builds of the same C ABI)
+LIB_PATH = os.environ.get("ADUNET_LIB") or os.path.join(_HERE, "csrc", "libadunet_hip.so")
 
 AD_F32, AD_BF16 = 0, 1
 EPI_NONE, EPI_RELU = 0, 1

@@ -38,7 +38,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
         obj = sp[:-4] + ".o"
         newest = max(os.path.getmtime(p) for p in [sp] + deps)
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < newest:
-            cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value", "-c", sp, "-o", obj]
+            extra = os.environ.get("AD_CFLAGS", "").split()   # e.g. -DAD_STAMP for the phase-stamp diagnostic build
+            cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value"] + extra + ["-c", sp, "-o", obj]
             if verbose:
                 print("[build]", " ".join(cmd), flush=True)
             subprocess.check_call(cmd)

@@ -7,7 +7,7 @@
 // L.Conv2D(nf, 3, padding="same") at Super_resolution/code/train_adaptive_unet.py:202,207,259.
 //
 // Data layout: activations NHWC; per workgroup a halo tile [(TH+2)x(TW+2) pixels][64-byte channel
-// chunk] lives in LDS with an 80-byte pixel stride (conflict-free ds_read_b128 for 16 consecutive
+// chunk] lives in LDS with a 96-byte pixel stride (conflict-free ds_read_b128 for 16 consecutive
 // pixels), so one read of the tile feeds all nine taps.  Weights are pre-packed to
 // [tap][Cin/KV][Cout][KV] (KV = 16 B) so that every MFMA weight fragment is one 16-byte LDS read.
 // The MFMA is oriented D[cout][pixel] = W^T * X^T: each lane then owns 4 CONSECUTIVE output channels
@@ -27,7 +27,11 @@
 
 namespace {
 
-constexpr int PIXB = 80;        // LDS bytes per halo pixel: 64-byte chunk + 16-byte pad
+// LDS bytes per halo pixel: 64-byte chunk + 32-byte pad.  ds_read_b128 serves a wave in 4 NON-contiguous
+// 16-lane groups ({0-3,12-15,20-27}, ...), which mix two k-slots of the fragment; a 96-byte stride keeps all
+// four groups conflict-free for 16 consecutive pixels (80 bytes is 2-way), and 8 consecutive pixels x 32 B
+// tile the 256-byte bank row exactly for the transposed wgrad reads.
+constexpr int PIXB = 96;
 constexpr int TM = 256;         // pixels per workgroup tile
 constexpr int BN = 64;          // output channels per workgroup
 constexpr int WSLOTS = 9 * 4 * BN / 256;   // 16-byte weight slots per thread and channel chunk (= 9)
@@ -64,26 +68,41 @@ static bool pick_geo(int n, int h, int w, Geo* g) {
 }
 
 // ------------------------------------------------------------------ element policies
-// mma_tap: acc[mt][nt] += W_tap^T (rows: 16 couts of n-tile nt) x X (cols: 16 pixels of m-tile mt)
+// mma_chunk: acc[mt][nt] += sum over the taps of W_tap^T (rows: 16 couts of n-tile nt) x X (cols: 16 pixels of
+// m-tile mt) for one channel chunk.  HALO = false: the feature map is 1x1, only the centre tap exists.
+// bf16: the fragments of tap t+1 are read from LDS while the 16 MFMAs of tap t issue (two register sets,
+// selected by the compile-time parity of t), so LDS latency is hidden inside a single wave.
 struct PolBF16 {
     typedef bf16_t T;
     static constexpr int CK = 32;   // channels per 64-byte chunk
     static constexpr int KV = 8;    // channels per 16 bytes
     static __device__ __forceinline__ int a_lane_off(int lane) { return (lane >> 4) * 16; }
-    template <int MT>
-    static __device__ __forceinline__ void mma_tap(f32x4 (&acc)[MT][4], const char* xt, const int (&abase)[MT],
-                                                   int toff, const char* wtap, int lane) {
-        bf16x8 wf[4];
+    template <int MT, bool HALO>
+    static __device__ __forceinline__ void mma_chunk(f32x4 (&acc)[MT][4], const char* xt, const int (&abase)[MT],
+                                                     int row_bytes, const char* wt, int lane) {
+        constexpr int NTAP = HALO ? 9 : 1;
+        bf16x8 wf[2][4], xf[2][MT];
+        const char* wl = wt + (((lane >> 4) * BN) + (lane & 15)) * 16;
+#define AD_LOAD_TAP(BUF, TAP)                                                                             \
+    {                                                                                                     \
+        const int tap_ = HALO ? (TAP) : 4;                                                                \
+        const int toff_ = HALO ? ((TAP) / 3 - 1) * row_bytes + ((TAP) % 3 - 1) * PIXB : 0;                \
+        _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                  \
+            wf[BUF][nt] = *reinterpret_cast<const bf16x8*>(wl + tap_ * (4 * BN * 16) + nt * 256);         \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                 \
+            xf[BUF][mt] = *reinterpret_cast<const bf16x8*>(xt + abase[mt] + toff_);                       \
+    }
+        AD_LOAD_TAP(0, 0)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-            wf[nt] = *reinterpret_cast<const bf16x8*>(wtap + (((lane >> 4) * BN) + nt * 16 + (lane & 15)) * 16);
+        for (int t = 0; t < NTAP; ++t) {
+            if (t + 1 < NTAP) AD_LOAD_TAP((t + 1) & 1, t + 1)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            bf16x8 xf = *reinterpret_cast<const bf16x8*>(xt + abase[mt] + toff);
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf, acc[mt][nt], 0, 0, 0);
+                for (int nt = 0; nt < 4; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t & 1][nt], xf[t & 1][mt], acc[mt][nt], 0, 0, 0);
         }
+#undef AD_LOAD_TAP
     }
 };
 
@@ -92,27 +111,39 @@ struct PolF32 {
     static constexpr int CK = 16;
     static constexpr int KV = 4;
     static __device__ __forceinline__ int a_lane_off(int lane) { return (lane >> 4) * 4; }
-    template <int MT>
-    static __device__ __forceinline__ void mma_tap(f32x4 (&acc)[MT][4], const char* xt, const int (&abase)[MT],
-                                                   int toff, const char* wtap, int lane) {
+    template <int MT, bool HALO>
+    static __device__ __forceinline__ void mma_chunk(f32x4 (&acc)[MT][4], const char* xt, const int (&abase)[MT],
+                                                     int row_bytes, const char* wt, int lane) {
+        constexpr int NTAP = HALO ? 9 : 1;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            float wf[4];
+        for (int t = 0; t < NTAP; ++t) {
+            const int tap = HALO ? t : 4;
+            const int toff = HALO ? (t / 3 - 1) * row_bytes + (t % 3 - 1) * PIXB : 0;
+            const char* wtap = wt + tap * (4 * BN * 16);
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-                wf[nt] = *reinterpret_cast<const float*>(wtap + ((ks * BN) + nt * 16 + (lane & 15)) * 16 + (lane >> 4) * 4);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                float xf = *reinterpret_cast<const float*>(xt + abase[mt] + toff + ks * 16);
+            for (int ks = 0; ks < 4; ++ks) {
+                float wf[4];
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt], xf, acc[mt][nt], 0, 0, 0);
+                    wf[nt] = *reinterpret_cast<const float*>(wtap + ((ks * BN) + nt * 16 + (lane & 15)) * 16 + (lane >> 4) * 4);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    float xf = *reinterpret_cast<const float*>(xt + abase[mt] + toff + ks * 16);
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt], xf, acc[mt][nt], 0, 0, 0);
+                }
             }
         }
     }
 };
 
 // ------------------------------------------------------------------ shared tile helpers
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt(0) -- on gfx9 stores and
+// loads share that counter -- which would expose the full latency of the epilogue's global stores and of the
+// prefetch loads at every barrier.  The LDS hand-offs in these kernels need only lgkmcnt(0) + s_barrier.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 struct TileCtx {
     int n0, y0, x0;
 };
@@ -127,7 +158,9 @@ __device__ __forceinline__ TileCtx decode_tile(int tile, const Geo& g) {
     return t;
 }
 
-// gtab[hp] = flat pixel index (n*H + y)*W + x of halo pixel hp, or -1 outside the image / batch.
+// gtab[hp] = flat pixel index (n*H + y)*W + x of halo pixel hp.  Outside the image / batch it holds the
+// bitwise NOT (negative) of the nearest valid pixel's index: the loader always reads a valid, well spread
+// address (no branch, no hot "zero page" line) and the zero fill is applied when the registers go to LDS.
 template <int NTHR = 256>
 __device__ __forceinline__ void build_gtab(int* gtab, const Geo& g, const TileCtx& t, int n, int h, int w, int tid) {
     for (int hp = tid; hp < g.NPHP; hp += NTHR) {
@@ -137,7 +170,8 @@ __device__ __forceinline__ void build_gtab(int* gtab, const Geo& g, const TileCt
         int img = r / g.HH;
         int nn = t.n0 + img, y = t.y0 + hy - g.ph, x = t.x0 + hx - g.pw;
         bool ok = hp < g.NPH && nn < n && y >= 0 && y < h && x >= 0 && x < w;
-        gtab[hp] = ok ? (nn * h + y) * w + x : -1;
+        int idx = (min(nn, n - 1) * h + min(max(y, 0), h - 1)) * w + min(max(x, 0), w - 1);
+        gtab[hp] = ok ? idx : ~idx;
     }
 }
 
@@ -150,8 +184,7 @@ __device__ __forceinline__ int halo_of(int m, const Geo& g) {
 }
 
 // Register-staged halo chunk: XS 16-byte slots per thread (slot s = tid + NTHR*i -> pixel s>>2, part s&3).
-// Branch-free: padding pixels read pixel 0 (always a valid address) and are zeroed by a select; the LDS
-// regions are sized for XS*NTHR slots, so no bounds test is needed either.
+// Branch-free; gtab is sized for XS*NTHR/4 entries (-1 beyond the halo), so no bounds test is needed.
 template <int XS, int NTHR = 256>
 __device__ __forceinline__ void load_halo(uint4 (&xr)[XS], const int* gtab, const char* src, int row_bytes,
                                           int off_bytes, int tid) {
@@ -159,17 +192,33 @@ __device__ __forceinline__ void load_halo(uint4 (&xr)[XS], const int* gtab, cons
     for (int i = 0; i < XS; ++i) {
         const int s = tid + NTHR * i;
         const int gp = gtab[s >> 2];
-        const uint4 v = *reinterpret_cast<const uint4*>(src + (size_t)max(gp, 0) * row_bytes + off_bytes + (s & 3) * 16);
-        xr[i] = gp >= 0 ? v : make_uint4(0, 0, 0, 0);
+        const int idx = gp >= 0 ? gp : ~gp;
+        xr[i] = *reinterpret_cast<const uint4*>(src + (size_t)idx * row_bytes + off_bytes + (s & 3) * 16);
     }
 }
 
+// Scalar-slot forms of the two helpers above: the forward kernel keeps its staged slots in NAMED registers,
+// because hipcc leaves a `uint4 xr[XS]` that is live across its multi-exit pipeline loop in scratch memory
+// (every load then drains with vmcnt(0) into a scratch store, which serialises the prefetch).
+__device__ __forceinline__ uint4 load_halo_slot(const int* gtab, const char* src, int row_bytes, int off_bytes, int s) {
+    const int gp = gtab[s >> 2];
+    const int idx = gp >= 0 ? gp : ~gp;
+    return *reinterpret_cast<const uint4*>(src + (size_t)idx * row_bytes + off_bytes + (s & 3) * 16);
+}
+
+__device__ __forceinline__ void store_halo_slot(const uint4& v, char* xt, const int* gtab, int nph, int s) {
+    const bool ok = gtab[s >> 2] >= 0;
+    if (s < nph * 4) *reinterpret_cast<uint4*>(xt + (s >> 2) * PIXB + (s & 3) * 16) = ok ? v : make_uint4(0, 0, 0, 0);
+}
+
 template <int XS, int NTHR = 256>
-__device__ __forceinline__ void store_halo(const uint4 (&xr)[XS], char* xt, int tid) {
+__device__ __forceinline__ void store_halo(const uint4 (&xr)[XS], char* xt, const int* gtab, int nph, int tid) {
 #pragma unroll
     for (int i = 0; i < XS; ++i) {
         const int s = tid + NTHR * i;
-        *reinterpret_cast<uint4*>(xt + (s >> 2) * PIXB + (s & 3) * 16) = xr[i];
+        const bool ok = gtab[s >> 2] >= 0;
+        if (s < nph * 4)
+            *reinterpret_cast<uint4*>(xt + (s >> 2) * PIXB + (s & 3) * 16) = ok ? xr[i] : make_uint4(0, 0, 0, 0);
     }
 }
 
@@ -187,19 +236,32 @@ struct ConvArgs {
     char* y1; char* y2; int cy1;
     int n, h, w, cout, epilogue;
     int ntiles;
+    unsigned long long* dbg;   // diagnostic builds only (-DAD_STAMP): per-workgroup phase cycle sums
     Geo g;
 };
+
+#ifdef AD_STAMP
+#define STAMP(slot)                                            \
+    do {                                                       \
+        unsigned long long now_ = clock64();                   \
+        if (tid == 0) st[slot] += now_ - t_last;               \
+        t_last = now_;                                         \
+    } while (0)
+#else
+#define STAMP(slot) do {} while (0)
+#endif
 
 // Persistent forward / dgrad kernel.  Work item = (tile, 64-channel output block); the item's channel
 // chunks form the K loop.  LDS: [gtab0][gtab1][halo chunk][weight chunk]; the output tile aliases the
 // halo+weight region during the epilogue.
-// 512 threads: 8 waves, each 32 pixels x 64 output channels (2 x 4 accumulator tiles of 16x16).
-constexpr int FT = 512;                        // threads of the forward kernel
-constexpr int FWS = (9 * 4 * BN + FT - 1) / FT;  // weight slots per thread (= 5, last one partial)
-constexpr int FMT = TM / (FT / 64) / 16;       // m-tiles per wave (= 2)
+// 256 threads: 4 waves, each 64 pixels x 64 output channels (4 x 4 accumulator tiles of 16x16): 8 LDS
+// fragment reads feed 16 MFMAs per tap, which keeps the LDS pipe at ~50 % of the MFMA time.
+constexpr int FT = 256;                        // threads of the forward kernel
+constexpr int FWS = (9 * 4 * BN + FT - 1) / FT;  // weight slots per thread (= 9)
+constexpr int FMT = TM / (FT / 64) / 16;       // m-tiles per wave (= 4)
 
-template <typename P, int XS>
-__global__ __launch_bounds__(FT, XS <= 3 ? 4 : 2) void conv3x3_fwd_kernel(ConvArgs a) {
+template <typename P, int XS, bool HALO>
+__global__ __launch_bounds__(FT, XS <= 6 ? 2 : 1) void conv3x3_fwd_kernel(ConvArgs a) {
     typedef typename P::T T;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Geo& g = a.g;
@@ -207,9 +269,9 @@ __global__ __launch_bounds__(FT, XS <= 3 ? 4 : 2) void conv3x3_fwd_kernel(ConvAr
     const int gtab_bytes = g.NPHP * 4;
     int* gtab0 = reinterpret_cast<int*>(smem);
     int* gtab1 = reinterpret_cast<int*>(smem + gtab_bytes);
-    char* xt = smem + 2 * gtab_bytes;
-    char* wt = xt + g.NPHP * PIXB;
-    char* ot = xt;
+    float* bias_lds = reinterpret_cast<float*>(smem + 2 * gtab_bytes);   // 2 x 64 biases (item parity)
+    char* xt = smem + 2 * gtab_bytes + 2 * BN * 4;
+    char* wt = xt + ((g.NPH * PIXB + 15) & ~15);
 
     const int nblk = a.cout / BN;
     const int nitems = a.ntiles * nblk;
@@ -225,9 +287,12 @@ __global__ __launch_bounds__(FT, XS <= 3 ? 4 : 2) void conv3x3_fwd_kernel(ConvAr
         abase[mt] = halo_of(m, g) * PIXB + P::a_lane_off(lane);
     }
 
-    uint4 xr[XS];
-    static_assert(FWS == 5, "weight slots are held in five named registers");
-    uint4 w0, w1, w2, w3, w4;
+    static_assert(XS <= 16, "halo slots are held in up to sixteen named registers");
+    uint4 x0, x1, x2, x3, x4, x5, x6, x7, x8, x9, x10, x11, x12, x13, x14, x15;
+    static_assert(FWS == 9, "weight slots are held in nine named registers");
+    uint4 w0, w1, w2, w3, w4, w5, w6, w7, w8;
+    float bq = 0.f;   // bias of channel (tid & 63), fetched with the item's first chunk (a load in the epilogue
+                      // would sit behind the prefetch in the in-order vmcnt queue and drain it)
 
     // issue the global loads of (tile described by gt, channel chunk ch, output block nb) into registers
 #define FWD_ISSUE(GT, CH, NB)                                                                         \
@@ -237,22 +302,48 @@ __global__ __launch_bounds__(FT, XS <= 3 ? 4 : 2) void conv3x3_fwd_kernel(ConvAr
         const char* src_ = first_ ? a.x1 : a.x2;                                                      \
         const int rb_ = (first_ ? a.c1 : a.c2) * TSZ;                                                 \
         const int ob_ = (first_ ? c0_ : c0_ - a.c1) * TSZ;                                            \
-        load_halo<XS, FT>(xr, (GT), src_, rb_, ob_, tid);                                             \
+        if ((CH) == 0 && a.bias) bq = a.bias[(NB) * BN + (tid & 63)];                                 \
+        if constexpr (XS > 0) x0 = load_halo_slot((GT), src_, rb_, ob_, tid + 0 * FT);                                  \
+        if constexpr (XS > 1) x1 = load_halo_slot((GT), src_, rb_, ob_, tid + 1 * FT);                                  \
+        if constexpr (XS > 2) x2 = load_halo_slot((GT), src_, rb_, ob_, tid + 2 * FT);                                  \
+        if constexpr (XS > 3) x3 = load_halo_slot((GT), src_, rb_, ob_, tid + 3 * FT);                                  \
+        if constexpr (XS > 4) x4 = load_halo_slot((GT), src_, rb_, ob_, tid + 4 * FT);                                  \
+        if constexpr (XS > 5) x5 = load_halo_slot((GT), src_, rb_, ob_, tid + 5 * FT);                                  \
+        if constexpr (XS > 6) x6 = load_halo_slot((GT), src_, rb_, ob_, tid + 6 * FT);                                  \
+        if constexpr (XS > 7) x7 = load_halo_slot((GT), src_, rb_, ob_, tid + 7 * FT);                                  \
+        if constexpr (XS > 8) x8 = load_halo_slot((GT), src_, rb_, ob_, tid + 8 * FT);                                  \
+        if constexpr (XS > 9) x9 = load_halo_slot((GT), src_, rb_, ob_, tid + 9 * FT);                                  \
+        if constexpr (XS > 10) x10 = load_halo_slot((GT), src_, rb_, ob_, tid + 10 * FT);                               \
+        if constexpr (XS > 11) x11 = load_halo_slot((GT), src_, rb_, ob_, tid + 11 * FT);                               \
+        if constexpr (XS > 12) x12 = load_halo_slot((GT), src_, rb_, ob_, tid + 12 * FT);                               \
+        if constexpr (XS > 13) x13 = load_halo_slot((GT), src_, rb_, ob_, tid + 13 * FT);                               \
+        if constexpr (XS > 14) x14 = load_halo_slot((GT), src_, rb_, ob_, tid + 14 * FT);                               \
+        if constexpr (XS > 15) x15 = load_halo_slot((GT), src_, rb_, ob_, tid + 15 * FT);                               \
         w0 = load_w_slot(a.wp, kc_total, (CH), a.cout, (NB), tid);                                    \
         w1 = load_w_slot(a.wp, kc_total, (CH), a.cout, (NB), tid + FT);                               \
         w2 = load_w_slot(a.wp, kc_total, (CH), a.cout, (NB), tid + 2 * FT);                           \
         w3 = load_w_slot(a.wp, kc_total, (CH), a.cout, (NB), tid + 3 * FT);                           \
         w4 = load_w_slot(a.wp, kc_total, (CH), a.cout, (NB), tid + 4 * FT);                           \
+        w5 = load_w_slot(a.wp, kc_total, (CH), a.cout, (NB), tid + 5 * FT);                           \
+        w6 = load_w_slot(a.wp, kc_total, (CH), a.cout, (NB), tid + 6 * FT);                           \
+        w7 = load_w_slot(a.wp, kc_total, (CH), a.cout, (NB), tid + 7 * FT);                           \
+        w8 = load_w_slot(a.wp, kc_total, (CH), a.cout, (NB), tid + 8 * FT);                           \
     } while (0)
 
+#ifdef AD_STAMP
+    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t_last = clock64();
+    const unsigned long long t_begin = t_last;
+#endif
     int item = blockIdx.x;
     int cur = 0;
     if (item < nitems) {
         const TileCtx t0 = decode_tile(item / nblk, g);
         build_gtab<FT>(gtab0, g, t0, a.n, a.h, a.w, tid);
-        __syncthreads();
+        lds_barrier();
         FWD_ISSUE(gtab0, 0, item % nblk);
     }
+    STAMP(0);
 
     for (; item < nitems; item += gridDim.x) {
         const int tile = item / nblk, nb = item % nblk;
@@ -270,18 +361,41 @@ __global__ __launch_bounds__(FT, XS <= 3 ? 4 : 2) void conv3x3_fwd_kernel(ConvAr
 
         for (int ch = 0; ch < nch; ++ch) {
             // registers hold (item, ch): publish them to LDS (previous readers are past their barrier)
-            store_halo<XS, FT>(xr, xt, tid);
+            if constexpr (XS > 0) store_halo_slot(x0, xt, gt_cur, g.NPH, tid + 0 * FT);
+            if constexpr (XS > 1) store_halo_slot(x1, xt, gt_cur, g.NPH, tid + 1 * FT);
+            if constexpr (XS > 2) store_halo_slot(x2, xt, gt_cur, g.NPH, tid + 2 * FT);
+            if constexpr (XS > 3) store_halo_slot(x3, xt, gt_cur, g.NPH, tid + 3 * FT);
+            if constexpr (XS > 4) store_halo_slot(x4, xt, gt_cur, g.NPH, tid + 4 * FT);
+            if constexpr (XS > 5) store_halo_slot(x5, xt, gt_cur, g.NPH, tid + 5 * FT);
+            if constexpr (XS > 6) store_halo_slot(x6, xt, gt_cur, g.NPH, tid + 6 * FT);
+            if constexpr (XS > 7) store_halo_slot(x7, xt, gt_cur, g.NPH, tid + 7 * FT);
+            if constexpr (XS > 8) store_halo_slot(x8, xt, gt_cur, g.NPH, tid + 8 * FT);
+            if constexpr (XS > 9) store_halo_slot(x9, xt, gt_cur, g.NPH, tid + 9 * FT);
+            if constexpr (XS > 10) store_halo_slot(x10, xt, gt_cur, g.NPH, tid + 10 * FT);
+            if constexpr (XS > 11) store_halo_slot(x11, xt, gt_cur, g.NPH, tid + 11 * FT);
+            if constexpr (XS > 12) store_halo_slot(x12, xt, gt_cur, g.NPH, tid + 12 * FT);
+            if constexpr (XS > 13) store_halo_slot(x13, xt, gt_cur, g.NPH, tid + 13 * FT);
+            if constexpr (XS > 14) store_halo_slot(x14, xt, gt_cur, g.NPH, tid + 14 * FT);
+            if constexpr (XS > 15) store_halo_slot(x15, xt, gt_cur, g.NPH, tid + 15 * FT);
             *reinterpret_cast<uint4*>(wt + tid * 16) = w0;
             *reinterpret_cast<uint4*>(wt + (tid + FT) * 16) = w1;
             *reinterpret_cast<uint4*>(wt + (tid + 2 * FT) * 16) = w2;
             *reinterpret_cast<uint4*>(wt + (tid + 3 * FT) * 16) = w3;
             *reinterpret_cast<uint4*>(wt + (tid + 4 * FT) * 16) = w4;
+            *reinterpret_cast<uint4*>(wt + (tid + 5 * FT) * 16) = w5;
+            *reinterpret_cast<uint4*>(wt + (tid + 6 * FT) * 16) = w6;
+            *reinterpret_cast<uint4*>(wt + (tid + 7 * FT) * 16) = w7;
+            *reinterpret_cast<uint4*>(wt + (tid + 8 * FT) * 16) = w8;
+            if (ch == 0 && tid < BN) bias_lds[(cur ? BN : 0) + tid] = bq;
+            STAMP(1);   // wait for prefetched loads + LDS stores
             const bool last = ch == nch - 1;
             if (last && has_next) {
                 const TileCtx tn = decode_tile(next / nblk, g);
                 build_gtab<FT>(gt_nxt, g, tn, a.n, a.h, a.w, tid);
             }
-            __syncthreads();
+            STAMP(2);   // gtab build
+            lds_barrier();
+            STAMP(3);   // barrier A
             // prefetch the next chunk (or the next item's first chunk) while this one is multiplied
             if (!last || has_next) {
                 const int* gt_p = last ? gt_nxt : gt_cur;
@@ -289,66 +403,62 @@ __global__ __launch_bounds__(FT, XS <= 3 ? 4 : 2) void conv3x3_fwd_kernel(ConvAr
                 const int nb_p = last ? next % nblk : nb;
                 FWD_ISSUE(gt_p, ch_p, nb_p);
             }
-#pragma unroll
-            for (int kh = 0; kh < 3; ++kh) {
-                if (!g.ph && kh != 1) continue;
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    if (!g.pw && kw != 1) continue;
-                    const int toff = ((kh - 1) * g.HW + (kw - 1)) * PIXB;
-                    P::template mma_tap<FMT>(acc, xt, abase, toff, wt + (kh * 3 + kw) * (4 * BN * 16), lane);
-                }
-            }
-            __syncthreads();
+            STAMP(4);   // issue prefetch
+            P::template mma_chunk<FMT, HALO>(acc, xt, abase, g.HW * PIXB, wt, lane);
+            STAMP(5);   // MFMA phase
+            lds_barrier();
+            STAMP(6);   // barrier B
         }
 
-        // ---- epilogue: bias (+ReLU), convert; each lane owns 4 consecutive couts of a pixel
-        constexpr int OS = BN * TSZ + 16;
+        // ---- epilogue straight from the accumulators: each lane owns 4 consecutive couts (8 B bf16 / 16 B f32)
+        // of pixel (lane & 15) of every m-tile; the four lane groups of a wave complete 32/64-byte row pieces.
+        // No LDS round trip and no barrier: barrier B already fenced the staging buffers.
+        {
+            char* yp; int cy, coff;
+            if (nb * BN < a.cy1) { yp = a.y1; cy = a.cy1; coff = nb * BN; }
+            else { yp = a.y2; cy = a.cout - a.cy1; coff = nb * BN - a.cy1; }
+            const float* bl = bias_lds + (cur ? BN : 0);
+            float4 bv[4];
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const int co = nt * 16 + (lane >> 4) * 4;
-            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (a.bias) bv = *reinterpret_cast<const float4*>(a.bias + nb * BN + co);
+            for (int nt = 0; nt < 4; ++nt) bv[nt] = *reinterpret_cast<const float4*>(bl + nt * 16 + (lane >> 4) * 4);
 #pragma unroll
             for (int mt = 0; mt < FMT; ++mt) {
                 const int pix = wave * (16 * FMT) + mt * 16 + (lane & 15);
-                float v[4] = {acc[mt][nt][0] + bv.x, acc[mt][nt][1] + bv.y, acc[mt][nt][2] + bv.z, acc[mt][nt][3] + bv.w};
-                if (a.epilogue == AD_EPI_RELU) {
+                const int tx = pix & ((1 << g.ltw) - 1);
+                const int ty = (pix >> g.ltw) & ((1 << g.lth) - 1);
+                const int img = pix >> (g.ltw + g.lth);
+                const int nn = t.n0 + img, y = t.y0 + ty, x = t.x0 + tx;
+                if (nn < a.n && y < a.h && x < a.w) {
+                    const size_t gp = ((size_t)nn * a.h + y) * a.w + x;
+                    T* dst = reinterpret_cast<T*>(yp) + gp * cy + coff + (lane >> 4) * 4;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-                }
-                T* dst = reinterpret_cast<T*>(ot + pix * OS + co * TSZ);
-                if constexpr (sizeof(T) == 2) {
-                    bf16x4 pk = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-                    *reinterpret_cast<bf16x4*>(dst) = pk;
-                } else {
-                    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                    for (int nt = 0; nt < 4; ++nt) {
+                        float v[4] = {acc[mt][nt][0] + bv[nt].x, acc[mt][nt][1] + bv[nt].y, acc[mt][nt][2] + bv[nt].z,
+                                      acc[mt][nt][3] + bv[nt].w};
+                        if (a.epilogue == AD_EPI_RELU) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                        }
+                        if constexpr (sizeof(T) == 2) {
+                            bf16x4 pk = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+                            *reinterpret_cast<bf16x4*>(dst + nt * 16) = pk;
+                        } else {
+                            *reinterpret_cast<float4*>(dst + nt * 16) = make_float4(v[0], v[1], v[2], v[3]);
+                        }
+                    }
                 }
             }
         }
-        __syncthreads();
-        constexpr int PARTS = BN * TSZ / 16;
-        char* yp; int cy, coff;
-        if (nb * BN < a.cy1) { yp = a.y1; cy = a.cy1; coff = nb * BN; }
-        else { yp = a.y2; cy = a.cout - a.cy1; coff = nb * BN - a.cy1; }
-#pragma unroll
-        for (int i = 0; i < TM * PARTS / FT; ++i) {
-            const int s = tid + FT * i;
-            const int pix = s / PARTS, part = s % PARTS;
-            const int tx = pix & ((1 << g.ltw) - 1);
-            const int ty = (pix >> g.ltw) & ((1 << g.lth) - 1);
-            const int img = pix >> (g.ltw + g.lth);
-            const int nn = t.n0 + img, y = t.y0 + ty, x = t.x0 + tx;
-            if (nn < a.n && y < a.h && x < a.w) {
-                const size_t gp = ((size_t)nn * a.h + y) * a.w + x;
-                *reinterpret_cast<uint4*>(yp + (gp * cy + coff) * TSZ + part * 16) =
-                    *reinterpret_cast<const uint4*>(ot + pix * OS + part * 16);
-            }
-        }
-        __syncthreads();   // the output tile aliases the staging buffers of the next item
+        STAMP(7);   // epilogue
         cur ^= 1;
     }
 #undef FWD_ISSUE
+#ifdef AD_STAMP
+    if (tid == 0 && a.dbg) {
+        for (int i = 0; i < 8; ++i) a.dbg[blockIdx.x * 9 + i] = st[i];
+        a.dbg[blockIdx.x * 9 + 8] = clock64() - t_begin;
+    }
+#endif
 }
 
 // ------------------------------------------------------------------ wgrad
@@ -365,7 +475,7 @@ template <typename P> struct WgradPol;
 
 template <> struct WgradPol<PolBF16> {
     static constexpr int NACC = 2;   // n-tiles per wave (one m-tile of 16 input channels)
-    static constexpr int DZS = BN * 2 + 16;
+    static constexpr int DZS = BN * 2 + 32;   // 160 B: 8 consecutive pixels x 32 B tile the 256-B bank row
     static constexpr int DSLOTS = BN * 2 / 16;   // 16-byte dz slots per thread (one pixel row each)
     static __device__ __forceinline__ bf16x8 tr_pair(const char* p0, const char* p1) {
         typedef __attribute__((address_space(3))) short4_t* lds_p;
@@ -382,13 +492,15 @@ template <> struct WgradPol<PolBF16> {
         const int mt = wave & 1, nt0 = (wave >> 1) * 2;
 #pragma unroll 2
         for (int ks = 0; ks < TM / 32; ++ks) {
-            const int m = ks * 32 + grp * 8 + q;
+            // k index 8*grp + j of this k-step <-> pixel ks*32 + 16*(j>>2) + 4*grp + (j&3): each transposed read
+            // then covers 8 consecutive pixels per 32-lane half (conflict-free); A and B use the same map.
+            const int m = ks * 32 + grp * 4 + q;
             const int hb0 = hbase[m] * PIXB + mt * 32 + p * 8;
-            const int hb1 = hbase[m + 4] * PIXB + mt * 32 + p * 8;
+            const int hb1 = hbase[m + 16] * PIXB + mt * 32 + p * 8;
             bf16x8 bfr[NACC];
 #pragma unroll
             for (int j = 0; j < NACC; ++j)
-                bfr[j] = tr_pair(dzt + m * DZS + (nt0 + j) * 32 + p * 8, dzt + (m + 4) * DZS + (nt0 + j) * 32 + p * 8);
+                bfr[j] = tr_pair(dzt + m * DZS + (nt0 + j) * 32 + p * 8, dzt + (m + 16) * DZS + (nt0 + j) * 32 + p * 8);
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
@@ -452,7 +564,7 @@ __global__ __launch_bounds__(256, XS <= 6 ? 2 : 1) void conv3x3_wgrad_kernel(Wgr
     int* gtab1 = reinterpret_cast<int*>(smem + gtab_bytes);
     int* hbase = reinterpret_cast<int*>(smem + 2 * gtab_bytes);
     char* xt = smem + 2 * gtab_bytes + TM * 4;
-    char* dzt = xt + g.NPHP * PIXB;
+    char* dzt = xt + ((g.NPH * PIXB + 15) & ~15);
     constexpr int TSZ = (int)sizeof(T);
 
     const int split = blockIdx.x, cib = blockIdx.y, cob = blockIdx.z;
@@ -481,9 +593,9 @@ __global__ __launch_bounds__(256, XS <= 6 ? 2 : 1) void conv3x3_wgrad_kernel(Wgr
         _Pragma("unroll") for (int i = 0; i < WP::DSLOTS; ++i) {                                               \
             const int s_ = tid + 256 * i;                                                                      \
             const int gp_ = (GT)[dz_hb[i]];                                                                    \
-            const uint4 v_ = *reinterpret_cast<const uint4*>(                                                  \
-                a.dz + ((size_t)max(gp_, 0) * a.cout + cob * BN) * TSZ + (s_ % WP::DSLOTS) * 16);              \
-            dr[i] = gp_ >= 0 ? v_ : make_uint4(0, 0, 0, 0);                                                    \
+            const int idx_ = gp_ >= 0 ? gp_ : ~gp_;                                                            \
+            dr[i] = *reinterpret_cast<const uint4*>(                                                           \
+                a.dz + ((size_t)idx_ * a.cout + cob * BN) * TSZ + (s_ % WP::DSLOTS) * 16);                     \
         }                                                                                                      \
     } while (0)
 
@@ -492,23 +604,26 @@ __global__ __launch_bounds__(256, XS <= 6 ? 2 : 1) void conv3x3_wgrad_kernel(Wgr
     int cur = 0;
     if (t_begin < t_end) {
         build_gtab(gtab0, g, decode_tile(t_begin, g), a.n, a.h, a.w, tid);
-        __syncthreads();
+        lds_barrier();
         WG_ISSUE(gtab0);
     }
     for (int tile = t_begin; tile < t_end; ++tile) {
+        int* gt_cur = cur ? gtab1 : gtab0;
         int* gt_nxt = cur ? gtab0 : gtab1;
-        store_halo<XS, 256>(xr, xt, tid);
+        store_halo<XS, 256>(xr, xt, gt_cur, g.NPH, tid);
 #pragma unroll
         for (int i = 0; i < WP::DSLOTS; ++i) {
             const int s = tid + 256 * i;
-            *reinterpret_cast<uint4*>(dzt + (s / WP::DSLOTS) * WP::DZS + (s % WP::DSLOTS) * 16) = dr[i];
+            const bool ok = gt_cur[dz_hb[i]] >= 0;
+            *reinterpret_cast<uint4*>(dzt + (s / WP::DSLOTS) * WP::DZS + (s % WP::DSLOTS) * 16) =
+                ok ? dr[i] : make_uint4(0, 0, 0, 0);
         }
         const bool has_next = tile + 1 < t_end;
         if (has_next) build_gtab(gt_nxt, g, decode_tile(tile + 1, g), a.n, a.h, a.w, tid);
-        __syncthreads();
+        lds_barrier();
         if (has_next) WG_ISSUE(gt_nxt);
         WP::tile(acc, xt, dzt, hbase, g, lane, wave);
-        __syncthreads();
+        lds_barrier();
         cur ^= 1;
     }
 
@@ -592,26 +707,30 @@ static void allow_big_lds(K kern) {
 template <typename P>
 int launch_fwd(ConvArgs a, hipStream_t s) {
     Geo& g = a.g;
-    const int xs = g.NPH * 4 <= 3 * FT ? 3 : 8;
+    const int xs = g.NPH * 4 <= 6 * FT ? 6 : 16;
     g.NPHP = xs * FT / 4;
-    size_t stage = 2 * (size_t)g.NPHP * 4 + (size_t)g.NPHP * PIXB + (size_t)FWS * FT * 16;
-    size_t outb = 2 * (size_t)g.NPHP * 4 + (size_t)TM * (BN * sizeof(typename P::T) + 16);
-    size_t lds = stage > outb ? stage : outb;
+    size_t lds = 2 * (size_t)g.NPHP * 4 + 2 * BN * 4 + (((size_t)g.NPH * PIXB + 15) & ~15) + (size_t)FWS * FT * 16;
     if (lds > 160 * 1024) return ad_set_error(AD_ERR_ARG, "conv3x3_fwd: LDS %zu too large", lds);
     static bool attr_set = false;
     if (!attr_set) {
-        allow_big_lds(conv3x3_fwd_kernel<P, 3>);
-        allow_big_lds(conv3x3_fwd_kernel<P, 8>);
+        allow_big_lds(conv3x3_fwd_kernel<P, 6, true>);
+        allow_big_lds(conv3x3_fwd_kernel<P, 16, true>);
+        allow_big_lds(conv3x3_fwd_kernel<P, 6, false>);
         attr_set = true;
     }
     const int nitems = a.ntiles * (a.cout / BN);
     const int per_cu = lds <= 80 * 1024 ? 2 : 1;
     int grid = NUM_CU * per_cu;
     if (grid > nitems) grid = nitems;
-    if (xs == 3)
-        conv3x3_fwd_kernel<P, 3><<<grid, FT, lds, s>>>(a);
+    const bool halo = g.ph && g.pw;
+    if (!halo && (g.ph || g.pw || xs != 6))
+        return ad_set_error(AD_ERR_ARG, "conv3x3_fwd: feature maps with exactly one unit extent (%dx%d) are not supported", a.h, a.w);
+    if (!halo)
+        conv3x3_fwd_kernel<P, 6, false><<<grid, FT, lds, s>>>(a);
+    else if (xs == 6)
+        conv3x3_fwd_kernel<P, 6, true><<<grid, FT, lds, s>>>(a);
     else
-        conv3x3_fwd_kernel<P, 8><<<grid, FT, lds, s>>>(a);
+        conv3x3_fwd_kernel<P, 16, true><<<grid, FT, lds, s>>>(a);
     AD_LAUNCH_CHECK("conv3x3_fwd");
     return AD_OK;
 }
@@ -642,7 +761,7 @@ int launch_wgrad(WgradArgs a, const WgradPlan& p, hipStream_t s) {
     Geo& g = a.g;
     const int xs = g.NPH * 4 <= 6 * 256 ? 6 : 16;
     g.NPHP = xs * 256 / 4;
-    size_t lds = 2 * (size_t)g.NPHP * 4 + TM * 4 + (size_t)g.NPHP * PIXB + (size_t)TM * WP::DZS;
+    size_t lds = 2 * (size_t)g.NPHP * 4 + TM * 4 + (((size_t)g.NPH * PIXB + 15) & ~15) + (size_t)TM * WP::DZS;
     if (lds > 160 * 1024) return ad_set_error(AD_ERR_ARG, "conv3x3_wgrad: LDS %zu too large", lds);
     static bool attr_set = false;
     if (!attr_set) {
@@ -660,6 +779,11 @@ int launch_wgrad(WgradArgs a, const WgradPlan& p, hipStream_t s) {
 }
 
 }  // namespace
+
+static unsigned long long* g_dbg = nullptr;
+#ifdef AD_STAMP
+extern "C" void ad_dbg_set_stamp_buffer(void* p) { g_dbg = (unsigned long long*)p; }
+#endif
 
 extern "C" int ad_conv3x3_pack(const float* w_hwio, int cin, int cout, int cin_pad, void* w_fwd, void* w_dgrad,
                                int dtype, void* stream) {
@@ -694,12 +818,12 @@ extern "C" int ad_conv3x3_fwd(const void* x1, int c1, const void* x2, int c2, co
     AD_REQUIRE(cy1 > 0 && cy1 <= cout && cy1 % BN == 0 && ((cy1 == cout) == (y2 == nullptr)),
                "ad_conv3x3_fwd: bad output split cy1=%d cout=%d", cy1, cout);
     AD_REQUIRE(epilogue == AD_EPI_NONE || epilogue == AD_EPI_RELU, "ad_conv3x3_fwd: bad epilogue %d", epilogue);
-    AD_REQUIRE(bias == nullptr || ((uintptr_t)bias % 16) == 0, "ad_conv3x3_fwd: bias must be 16-byte aligned");
     ConvArgs a;
     a.x1 = (const char*)x1; a.x2 = (const char*)x2; a.c1 = c1; a.c2 = c2;
     a.wp = (const char*)w_packed; a.bias = bias;
     a.y1 = (char*)y1; a.y2 = (char*)y2; a.cy1 = cy1;
     a.n = n; a.h = h; a.w = w; a.cout = cout; a.epilogue = epilogue;
+    a.dbg = g_dbg;
     pick_geo(n, h, w, &a.g);
     a.ntiles = a.g.tiles_x * a.g.tiles_y * a.g.tiles_i;
     hipStream_t s = (hipStream_t)stream;
