@@ -1,0 +1,243 @@
+"""Host data path: mirror of /root/reference/shared/pipeline.py (names, signatures, dtype/shape/range contract).
+
+The reference feeds the model from one Python generator (cv2.imread + cv2.resize per patch) wrapped in tf.data.
+Here the same functions return plain Python iterables of NumPy float32 NHWC batches in [0,1]; image decoding uses
+Pillow and the LR synthesis (INTER_AREA shrink, INTER_CUBIC a=-0.75 enlarge, not clipped) is restated in NumPy.
+OpenCV is not installed in this image, so pixel values of `degrade_image` are *parity unpinned* against cv2; the
+deterministic parts (natural sort, patch grids, labels, split indices, RNG consumption order) are tested.
+"""
+from __future__ import annotations
+
+import math
+from pathlib import Path
+from typing import Iterable, Iterator, List, Sequence, Tuple
+
+import numpy as np
+
+
+def sorted_alphanumeric(items: Iterable[str]) -> List[str]:
+    """pipeline.py:11-34 -- natural sort: digit runs compare numerically, text case-insensitively."""
+
+    def split_key(text: str):
+        tokens, token = [], ""
+        for ch in text:
+            if token and ch.isdigit() != token[-1].isdigit():
+                tokens.append(token)
+                token = ""
+            token += ch
+        if token:
+            tokens.append(token)
+        return [int(t) if t.isdigit() else t.lower() for t in tokens]
+
+    return sorted(items, key=split_key)
+
+
+def load_rgb_image_full(path) -> np.ndarray:
+    """pipeline.py:70-76 -- RGB float32 in [0,1], no resizing."""
+    from PIL import Image
+    try:
+        with Image.open(str(path)) as im:
+            return np.asarray(im.convert("RGB"), dtype=np.float32) / 255.0
+    except (FileNotFoundError, OSError) as exc:
+        raise FileNotFoundError(f"Unable to read image: {path}") from exc
+
+
+def _area_matrix(n_in: int, n_out: int) -> np.ndarray:
+    """INTER_AREA shrink as a [n_out, n_in] box-average matrix (fractional coverage at the cell borders)."""
+    m = np.zeros((n_out, n_in), dtype=np.float64)
+    scale = n_in / n_out
+    for o in range(n_out):
+        lo, hi = o * scale, (o + 1) * scale
+        for j in range(int(math.floor(lo)), min(int(math.ceil(hi)), n_in)):
+            m[o, j] = max(0.0, min(hi, j + 1) - max(lo, j))
+        m[o] /= m[o].sum()
+    return m
+
+
+def _cubic_matrix(n_in: int, n_out: int, a: float = -0.75) -> np.ndarray:
+    """INTER_CUBIC (Keys kernel, a=-0.75, half-pixel centres, replicated border) as a [n_out, n_in] matrix."""
+    def k(x):
+        x = abs(x)
+        if x <= 1:
+            return (a + 2) * x ** 3 - (a + 3) * x ** 2 + 1
+        if x < 2:
+            return a * x ** 3 - 5 * a * x ** 2 + 8 * a * x - 4 * a
+        return 0.0
+    m = np.zeros((n_out, n_in), dtype=np.float64)
+    scale = n_in / n_out
+    for o in range(n_out):
+        src = (o + 0.5) * scale - 0.5
+        base = int(math.floor(src))
+        for t in range(-1, 3):
+            m[o, min(max(base + t, 0), n_in - 1)] += k(src - (base + t))
+    return m
+
+
+def degrade_image(image: np.ndarray, scale: float, output_size: int) -> np.ndarray:
+    """pipeline.py:79-94 -- shrink (area) to round(size*scale), enlarge back (cubic); output NOT clipped."""
+    if not 0 < scale < 1:
+        raise ValueError("Scale must be between 0 and 1 for degradation.")
+    hr = np.clip(np.asarray(image, dtype=np.float32), 0.0, 1.0)
+    height, width = hr.shape[:2]
+    target_h = target_w = output_size if output_size > 0 else max(height, width)
+    down_h = max(1, int(round(target_h * scale)))
+    down_w = max(1, int(round(target_w * scale)))
+    ay, ax = _area_matrix(height, down_h), _area_matrix(width, down_w)
+    small = np.einsum("oh,hwc->owc", ay, hr.astype(np.float64))
+    small = np.einsum("pw,owc->opc", ax, small)
+    cy, cx = _cubic_matrix(down_h, target_h), _cubic_matrix(down_w, target_w)
+    up = np.einsum("oh,hwc->owc", cy, small)
+    up = np.einsum("pw,owc->opc", cx, up)
+    return up.astype(np.float32)
+
+
+def random_patch(image: np.ndarray, patch_size: int, *, rng: np.random.Generator | None = None) -> np.ndarray:
+    """pipeline.py:97-118."""
+    if patch_size <= 0:
+        raise ValueError("patch_size must be positive.")
+    if image.ndim != 3 or image.shape[-1] != 3:
+        raise ValueError("image must be an HxWx3 RGB array.")
+    height, width = image.shape[:2]
+    if height < patch_size or width < patch_size:
+        raise ValueError("patch_size exceeds image dimensions.")
+    generator = rng or np.random.default_rng()
+    max_y, max_x = height - patch_size, width - patch_size
+    top = int(generator.integers(0, max_y + 1)) if max_y > 0 else 0
+    left = int(generator.integers(0, max_x + 1)) if max_x > 0 else 0
+    return image[top:top + patch_size, left:left + patch_size, :]
+
+
+def random_patches(image: np.ndarray, patch_size: int, count: int, *, rng: np.random.Generator | None = None) -> np.ndarray:
+    """pipeline.py:121-136."""
+    if count <= 0:
+        raise ValueError("count must be positive.")
+    generator = rng or np.random.default_rng()
+    return np.stack([random_patch(image, patch_size, rng=generator) for _ in range(count)], axis=0)
+
+
+def grid_patches(image: np.ndarray, patch_size: int, *, stride: int | None = None, drop_remainder: bool = False) -> np.ndarray:
+    """pipeline.py:139-174 -- regular grid; bottom-right aligned patch if the stride skipped everything."""
+    if patch_size <= 0:
+        raise ValueError("patch_size must be positive.")
+    if image.ndim != 3 or image.shape[-1] != 3:
+        raise ValueError("image must be an HxWx3 RGB array.")
+    stride = stride or patch_size
+    if stride <= 0:
+        raise ValueError("stride must be positive.")
+    height, width = image.shape[:2]
+    if height < patch_size or width < patch_size:
+        raise ValueError("patch_size exceeds image dimensions.")
+    patches = [image[t:t + patch_size, l:l + patch_size, :]
+               for t in range(0, height - patch_size + 1, stride)
+               for l in range(0, width - patch_size + 1, stride)]
+    if not patches and not drop_remainder:
+        patches.append(image[-patch_size:, -patch_size:, :])
+    return np.stack(patches, axis=0) if patches else np.empty((0, patch_size, patch_size, 3), dtype=image.dtype)
+
+
+def _iter_random_patch_pairs(hr_files, patch_size, patches_per_image, scale, seed) -> Iterator[Tuple[np.ndarray, np.ndarray]]:
+    """pipeline.py:177-195 -- infinite stream; one rng drives the file shuffle and the crops."""
+    rng = np.random.default_rng(seed)
+    hr_files = list(hr_files)
+    if not hr_files:
+        return
+    while True:
+        rng.shuffle(hr_files)
+        for path in hr_files:
+            hr_image = load_rgb_image_full(path)
+            for hr_patch in random_patches(hr_image, patch_size, count=patches_per_image, rng=rng):
+                yield degrade_image(hr_patch, scale, patch_size), hr_patch
+
+
+def _iter_grid_patch_pairs(hr_files, patch_size, stride, scale) -> Iterator[Tuple[np.ndarray, np.ndarray]]:
+    """pipeline.py:198-211."""
+    for path in hr_files:
+        hr_patches = grid_patches(load_rgb_image_full(path), patch_size, stride=stride, drop_remainder=False)
+        for hr_patch in hr_patches:
+            yield degrade_image(hr_patch, scale, patch_size), hr_patch
+
+
+class PatchDataset:
+    """Re-iterable stream of (lr, hr) float32 batches [B,P,P,3]: from_generator -> shuffle(buffer) -> batch."""
+
+    def __init__(self, factory, batch_size: int, shuffle_buffer: int = 0, seed: int = 0, infinite: bool = False):
+        self.factory, self.batch_size = factory, int(batch_size)
+        self.shuffle_buffer, self.seed, self.infinite = int(shuffle_buffer), seed, infinite
+        self._epoch = 0
+
+    def __iter__(self):
+        rng = np.random.default_rng(self.seed + self._epoch)   # reshuffle_each_iteration=True
+        self._epoch += 1
+        buf: List[Tuple[np.ndarray, np.ndarray]] = []
+
+        def shuffled():
+            for item in self.factory():
+                if self.shuffle_buffer <= 0:
+                    yield item
+                    continue
+                buf.append(item)
+                if len(buf) >= self.shuffle_buffer:
+                    yield buf.pop(int(rng.integers(0, len(buf))))
+            while buf:
+                yield buf.pop(int(rng.integers(0, len(buf))))
+
+        lr, hr = [], []
+        for a, b in shuffled():
+            lr.append(a)
+            hr.append(b)
+            if len(lr) == self.batch_size:
+                yield np.stack(lr).astype(np.float32), np.stack(hr).astype(np.float32)
+                lr, hr = [], []
+        if lr:                                               # drop_remainder=False
+            yield np.stack(lr).astype(np.float32), np.stack(hr).astype(np.float32)
+
+
+def make_training_patch_dataset(hr_files: Sequence[str], patch_size: int, patches_per_image: int, scale: float,
+                                batch_size: int, seed: int, shuffle_buffer: int = 1024):
+    """pipeline.py:214-246 -> (infinite dataset, patches per epoch)."""
+    hr_files = list(hr_files)
+    if not hr_files:
+        raise ValueError("hr_files must contain at least one path.")
+    if patches_per_image <= 0:
+        raise ValueError("patches_per_image must be positive.")
+    ds = PatchDataset(lambda: _iter_random_patch_pairs(hr_files, patch_size, patches_per_image, scale, seed),
+                      batch_size, shuffle_buffer=shuffle_buffer, seed=seed, infinite=True)
+    return ds, len(hr_files) * patches_per_image
+
+
+def make_eval_patch_dataset(hr_files: Sequence[str], patch_size: int, scale: float, batch_size: int, *,
+                            stride: int | None = None):
+    """pipeline.py:249-288 -> (finite dataset, total patches, labels '<file>#patchNNNN')."""
+    hr_files = list(hr_files)
+    if not hr_files:
+        raise ValueError("hr_files must contain at least one path.")
+    stride = stride or patch_size
+    if stride <= 0:
+        raise ValueError("stride must be positive.")
+    ds = PatchDataset(lambda: _iter_grid_patch_pairs(hr_files, patch_size, stride, scale), batch_size)
+    labels: List[str] = []
+    for path in hr_files:
+        n = grid_patches(load_rgb_image_full(path), patch_size, stride=stride, drop_remainder=False).shape[0]
+        labels += [f"{Path(path).name}#patch{idx:04d}" for idx in range(n)]
+    return ds, len(labels), labels
+
+
+def split_indices(n_samples: int, train: float, val: float, test: float, seed: int):
+    """pipeline.py:291-317."""
+    if not 0 < train < 1:
+        raise ValueError("Train fraction should be between 0 and 1.")
+    if not 0 <= val < 1 or not 0 <= test < 1:
+        raise ValueError("Val/test fractions should be between 0 and 1.")
+    total = train + val + test
+    if total <= 0:
+        raise ValueError("Fractions must sum to a positive value.")
+    rng = np.random.default_rng(seed)
+    indices = np.arange(n_samples)
+    rng.shuffle(indices)
+    train_count = int(round(n_samples * train / total))
+    val_count = int(round(n_samples * val / total))
+    train_count = min(train_count, n_samples - 2) if n_samples > 2 else train_count
+    val_count = min(val_count, n_samples - train_count - 1) if n_samples > (train_count + 1) else val_count
+    if train_count <= 0:
+        raise ValueError("Train split is empty; adjust fractions.")
+    return indices[:train_count], indices[train_count:train_count + val_count], indices[train_count + val_count:]

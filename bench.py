@@ -96,7 +96,8 @@ def main():
     device = torch.device("cuda", local_rank)
 
     import torch.distributed as dist
-    if world > 1:
+    use_dist = "RANK" in os.environ          # launched by torch.distributed.run (also exercised at world size 1)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
@@ -115,12 +116,12 @@ def main():
     model._require_device()
     # non-degenerate head so that every gradient is exercised (SURVEY 8d workload recipe)
     model.set_weights(model.initial_weights(np.random.default_rng(1234), head_uniform=0.05))
-    if world > 1:
+    if use_dist:
         DataParallel(model)
     lr_img, hr_img = synth_batch(rank, batch, patch, device)
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -135,7 +136,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     ops.set_timer(None)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
@@ -173,7 +174,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(scale, depth, patch)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -1,0 +1,91 @@
+"""CPU tests of the host data path and eval metrics (adunet_amd.pipeline / metrics): deterministic contracts of
+/root/reference/shared/pipeline.py (sort order, grid patches, labels, split rules, RNG consumption) and metric
+definitions.  cv2 pixel values for degrade_image are parity unpinned (OpenCV is not installed): only its
+shape / dtype / range / resampling-identity properties are asserted."""
+import numpy as np
+import pytest
+
+from adunet_amd import metrics, pipeline
+from oracle import ops as ref
+
+
+def test_sorted_alphanumeric():
+    names = ["img10.png", "img2.png", "IMG1.png", "a_12_b3.png", "a_2_b30.png"]
+    assert pipeline.sorted_alphanumeric(names) == ["a_2_b30.png", "a_12_b3.png", "IMG1.png", "img2.png", "img10.png"]
+
+
+def test_grid_patches_and_errors():
+    img = np.arange(10 * 12 * 3, dtype=np.float32).reshape(10, 12, 3)
+    p = pipeline.grid_patches(img, 4)
+    assert p.shape == (6, 4, 4, 3) and np.array_equal(p[1], img[0:4, 4:8])
+    assert pipeline.grid_patches(img, 4, stride=3).shape[0] == 3 * 3
+    assert pipeline.grid_patches(img, 10, stride=50).shape[0] == 1
+    with pytest.raises(ValueError):
+        pipeline.grid_patches(img, 16)
+    with pytest.raises(ValueError):
+        pipeline.random_patch(img, 0)
+    rng1, rng2 = np.random.default_rng(3), np.random.default_rng(3)
+    a = pipeline.random_patches(img, 4, 5, rng=rng1)
+    tops = [(int(rng2.integers(0, 7)), int(rng2.integers(0, 9))) for _ in range(5)]     # y first, then x
+    assert all(np.array_equal(a[i], img[t:t + 4, l:l + 4]) for i, (t, l) in enumerate(tops))
+
+
+def test_split_indices_rules():
+    tr, va, te = pipeline.split_indices(100, 0.8, 0.1, 0.1, seed=1234)
+    assert (len(tr), len(va), len(te)) == (80, 10, 10)
+    assert sorted(np.concatenate([tr, va, te]).tolist()) == list(range(100))
+    exp = np.arange(100)
+    np.random.default_rng(1234).shuffle(exp)
+    assert np.array_equal(tr, exp[:80])
+    tr, va, te = pipeline.split_indices(3, 0.8, 0.1, 0.1, seed=0)
+    assert len(tr) == 1 and len(va) + len(te) == 2
+    with pytest.raises(ValueError):
+        pipeline.split_indices(10, 1.0, 0.0, 0.0, seed=0)
+
+
+def test_degrade_image_contract():
+    rng = np.random.default_rng(0)
+    hr = rng.random((32, 32, 3)).astype(np.float32)
+    lr = pipeline.degrade_image(hr, 0.5, 32)
+    assert lr.shape == (32, 32, 3) and lr.dtype == np.float32
+    assert abs(float(lr.mean()) - float(hr.mean())) < 0.02          # area + cubic preserve the mean
+    flat = np.full((16, 16, 3), 0.25, np.float32)
+    assert np.allclose(pipeline.degrade_image(flat, 0.5, 16), 0.25, atol=1e-6)
+    with pytest.raises(ValueError):
+        pipeline.degrade_image(hr, 1.5, 32)
+
+
+def test_eval_dataset_labels_and_batches(tmp_path):
+    from PIL import Image
+    rng = np.random.default_rng(1)
+    files = []
+    for name, (h, w) in (("img2.png", (40, 72)), ("img10.png", (32, 32))):
+        Image.fromarray((rng.random((h, w, 3)) * 255).astype(np.uint8)).save(tmp_path / name)
+        files.append(str(tmp_path / name))
+    files = pipeline.sorted_alphanumeric(files)
+    ds, total, labels = pipeline.make_eval_patch_dataset(files, 32, 0.5, batch_size=2)
+    assert total == 3 and labels == ["img2.png#patch0000", "img2.png#patch0001", "img10.png#patch0000"]
+    batches = list(ds)
+    assert [b[0].shape[0] for b in batches] == [2, 1] and batches[0][0].dtype == np.float32
+    assert batches[0][1].min() >= 0 and batches[0][1].max() <= 1
+    tds, n = pipeline.make_training_patch_dataset(files, 16, 3, 0.5, batch_size=4, seed=7, shuffle_buffer=4)
+    it = iter(tds)
+    lr, hr = next(it)
+    assert n == 6 and lr.shape == (4, 16, 16, 3) and hr.shape == (4, 16, 16, 3)
+
+
+def test_metrics_definitions():
+    rng = np.random.default_rng(2)
+    a = rng.random((2, 48, 48, 3)).astype(np.float32)
+    assert np.allclose(metrics.rgb_to_luma_bt601(a), ref.rgb_to_luma_bt601(a.astype(np.float64)), atol=1e-6)
+    assert [metrics.infer_eval_shave(s) for s in (0.5, 0.25, 0.6, 0.2, 0.8)] == [4, 8, 4, 10, 2]
+    assert metrics.infer_eval_shave(0.5, 3) == 3 and ref.infer_eval_shave(0.3) == metrics.infer_eval_shave(0.3)
+    y, b = a[..., :1], np.clip(a[..., :1] + 0.05 * rng.standard_normal((2, 48, 48, 1)).astype(np.float32), 0, 1)
+    assert np.allclose(metrics.psnr_per_image(y, b), ref.psnr_per_image(y.astype(np.float64), b.astype(np.float64)), atol=1e-4)
+    assert np.isinf(metrics.psnr_per_image(y, y)).all()
+    s = metrics.ssim_per_image(y, b)
+    assert np.allclose(metrics.ssim_per_image(y, y), 1.0) and (s < 1).all() and (s > 0.3).all()
+    big = rng.random((1, 192, 192, 1)).astype(np.float32)
+    assert np.allclose(metrics.msssim_per_image(big, big), 1.0, atol=1e-6)
+    noisy = np.clip(big + 0.1 * rng.standard_normal(big.shape).astype(np.float32), 0, 1)
+    assert 0 < float(metrics.msssim_per_image(big, noisy)[0]) < 1
