@@ -1,0 +1,627 @@
+// Tier-2 ops of the segmentation models: BatchNormalization (+ReLU), MaxPooling2D(2),
+// the pixel shuffles behind Conv2DTranspose(k=2, s=2), and the sigmoid / BCE / Dice head.
+//   Segmenation/code/train_adaptive_unet.py:258-362 (BN conv_block, MaxPool, bilinear x2, sigmoid head, losses)
+//   Segmenation/code/unet_vinillia.py:66-69 (Conv2DTranspose(nf, 2, strides=2))
+// All HBM-bound row kernels over NHWC tensors; statistics and reductions in fp32, deterministic two-stage sums.
+#include "common.h"
+
+namespace {
+
+constexpr int NBLK = 512;   // blocks of the column-reduction kernels (partials per block in ws)
+
+// ------------------------------------------------------------------ per-channel column statistics
+// part[block][2][c] = { sum_p (x[p][ch] - shift[ch]), sum_p (x[p][ch] - shift[ch])^2 }
+template <typename T>
+__global__ __launch_bounds__(256) void colstats_kernel(const T* __restrict__ x, const float* __restrict__ shift,
+                                                       float* __restrict__ part, int64_t npix, int c) {
+    constexpr int EPT = ElemTraits<T>::EPT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = reinterpret_cast<float*>(smem);   // [rows][2][c]
+    const int vecs = c / EPT;                       // threads per pixel row
+    const int rows = 256 / vecs > 0 ? 256 / vecs : 1;
+    const int tid = threadIdx.x;
+    const int v = tid % vecs, r = tid / vecs;
+    float s1[EPT], s2[EPT], sh[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) { s1[e] = s2[e] = 0.f; sh[e] = shift ? shift[v * EPT + e] : 0.f; }
+    if (r < rows)
+        for (int64_t p = (int64_t)blockIdx.x * rows + r; p < npix; p += (int64_t)gridDim.x * rows) {
+            Vec16<T> ld;
+            float f[EPT];
+            ld.load(x + p * c + v * EPT);
+            ld.to_f32(f);
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) { float d = f[e] - sh[e]; s1[e] += d; s2[e] += d * d; }
+        }
+    if (r < rows) {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            red[(r * 2 + 0) * c + v * EPT + e] = s1[e];
+            red[(r * 2 + 1) * c + v * EPT + e] = s2[e];
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * c; i += 256) {
+        float s = 0.f;
+        for (int q = 0; q < rows; ++q) s += red[q * 2 * c + i];
+        part[(size_t)blockIdx.x * 2 * c + i] = s;
+    }
+}
+
+// out0[ch] = sum_b part[b][0][ch] * scale0 (+ add0[ch]), out1[ch] = sum_b part[b][1][ch] * scale1
+__global__ void colstats_finish_kernel(const float* __restrict__ part, int nblocks, int c, float scale0, float scale1,
+                                       const float* __restrict__ add0, float* __restrict__ out0, float* __restrict__ out1) {
+    int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    float a = 0.f, b = 0.f;
+    for (int k = 0; k < nblocks; ++k) { a += part[(size_t)k * 2 * c + ch]; b += part[(size_t)k * 2 * c + c + ch]; }
+    if (out0) out0[ch] = a * scale0 + (add0 ? add0[ch] : 0.f);
+    if (out1) out1[ch] = b * scale1;
+}
+
+// rstd = rsqrt(var + eps); moving <- moving * m + batch * (1 - m)   (Keras BatchNormalization, momentum 0.99)
+__global__ void bn_finalize_kernel(const float* __restrict__ mean, const float* __restrict__ var, float* __restrict__ rstd,
+                                   float* __restrict__ mmean, float* __restrict__ mvar, float momentum, float eps, int c) {
+    int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    rstd[ch] = rsqrtf(var[ch] + eps);
+    if (mmean) mmean[ch] = mmean[ch] * momentum + mean[ch] * (1.f - momentum);
+    if (mvar) mvar[ch] = mvar[ch] * momentum + var[ch] * (1.f - momentum);
+}
+
+// y = relu?((x - mean) * rstd * gamma + beta)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ mean,
+                                                       const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, T* __restrict__ y, int64_t npix, int c,
+                                                       int relu) {
+    constexpr int EPT = ElemTraits<T>::EPT;
+    const int vecs = c / EPT;
+    const int64_t total = npix * vecs;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int v = (int)(i % vecs);
+        Vec16<T> ld, st;
+        float f[EPT], o[EPT];
+        ld.load(x + i * EPT);
+        ld.to_f32(f);
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int ch = v * EPT + e;
+            float t = (f[e] - mean[ch]) * rstd[ch] * gamma[ch] + beta[ch];
+            o[e] = relu ? fmaxf(t, 0.f) : t;
+        }
+        st.from_f32(o);
+        st.store(y + i * EPT);
+    }
+}
+
+// backward pass 1: part[block][2][c] = { sum dyl * xhat, sum dyl }  with dyl = dy * [y > 0]
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float* __restrict__ part, int64_t npix, int c, int relu) {
+    constexpr int EPT = ElemTraits<T>::EPT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = reinterpret_cast<float*>(smem);
+    const int vecs = c / EPT;
+    const int rows = 256 / vecs > 0 ? 256 / vecs : 1;
+    const int tid = threadIdx.x;
+    const int v = tid % vecs, r = tid / vecs;
+    float s1[EPT], s2[EPT], mu[EPT], rs[EPT], ga[EPT], be[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int ch = v * EPT + e;
+        s1[e] = s2[e] = 0.f; mu[e] = mean[ch]; rs[e] = rstd[ch]; ga[e] = gamma[ch]; be[e] = beta[ch];
+    }
+    if (r < rows)
+        for (int64_t p = (int64_t)blockIdx.x * rows + r; p < npix; p += (int64_t)gridDim.x * rows) {
+            Vec16<T> l0, l1;
+            float f[EPT], d[EPT];
+            l0.load(x + p * c + v * EPT);
+            l1.load(dy + p * c + v * EPT);
+            l0.to_f32(f);
+            l1.to_f32(d);
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) {
+                float h = (f[e] - mu[e]) * rs[e];
+                float dl = (relu && !(h * ga[e] + be[e] > 0.f)) ? 0.f : d[e];
+                s1[e] += dl * h;
+                s2[e] += dl;
+            }
+        }
+    if (r < rows) {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            red[(r * 2 + 0) * c + v * EPT + e] = s1[e];
+            red[(r * 2 + 1) * c + v * EPT + e] = s2[e];
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * c; i += 256) {
+        float s = 0.f;
+        for (int q = 0; q < rows; ++q) s += red[q * 2 * c + i];
+        part[(size_t)blockIdx.x * 2 * c + i] = s;
+    }
+}
+
+// backward pass 2: dx = gamma * rstd * (dyl - dbeta/m - xhat * dgamma/m)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+                                                           T* __restrict__ dx, int64_t npix, int c, int relu) {
+    constexpr int EPT = ElemTraits<T>::EPT;
+    const int vecs = c / EPT;
+    const int64_t total = npix * vecs;
+    const float inv_m = 1.0f / (float)npix;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int v = (int)(i % vecs);
+        Vec16<T> l0, l1, st;
+        float f[EPT], d[EPT], o[EPT];
+        l0.load(x + i * EPT);
+        l1.load(dy + i * EPT);
+        l0.to_f32(f);
+        l1.to_f32(d);
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int ch = v * EPT + e;
+            float h = (f[e] - mean[ch]) * rstd[ch];
+            float dl = (relu && !(h * gamma[ch] + beta[ch] > 0.f)) ? 0.f : d[e];
+            o[e] = gamma[ch] * rstd[ch] * (dl - dbeta[ch] * inv_m - h * dgamma[ch] * inv_m);
+        }
+        st.from_f32(o);
+        st.store(dx + i * EPT);
+    }
+}
+
+// ------------------------------------------------------------------ MaxPooling2D(2)
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int n, int h, int w,
+                                                           int c) {
+    constexpr int EPT = ElemTraits<T>::EPT;
+    const int vecs = c / EPT, oh = h / 2, ow = w / 2;
+    const int64_t total = (int64_t)n * oh * ow * vecs;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        int v = (int)(i % vecs);
+        int64_t p = i / vecs;
+        int ox = (int)(p % ow);
+        int64_t r = p / ow;
+        int oy = (int)(r % oh), nn = (int)(r / oh);
+        float m[EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) m[e] = -INFINITY;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                Vec16<T> ld;
+                float f[EPT];
+                ld.load(x + (((int64_t)nn * h + 2 * oy + a) * w + 2 * ox + b) * c + v * EPT);
+                ld.to_f32(f);
+#pragma unroll
+                for (int e = 0; e < EPT; ++e) m[e] = fmaxf(m[e], f[e]);
+            }
+        Vec16<T> st;
+        st.from_f32(m);
+        st.store(y + p * c + v * EPT);
+    }
+}
+
+// gradient goes to the FIRST maximal element of each window (TF MaxPoolGrad); untouched rows/cols get zero
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                           T* __restrict__ dx, int n, int h, int w, int c) {
+    constexpr int EPT = ElemTraits<T>::EPT;
+    const int vecs = c / EPT, oh = h / 2, ow = w / 2;
+    const int64_t total = (int64_t)n * h * w * vecs;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        int v = (int)(i % vecs);
+        int64_t p = i / vecs;
+        int xx = (int)(p % w);
+        int64_t r = p / w;
+        int yy = (int)(r % h), nn = (int)(r / h);
+        float o[EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) o[e] = 0.f;
+        const int oy = yy / 2, ox = xx / 2;
+        if (oy < oh && ox < ow) {
+            float win[4][EPT], g[EPT];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                Vec16<T> ld;
+                ld.load(x + (((int64_t)nn * h + 2 * oy + (k >> 1)) * w + 2 * ox + (k & 1)) * c + v * EPT);
+                ld.to_f32(win[k]);
+            }
+            Vec16<T> lg;
+            lg.load(dy + (((int64_t)nn * oh + oy) * ow + ox) * c + v * EPT);
+            lg.to_f32(g);
+            const int me = (yy & 1) * 2 + (xx & 1);
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) {
+                int arg = 0;
+                float best = win[0][e];
+#pragma unroll
+                for (int k = 1; k < 4; ++k)
+                    if (win[k][e] > best) { best = win[k][e]; arg = k; }
+                o[e] = arg == me ? g[e] : 0.f;
+            }
+        }
+        Vec16<T> st;
+        st.from_f32(o);
+        st.store(dx + p * c + v * EPT);
+    }
+}
+
+// ------------------------------------------------------------------ pixel shuffles for Conv2DTranspose(2, s=2)
+// depth_to_space: x[n,h,w,4*c] (blocks ordered a*2+b) -> y[n,2h,2w,c];  TO_SPACE = false is the inverse.
+template <typename T, bool TO_SPACE>
+__global__ __launch_bounds__(256) void shuffle2_kernel(const T* __restrict__ x, T* __restrict__ y, int n, int h, int w, int c) {
+    constexpr int EPT = ElemTraits<T>::EPT;
+    const int vecs = c / EPT;
+    const int64_t total = (int64_t)n * h * w * 4 * vecs;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        int v = (int)(i % vecs);
+        int64_t r = i / vecs;
+        int ab = (int)(r % 4);
+        int64_t p = r / 4;                                   // low-res pixel
+        int xx = (int)(p % w);
+        int64_t q = p / w;
+        int yy = (int)(q % h), nn = (int)(q / h);
+        const int64_t lo = (p * 4 + ab) * c + v * EPT;
+        const int64_t hi = ((((int64_t)nn * 2 * h + 2 * yy + (ab >> 1)) * 2 * w) + 2 * xx + (ab & 1)) * c + v * EPT;
+        if (TO_SPACE) *reinterpret_cast<uint4*>(y + hi) = *reinterpret_cast<const uint4*>(x + lo);
+        else *reinterpret_cast<uint4*>(y + lo) = *reinterpret_cast<const uint4*>(x + hi);
+    }
+}
+
+// ------------------------------------------------------------------ segmentation head
+// p = sigmoid(xh @ w[ch] + b); per-sample sums for BCE / Dice / IoU:
+//   sums[n][0] = sum BCE(y, clip(p)),  [1] = sum y*pc,  [2] = sum (y + pc)     (pc = clip(p, 1e-7, 1-1e-7))
+template <int G>
+__device__ __forceinline__ float gsum2(float v) {
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <typename T, int G>
+__global__ __launch_bounds__(256) void seg_head_fwd_kernel(const T* __restrict__ xh, const float* __restrict__ w,
+                                                           const float* __restrict__ b, const float* __restrict__ target,
+                                                           float* __restrict__ prob, float* __restrict__ part, int64_t ppi,
+                                                           int ch) {
+    constexpr int EPT = ElemTraits<T>::EPT;
+    constexpr int PPB = 256 / G;
+    __shared__ float sm[3][4];
+    const int tid = threadIdx.x, gl = tid % G, gp = tid / G;
+    const int img = blockIdx.y;
+    float wl[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) wl[e] = w[gl * EPT + e];
+    const float b0 = b[0];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int64_t q = (int64_t)blockIdx.x * PPB + gp; q < ppi; q += (int64_t)gridDim.x * PPB) {
+        const int64_t pix = (int64_t)img * ppi + q;
+        Vec16<T> ld;
+        float x[EPT];
+        ld.load(xh + pix * ch + gl * EPT);
+        ld.to_f32(x);
+        float r = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) r += x[e] * wl[e];
+        r = gsum2<G>(r) + b0;
+        if (gl == 0) {
+            const float p = 1.f / (1.f + __expf(-r));
+            prob[pix] = p;
+            if (target) {
+                const float y = target[pix];
+                const float pc = fminf(fmaxf(p, 1e-7f), 1.f - 1e-7f);
+                s0 += -(y * __logf(pc) + (1.f - y) * __logf(1.f - pc));
+                s1 += y * pc;
+                s2 += y + pc;
+            }
+        }
+    }
+    float v[3] = {s0, s1, s2};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o, 64);
+        if ((tid & 63) == 0) sm[k][tid >> 6] = v[k];
+    }
+    __syncthreads();
+    if (tid < 3 && part)
+        part[((size_t)img * gridDim.x + blockIdx.x) * 3 + tid] = sm[tid][0] + sm[tid][1] + sm[tid][2] + sm[tid][3];
+}
+
+__global__ void seg_sums_kernel(const float* __restrict__ part, int n, int bpi, float* __restrict__ sums) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * 3) return;
+    int img = i / 3, k = i % 3;
+    float s = 0.f;
+    for (int j = 0; j < bpi; ++j) s += part[((size_t)img * bpi + j) * 3 + k];
+    sums[i] = s;
+}
+
+// backward: dL/dp = wb * dBCE/dp / count + wd * (-(1/n) * d dice_n / dp); dlogit = dL/dp * p (1 - p)
+template <typename T, int G>
+__global__ __launch_bounds__(256) void seg_head_bwd_kernel(const T* __restrict__ xh, const float* __restrict__ w,
+                                                           const float* __restrict__ target, const float* __restrict__ prob,
+                                                           const float* __restrict__ sums, T* __restrict__ dxh,
+                                                           float* __restrict__ part, int64_t ppi, int ch, int n, float wb,
+                                                           float wd, float smooth) {
+    constexpr int EPT = ElemTraits<T>::EPT;
+    constexpr int PPB = 256 / G;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = reinterpret_cast<float*>(smem);   // [PPB][ch + 1]
+    const int ncol = ch + 1;
+    const int tid = threadIdx.x, gl = tid % G, gp = tid / G;
+    const int img = blockIdx.y;
+    float wl[EPT], aw[EPT], ab = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) { wl[e] = w[gl * EPT + e]; aw[e] = 0.f; }
+    const float inter = sums[img * 3 + 1], uni = sums[img * 3 + 2];
+    const float den = uni + smooth;
+    const float inv_cnt = 1.0f / ((float)n * (float)ppi);
+    for (int64_t q = (int64_t)blockIdx.x * PPB + gp; q < ppi; q += (int64_t)gridDim.x * PPB) {
+        const int64_t pix = (int64_t)img * ppi + q;
+        const float p = prob[pix], y = target[pix];
+        const bool inside = p >= 1e-7f && p <= 1.f - 1e-7f;     // clip_by_value passes the gradient inside only
+        const float pc = fminf(fmaxf(p, 1e-7f), 1.f - 1e-7f);
+        float dp = 0.f;
+        if (inside) {
+            dp = wb * (-(y / pc) + (1.f - y) / (1.f - pc)) * inv_cnt;
+            const float ddice = (2.f * y * den - (2.f * inter + smooth)) / (den * den);
+            dp += -wd * ddice / (float)n;
+        }
+        const float g = dp * p * (1.f - p);
+        Vec16<T> ld, st;
+        float x[EPT], dx[EPT];
+        ld.load(xh + pix * ch + gl * EPT);
+        ld.to_f32(x);
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) { dx[e] = g * wl[e]; aw[e] += x[e] * g; }
+        ab += g;
+        st.from_f32(dx);
+        st.store(dxh + pix * ch + gl * EPT);
+    }
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) red[gp * ncol + gl * EPT + e] = aw[e];
+    if (gl == 0) red[gp * ncol + ch] = ab;
+    __syncthreads();
+    for (int i = tid; i < ncol; i += 256) {
+        float s = 0.f;
+        for (int p = 0; p < PPB; ++p) s += red[p * ncol + i];
+        part[((size_t)img * gridDim.x + blockIdx.x) * ncol + i] = s;
+    }
+}
+
+__global__ void rows_sum_kernel(const float* __restrict__ part, int nrows, int ncols, float* __restrict__ o0, int n0,
+                                float* __restrict__ o1) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ncols) return;
+    float s = 0.f;
+    for (int r = 0; r < nrows; ++r) s += part[(size_t)r * ncols + i];
+    if (i < n0) o0[i] = s; else o1[i - n0] = s;
+}
+
+static int ew_blocks(int64_t total) {
+    int64_t b = (total + 255) / 256;
+    return (int)(b < 16384 ? b : 16384);
+}
+
+static bool chan_ok(int c, int ept) { return c > 0 && c % ept == 0 && (c / ept) <= 256; }
+
+template <typename T>
+int colstats(const void* x, const float* shift, float* part, int64_t npix, int c, hipStream_t s, int* nblocks) {
+    const int vecs = c / ElemTraits<T>::EPT;
+    const int rows = 256 / vecs > 0 ? 256 / vecs : 1;
+    int64_t nb = (npix + rows - 1) / rows;
+    *nblocks = (int)(nb < NBLK ? nb : NBLK);
+    size_t lds = (size_t)rows * 2 * c * sizeof(float);
+    if (lds > 64 * 1024) return ad_set_error(AD_ERR_ARG, "batchnorm: c=%d too wide", c);
+    colstats_kernel<T><<<*nblocks, 256, lds, s>>>((const T*)x, shift, part, npix, c);
+    AD_LAUNCH_CHECK("colstats");
+    return AD_OK;
+}
+
+}  // namespace
+
+extern "C" size_t ad_batchnorm_ws_bytes(int c) { return (size_t)NBLK * 2 * c * sizeof(float); }
+
+extern "C" int ad_batchnorm_relu_fwd_train(const void* z, const float* gamma, const float* beta, void* y, float* save_mean,
+                                           float* save_rstd, float* save_var, float* moving_mean, float* moving_var,
+                                           float momentum, int64_t npix, int c, float eps, int relu, void* ws,
+                                           size_t ws_bytes, int dtype, void* stream) {
+    AD_REQUIRE(dtype == AD_BF16 || dtype == AD_F32, "ad_batchnorm_relu_fwd_train: bad dtype %d", dtype);
+    const int ept = dtype == AD_BF16 ? 8 : 4;
+    AD_REQUIRE(npix > 0 && chan_ok(c, ept), "ad_batchnorm_relu_fwd_train: unsupported npix=%ld c=%d", (long)npix, c);
+    if (!ws || ws_bytes < ad_batchnorm_ws_bytes(c)) return ad_set_error(AD_ERR_WS, "ad_batchnorm: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    float* part = (float*)ws;
+    int nb = 0, rc;
+    // pass 1: mean; pass 2: centred second moment (biased variance, as Keras)
+    rc = dtype == AD_BF16 ? colstats<bf16_t>(z, nullptr, part, npix, c, s, &nb) : colstats<float>(z, nullptr, part, npix, c, s, &nb);
+    if (rc) return rc;
+    colstats_finish_kernel<<<(c + 255) / 256, 256, 0, s>>>(part, nb, c, 1.0f / (float)npix, 0.f, nullptr, save_mean, nullptr);
+    rc = dtype == AD_BF16 ? colstats<bf16_t>(z, save_mean, part, npix, c, s, &nb) : colstats<float>(z, save_mean, part, npix, c, s, &nb);
+    if (rc) return rc;
+    colstats_finish_kernel<<<(c + 255) / 256, 256, 0, s>>>(part, nb, c, 0.f, 1.0f / (float)npix, nullptr, nullptr, save_var);
+    bn_finalize_kernel<<<(c + 255) / 256, 256, 0, s>>>(save_mean, save_var, save_rstd, moving_mean, moving_var, momentum, eps, c);
+    const int blocks = ew_blocks(npix * (c / ept));
+    if (dtype == AD_BF16)
+        bn_apply_kernel<bf16_t><<<blocks, 256, 0, s>>>((const bf16_t*)z, save_mean, save_rstd, gamma, beta, (bf16_t*)y, npix, c, relu);
+    else
+        bn_apply_kernel<float><<<blocks, 256, 0, s>>>((const float*)z, save_mean, save_rstd, gamma, beta, (float*)y, npix, c, relu);
+    AD_LAUNCH_CHECK("ad_batchnorm_relu_fwd_train");
+    return AD_OK;
+}
+
+extern "C" int ad_batchnorm_relu_fwd_infer(const void* z, const float* gamma, const float* beta, const float* moving_mean,
+                                           const float* moving_var, void* y, float* rstd_tmp, int64_t npix, int c, float eps,
+                                           int relu, int dtype, void* stream) {
+    AD_REQUIRE(dtype == AD_BF16 || dtype == AD_F32, "ad_batchnorm_relu_fwd_infer: bad dtype %d", dtype);
+    const int ept = dtype == AD_BF16 ? 8 : 4;
+    AD_REQUIRE(npix > 0 && chan_ok(c, ept), "ad_batchnorm_relu_fwd_infer: unsupported npix=%ld c=%d", (long)npix, c);
+    hipStream_t s = (hipStream_t)stream;
+    bn_finalize_kernel<<<(c + 255) / 256, 256, 0, s>>>(moving_mean, moving_var, rstd_tmp, nullptr, nullptr, 0.f, eps, c);
+    const int blocks = ew_blocks(npix * (c / ept));
+    if (dtype == AD_BF16)
+        bn_apply_kernel<bf16_t><<<blocks, 256, 0, s>>>((const bf16_t*)z, moving_mean, rstd_tmp, gamma, beta, (bf16_t*)y, npix, c, relu);
+    else
+        bn_apply_kernel<float><<<blocks, 256, 0, s>>>((const float*)z, moving_mean, rstd_tmp, gamma, beta, (float*)y, npix, c, relu);
+    AD_LAUNCH_CHECK("ad_batchnorm_relu_fwd_infer");
+    return AD_OK;
+}
+
+extern "C" int ad_batchnorm_relu_bwd(const void* dy, const void* z, const float* save_mean, const float* save_rstd,
+                                     const float* gamma, const float* beta, void* dz, float* dgamma, float* dbeta,
+                                     int64_t npix, int c, int relu, void* ws, size_t ws_bytes, int dtype, void* stream) {
+    AD_REQUIRE(dtype == AD_BF16 || dtype == AD_F32, "ad_batchnorm_relu_bwd: bad dtype %d", dtype);
+    const int ept = dtype == AD_BF16 ? 8 : 4;
+    AD_REQUIRE(npix > 0 && chan_ok(c, ept), "ad_batchnorm_relu_bwd: unsupported npix=%ld c=%d", (long)npix, c);
+    if (!ws || ws_bytes < ad_batchnorm_ws_bytes(c)) return ad_set_error(AD_ERR_WS, "ad_batchnorm: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    float* part = (float*)ws;
+    const int vecs = c / ept;
+    const int rows = 256 / vecs > 0 ? 256 / vecs : 1;
+    int64_t nbl = (npix + rows - 1) / rows;
+    const int nb = (int)(nbl < NBLK ? nbl : NBLK);
+    size_t lds = (size_t)rows * 2 * c * sizeof(float);
+    if (dtype == AD_BF16)
+        bn_bwd_reduce_kernel<bf16_t><<<nb, 256, lds, s>>>((const bf16_t*)dy, (const bf16_t*)z, save_mean, save_rstd, gamma, beta, part, npix, c, relu);
+    else
+        bn_bwd_reduce_kernel<float><<<nb, 256, lds, s>>>((const float*)dy, (const float*)z, save_mean, save_rstd, gamma, beta, part, npix, c, relu);
+    colstats_finish_kernel<<<(c + 255) / 256, 256, 0, s>>>(part, nb, c, 1.f, 1.f, nullptr, dgamma, dbeta);
+    const int blocks = ew_blocks(npix * vecs);
+    if (dtype == AD_BF16)
+        bn_bwd_apply_kernel<bf16_t><<<blocks, 256, 0, s>>>((const bf16_t*)dy, (const bf16_t*)z, save_mean, save_rstd, gamma, beta, dgamma, dbeta, (bf16_t*)dz, npix, c, relu);
+    else
+        bn_bwd_apply_kernel<float><<<blocks, 256, 0, s>>>((const float*)dy, (const float*)z, save_mean, save_rstd, gamma, beta, dgamma, dbeta, (float*)dz, npix, c, relu);
+    AD_LAUNCH_CHECK("ad_batchnorm_relu_bwd");
+    return AD_OK;
+}
+
+extern "C" int ad_colsum(const void* x, float* out, int64_t npix, int c, void* ws, size_t ws_bytes, int dtype, void* stream) {
+    AD_REQUIRE(dtype == AD_BF16 || dtype == AD_F32, "ad_colsum: bad dtype %d", dtype);
+    const int ept = dtype == AD_BF16 ? 8 : 4;
+    AD_REQUIRE(npix > 0 && chan_ok(c, ept), "ad_colsum: unsupported npix=%ld c=%d", (long)npix, c);
+    if (!ws || ws_bytes < ad_batchnorm_ws_bytes(c)) return ad_set_error(AD_ERR_WS, "ad_colsum: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    int nb = 0;
+    int rc = dtype == AD_BF16 ? colstats<bf16_t>(x, nullptr, (float*)ws, npix, c, s, &nb) : colstats<float>(x, nullptr, (float*)ws, npix, c, s, &nb);
+    if (rc) return rc;
+    colstats_finish_kernel<<<(c + 255) / 256, 256, 0, s>>>((const float*)ws, nb, c, 1.f, 0.f, nullptr, out, nullptr);
+    AD_LAUNCH_CHECK("ad_colsum");
+    return AD_OK;
+}
+
+extern "C" int ad_maxpool2_fwd(const void* x, void* y, int n, int h, int w, int c, int dtype, void* stream) {
+    AD_REQUIRE(dtype == AD_BF16 || dtype == AD_F32, "ad_maxpool2_fwd: bad dtype %d", dtype);
+    const int ept = dtype == AD_BF16 ? 8 : 4;
+    AD_REQUIRE(n > 0 && h >= 2 && w >= 2 && c > 0 && c % ept == 0, "ad_maxpool2_fwd: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    const int blocks = ew_blocks((int64_t)n * (h / 2) * (w / 2) * (c / ept));
+    if (dtype == AD_BF16) maxpool2_fwd_kernel<bf16_t><<<blocks, 256, 0, s>>>((const bf16_t*)x, (bf16_t*)y, n, h, w, c);
+    else maxpool2_fwd_kernel<float><<<blocks, 256, 0, s>>>((const float*)x, (float*)y, n, h, w, c);
+    AD_LAUNCH_CHECK("ad_maxpool2_fwd");
+    return AD_OK;
+}
+
+extern "C" int ad_maxpool2_bwd(const void* dy, const void* x, void* dx, int n, int h, int w, int c, int dtype, void* stream) {
+    AD_REQUIRE(dtype == AD_BF16 || dtype == AD_F32, "ad_maxpool2_bwd: bad dtype %d", dtype);
+    const int ept = dtype == AD_BF16 ? 8 : 4;
+    AD_REQUIRE(n > 0 && h >= 2 && w >= 2 && c > 0 && c % ept == 0, "ad_maxpool2_bwd: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    const int blocks = ew_blocks((int64_t)n * h * w * (c / ept));
+    if (dtype == AD_BF16) maxpool2_bwd_kernel<bf16_t><<<blocks, 256, 0, s>>>((const bf16_t*)dy, (const bf16_t*)x, (bf16_t*)dx, n, h, w, c);
+    else maxpool2_bwd_kernel<float><<<blocks, 256, 0, s>>>((const float*)dy, (const float*)x, (float*)dx, n, h, w, c);
+    AD_LAUNCH_CHECK("ad_maxpool2_bwd");
+    return AD_OK;
+}
+
+extern "C" int ad_pixel_shuffle2(const void* x, void* y, int n, int h, int w, int c, int to_space, int dtype, void* stream) {
+    AD_REQUIRE(dtype == AD_BF16 || dtype == AD_F32, "ad_pixel_shuffle2: bad dtype %d", dtype);
+    const int ept = dtype == AD_BF16 ? 8 : 4;
+    AD_REQUIRE(n > 0 && h > 0 && w > 0 && c > 0 && c % ept == 0, "ad_pixel_shuffle2: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    const int blocks = ew_blocks((int64_t)n * h * w * 4 * (c / ept));
+    if (dtype == AD_BF16) {
+        if (to_space) shuffle2_kernel<bf16_t, true><<<blocks, 256, 0, s>>>((const bf16_t*)x, (bf16_t*)y, n, h, w, c);
+        else shuffle2_kernel<bf16_t, false><<<blocks, 256, 0, s>>>((const bf16_t*)x, (bf16_t*)y, n, h, w, c);
+    } else {
+        if (to_space) shuffle2_kernel<float, true><<<blocks, 256, 0, s>>>((const float*)x, (float*)y, n, h, w, c);
+        else shuffle2_kernel<float, false><<<blocks, 256, 0, s>>>((const float*)x, (float*)y, n, h, w, c);
+    }
+    AD_LAUNCH_CHECK("ad_pixel_shuffle2");
+    return AD_OK;
+}
+
+#define SEG_DISPATCH(...)                                          \
+    switch (g) {                                                   \
+        case 4: { constexpr int G_ = 4; __VA_ARGS__ } break;       \
+        case 8: { constexpr int G_ = 8; __VA_ARGS__ } break;       \
+        case 16: { constexpr int G_ = 16; __VA_ARGS__ } break;     \
+        case 32: { constexpr int G_ = 32; __VA_ARGS__ } break;     \
+        default: { constexpr int G_ = 64; __VA_ARGS__ } break;     \
+    }
+
+static bool seg_group(int ch, int ept, int* g) {
+    if (ch <= 0 || ch % ept) return false;
+    int v = ch / ept;
+    if (v != 4 && v != 8 && v != 16 && v != 32 && v != 64) return false;
+    *g = v;
+    return true;
+}
+
+static int seg_bpi(int64_t ppi, int g) {
+    int64_t ppb = 256 / g;
+    int64_t nb = (ppi + ppb - 1) / ppb;
+    return (int)(nb < 64 ? nb : 64);
+}
+
+extern "C" size_t ad_seg_head_ws_bytes(int n, int ch) { return (size_t)n * 64 * (ch + 3) * sizeof(float); }
+
+extern "C" int ad_seg_head_fwd(const void* xh, const float* w, const float* b, const float* target, float* prob, float* sums,
+                               int n, int64_t pix_per_img, int ch, void* ws, size_t ws_bytes, int dtype, void* stream) {
+    AD_REQUIRE(dtype == AD_BF16 || dtype == AD_F32, "ad_seg_head_fwd: bad dtype %d", dtype);
+    int g;
+    AD_REQUIRE(n > 0 && pix_per_img > 0 && seg_group(ch, dtype == AD_BF16 ? 8 : 4, &g), "ad_seg_head_fwd: unsupported shape ch=%d", ch);
+    const int bpi = seg_bpi(pix_per_img, g);
+    float* part = nullptr;
+    if (target) {
+        if (!ws || ws_bytes < (size_t)n * bpi * 3 * sizeof(float)) return ad_set_error(AD_ERR_WS, "ad_seg_head_fwd: workspace too small");
+        part = (float*)ws;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(bpi, n);
+    if (dtype == AD_BF16) { SEG_DISPATCH(seg_head_fwd_kernel<bf16_t, G_><<<grid, 256, 0, s>>>((const bf16_t*)xh, w, b, target, prob, part, pix_per_img, ch);) }
+    else { SEG_DISPATCH(seg_head_fwd_kernel<float, G_><<<grid, 256, 0, s>>>((const float*)xh, w, b, target, prob, part, pix_per_img, ch);) }
+    AD_LAUNCH_CHECK("ad_seg_head_fwd");
+    if (target) {
+        seg_sums_kernel<<<(n * 3 + 255) / 256, 256, 0, s>>>(part, n, bpi, sums);
+        AD_LAUNCH_CHECK("seg_sums");
+    }
+    return AD_OK;
+}
+
+extern "C" int ad_seg_head_bwd(const void* xh, const float* w, const float* target, const float* prob, const float* sums,
+                               void* dxh, float* dw, float* db, int n, int64_t pix_per_img, int ch, float bce_weight,
+                               float dice_weight, float smooth, void* ws, size_t ws_bytes, int dtype, void* stream) {
+    AD_REQUIRE(dtype == AD_BF16 || dtype == AD_F32, "ad_seg_head_bwd: bad dtype %d", dtype);
+    int g;
+    AD_REQUIRE(n > 0 && pix_per_img > 0 && seg_group(ch, dtype == AD_BF16 ? 8 : 4, &g), "ad_seg_head_bwd: unsupported shape ch=%d", ch);
+    const int bpi = seg_bpi(pix_per_img, g);
+    const int ncol = ch + 1;
+    if (!ws || ws_bytes < (size_t)n * bpi * ncol * sizeof(float)) return ad_set_error(AD_ERR_WS, "ad_seg_head_bwd: workspace too small");
+    size_t lds = (size_t)(256 / g) * ncol * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(bpi, n);
+    if (dtype == AD_BF16) { SEG_DISPATCH(seg_head_bwd_kernel<bf16_t, G_><<<grid, 256, lds, s>>>((const bf16_t*)xh, w, target, prob, sums, (bf16_t*)dxh, (float*)ws, pix_per_img, ch, n, bce_weight, dice_weight, smooth);) }
+    else { SEG_DISPATCH(seg_head_bwd_kernel<float, G_><<<grid, 256, lds, s>>>((const float*)xh, w, target, prob, sums, (float*)dxh, (float*)ws, pix_per_img, ch, n, bce_weight, dice_weight, smooth);) }
+    AD_LAUNCH_CHECK("ad_seg_head_bwd");
+    rows_sum_kernel<<<(ncol + 255) / 256, 256, 0, s>>>((const float*)ws, n * bpi, ncol, dw, ch, db);
+    AD_LAUNCH_CHECK("seg rows_sum");
+    return AD_OK;
+}

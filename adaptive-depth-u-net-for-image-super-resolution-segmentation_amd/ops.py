@@ -251,3 +251,145 @@ def cast(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     y = torch.empty(x.shape, dtype=dtype, device=x.device)
     check(_lib.load().ad_cast(_p(x), dt(x.dtype), _p(y), dt(dtype), x.numel(), _stream()), "ad_cast")
     return y
+
+
+# --------------------------------------------------------------------------- tier 2 (segmentation models)
+BN_EPS, BN_MOMENTUM = 1e-3, 0.99   # Keras BatchNormalization defaults (Segmenation/code/train_adaptive_unet.py:327)
+
+
+def batchnorm_relu_fwd_train(z, gamma, beta, moving_mean, moving_var, ws: Workspace, relu: bool = True,
+                             eps: float = BN_EPS, momentum: float = BN_MOMENTUM):
+    """Returns (y, save_mean, save_rstd); updates moving_mean / moving_var in place (may be None)."""
+    c = z.shape[-1]
+    npix = z.numel() // c
+    y = torch.empty_like(z)
+    mean, rstd, var = (torch.empty(c, dtype=torch.float32, device=z.device) for _ in range(3))
+    lib = _lib.load()
+    ws.ensure(lib.ad_batchnorm_ws_bytes(c))
+    with _timed("batchnorm_fwd"):
+        check(lib.ad_batchnorm_relu_fwd_train(_p(z), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), _p(var),
+                                              _p(moving_mean), _p(moving_var), momentum, npix, c, eps, int(relu),
+                                              ws.ptr, ws.nbytes, dt(z.dtype), _stream()), "ad_batchnorm_relu_fwd_train")
+    return y, mean, rstd
+
+
+def batchnorm_relu_fwd_infer(z, gamma, beta, moving_mean, moving_var, relu: bool = True, eps: float = BN_EPS):
+    c = z.shape[-1]
+    y = torch.empty_like(z)
+    tmp = torch.empty(c, dtype=torch.float32, device=z.device)
+    with _timed("batchnorm_fwd"):
+        check(_lib.load().ad_batchnorm_relu_fwd_infer(_p(z), _p(gamma), _p(beta), _p(moving_mean), _p(moving_var), _p(y),
+                                                      _p(tmp), z.numel() // c, c, eps, int(relu), dt(z.dtype), _stream()),
+              "ad_batchnorm_relu_fwd_infer")
+    return y
+
+
+def batchnorm_relu_bwd(dy, z, mean, rstd, gamma, beta, dgamma, dbeta, ws: Workspace, relu: bool = True):
+    c = z.shape[-1]
+    dz = torch.empty_like(z)
+    lib = _lib.load()
+    ws.ensure(lib.ad_batchnorm_ws_bytes(c))
+    with _timed("batchnorm_bwd"):
+        check(lib.ad_batchnorm_relu_bwd(_p(dy), _p(z), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dz), _p(dgamma),
+                                        _p(dbeta), z.numel() // c, c, int(relu), ws.ptr, ws.nbytes, dt(z.dtype), _stream()),
+              "ad_batchnorm_relu_bwd")
+    return dz
+
+
+def colsum(x, out, ws: Workspace):
+    c = x.shape[-1]
+    lib = _lib.load()
+    ws.ensure(lib.ad_batchnorm_ws_bytes(c))
+    with _timed("colsum"):
+        check(lib.ad_colsum(_p(x), _p(out), x.numel() // c, c, ws.ptr, ws.nbytes, dt(x.dtype), _stream()), "ad_colsum")
+    return out
+
+
+def maxpool2_fwd(x):
+    n, h, w, c = x.shape
+    y = torch.empty((n, h // 2, w // 2, c), dtype=x.dtype, device=x.device)
+    with _timed("maxpool2"):
+        check(_lib.load().ad_maxpool2_fwd(_p(x), _p(y), n, h, w, c, dt(x.dtype), _stream()), "ad_maxpool2_fwd")
+    return y
+
+
+def maxpool2_bwd(dy, x):
+    n, h, w, c = x.shape
+    dx = torch.empty_like(x)
+    with _timed("maxpool2"):
+        check(_lib.load().ad_maxpool2_bwd(_p(dy), _p(x), _p(dx), n, h, w, c, dt(x.dtype), _stream()), "ad_maxpool2_bwd")
+    return dx
+
+
+def pixel_shuffle2(x, to_space: bool):
+    """to_space: [n,h,w,4c] -> [n,2h,2w,c]; else [n,2h,2w,c] -> [n,h,w,4c]."""
+    if to_space:
+        n, h, w, c4 = x.shape
+        c = c4 // 4
+        y = torch.empty((n, 2 * h, 2 * w, c), dtype=x.dtype, device=x.device)
+    else:
+        n, h2, w2, c = x.shape
+        h, w = h2 // 2, w2 // 2
+        y = torch.empty((n, h, w, 4 * c), dtype=x.dtype, device=x.device)
+    with _timed("pixel_shuffle2"):
+        check(_lib.load().ad_pixel_shuffle2(_p(x), _p(y), n, h, w, c, int(to_space), dt(x.dtype), _stream()),
+              "ad_pixel_shuffle2")
+    return y
+
+
+def conv_transpose2x2s2_pack(w_t: torch.Tensor, dtype: torch.dtype):
+    """Keras Conv2DTranspose kernel [2,2,Cout,Cin] -> operand packs of the equivalent pointwise GEMM Cin -> 4*Cout
+    (output block a*2+b holds W[a,b]^T).  Returns (w_fwd, w_dgrad)."""
+    kh, kw, cout, cin = w_t.shape
+    assert (kh, kw) == (2, 2)
+    wg = w_t.permute(3, 0, 1, 2).reshape(cin, 4 * cout)               # [Cin][(a,b,o)]
+    w9 = torch.zeros((3, 3, cin, 4 * cout), dtype=torch.float32, device=w_t.device)
+    w9[1, 1] = wg                                                     # pointwise = centre tap of the 3x3 operand
+    return conv3x3_pack(w9.contiguous(), cin, dtype, want_dgrad=True)
+
+
+def conv_transpose2x2s2_fwd(x, w_fwd, bias, cout: int):
+    """y[n,2h,2w,cout] = Conv2DTranspose(cout, 2, strides=2)(x): pointwise GEMM on the matrix cores + depth-to-space."""
+    n, h, w, cin = x.shape
+    b4 = bias.repeat(4).contiguous() if bias is not None else None
+    flat = conv3x3_fwd(x.view(n * h * w, 1, 1, cin), None, w_fwd, b4, 4 * cout)
+    return pixel_shuffle2(flat.view(n, h, w, 4 * cout), to_space=True)
+
+
+def conv_transpose2x2s2_bwd(x, dy, w_dgrad, dw_t: torch.Tensor, db: torch.Tensor, ws: Workspace):
+    """Returns dx; writes dw_t [2,2,Cout,Cin] (Keras layout) and db [Cout]."""
+    n, h, w, cin = x.shape
+    cout = dy.shape[-1]
+    g = pixel_shuffle2(dy, to_space=False).view(n * h * w, 1, 1, 4 * cout)
+    dx = conv3x3_fwd(g, None, w_dgrad, None, cin).view(n, h, w, cin)
+    dw9 = torch.empty((3, 3, cin, 4 * cout), dtype=torch.float32, device=x.device)
+    conv3x3_wgrad(x.view(n * h * w, 1, 1, cin), None, g, dw9, cin, ws)
+    dw_t.copy_(dw9[1, 1].view(cin, 2, 2, cout).permute(1, 2, 3, 0))
+    colsum(g.view(-1, cout), db, ws)        # bias grad: sum over pixels and the 4 sub-positions
+    return dx
+
+
+def seg_head_fwd(xh, w, b, target, ws: Workspace):
+    """Returns (prob [n,h,w,1] fp32, sums [n,3] or None)."""
+    n, h, wd, ch = xh.shape
+    prob = torch.empty((n, h, wd, 1), dtype=torch.float32, device=xh.device)
+    sums = torch.empty((n, 3), dtype=torch.float32, device=xh.device) if target is not None else None
+    lib = _lib.load()
+    ws.ensure(lib.ad_seg_head_ws_bytes(n, ch))
+    with _timed("seg_head_fwd"):
+        check(lib.ad_seg_head_fwd(_p(xh), _p(w), _p(b), _p(target), _p(prob), _p(sums), n, h * wd, ch, ws.ptr, ws.nbytes,
+                                  dt(xh.dtype), _stream()), "ad_seg_head_fwd")
+    return prob, sums
+
+
+def seg_head_bwd(xh, w, target, prob, sums, dw, db, bce_weight: float, dice_weight: float, ws: Workspace,
+                 smooth: float = 1e-6):
+    n, h, wd, ch = xh.shape
+    dxh = torch.empty_like(xh)
+    lib = _lib.load()
+    ws.ensure(lib.ad_seg_head_ws_bytes(n, ch))
+    with _timed("seg_head_bwd"):
+        check(lib.ad_seg_head_bwd(_p(xh), _p(w), _p(target), _p(prob), _p(sums), _p(dxh), _p(dw), _p(db), n, h * wd, ch,
+                                  bce_weight, dice_weight, smooth, ws.ptr, ws.nbytes, dt(xh.dtype), _stream()),
+              "ad_seg_head_bwd")
+    return dxh

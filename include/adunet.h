@@ -159,6 +159,49 @@ int ad_head_bwd(const void* xh, const float* w, const float* b, const float* inp
 int ad_adam_step(float* p, const float* g, float* m, float* v, int64_t count,
                  float lr, float b1, float b2, float eps, int step, float gscale, void* stream);
 
+/* ------------------------------------------------- tier 2: segmentation ops -- */
+
+/* L.BatchNormalization() (eps 1e-3, momentum 0.99) + L.Activation("relu"):
+ * Segmenation/code/train_adaptive_unet.py:325-332.  Training mode: batch statistics over (N,H,W) (two-pass,
+ * biased variance), saved mean/rstd/var [c] for the backward pass, and the Keras moving-average update
+ * moving = moving*momentum + batch*(1-momentum) (moving_* may be NULL).  Inference mode uses the moving stats. */
+size_t ad_batchnorm_ws_bytes(int c);
+int ad_batchnorm_relu_fwd_train(const void* z, const float* gamma, const float* beta, void* y,
+                                float* save_mean, float* save_rstd, float* save_var,
+                                float* moving_mean, float* moving_var, float momentum,
+                                int64_t npix, int c, float eps, int relu,
+                                void* ws, size_t ws_bytes, int dtype, void* stream);
+int ad_batchnorm_relu_fwd_infer(const void* z, const float* gamma, const float* beta,
+                                const float* moving_mean, const float* moving_var, void* y, float* rstd_tmp,
+                                int64_t npix, int c, float eps, int relu, int dtype, void* stream);
+int ad_batchnorm_relu_bwd(const void* dy, const void* z, const float* save_mean, const float* save_rstd,
+                          const float* gamma, const float* beta, void* dz, float* dgamma, float* dbeta,
+                          int64_t npix, int c, int relu, void* ws, size_t ws_bytes, int dtype, void* stream);
+
+/* out[c] = sum over pixels of x[npix, c] (BiasAddGrad of layers without a fused producer); ws as batchnorm. */
+int ad_colsum(const void* x, float* out, int64_t npix, int c, void* ws, size_t ws_bytes, int dtype, void* stream);
+
+/* L.MaxPooling2D(pool_size=(2,2)) (train_adaptive_unet.py:351 of Segmenation/code) and its gradient
+ * (first maximal element of each window, as TF MaxPoolGrad). y: [n, h/2, w/2, c]. */
+int ad_maxpool2_fwd(const void* x, void* y, int n, int h, int w, int c, int dtype, void* stream);
+int ad_maxpool2_bwd(const void* dy, const void* x, void* dx, int n, int h, int w, int c, int dtype, void* stream);
+
+/* Pixel shuffle behind L.Conv2DTranspose(nf, 2, strides=2) (Segmenation/code/unet_vinillia.py:67): the
+ * transposed conv is one pointwise GEMM to 4*nf channels (ad_conv3x3_fwd on a 1x1 geometry) followed by
+ * depth-to-space; to_space=1: x[n,h,w,4c] (block a*2+b) -> y[n,2h,2w,c]; to_space=0: the inverse gather. */
+int ad_pixel_shuffle2(const void* x, void* y, int n, int h, int w, int c, int to_space, int dtype, void* stream);
+
+/* Conv2D(1, 1, activation="sigmoid") head (:361) + the per-sample sums behind BinaryCrossentropy, dice and
+ * IoU (:258-318): prob[npix] = sigmoid(xh @ w[ch] + b); sums[n][3] = {sum BCE, sum y*pc, sum (y+pc)} with
+ * pc = clip(p, 1e-7, 1-1e-7).  Backward of loss = bce_weight*mean(BCE) + dice_weight*(1 - mean_n dice_n). */
+size_t ad_seg_head_ws_bytes(int n, int ch);
+int ad_seg_head_fwd(const void* xh, const float* w, const float* b, const float* target, float* prob, float* sums,
+                    int n, int64_t pix_per_img, int ch, void* ws, size_t ws_bytes, int dtype, void* stream);
+int ad_seg_head_bwd(const void* xh, const float* w, const float* target, const float* prob, const float* sums,
+                    void* dxh, float* dw, float* db, int n, int64_t pix_per_img, int ch,
+                    float bce_weight, float dice_weight, float smooth,
+                    void* ws, size_t ws_bytes, int dtype, void* stream);
+
 /* -------------------------------------------------------------- utilities -- */
 
 int ad_cast(const void* x, int dtype_in, void* y, int dtype_out, int64_t count, void* stream);

@@ -395,6 +395,25 @@ def iou_score(y_true, y_pred, smooth: float = 1e-6):
     return ((inter + smooth) / (union + smooth)).mean()
 
 
+def seg_loss_fwd_bwd(y_true, p, bce_weight: float, dice_weight: float, smooth: float = 1e-6):
+    """loss = bce_weight * BCE + dice_weight * (1 - dice)  (make_hybrid_ce_dice_loss / make_bce_dice_loss,
+    Segmenation/code/train_adaptive_unet.py:283-304) and its gradient w.r.t. the probabilities p."""
+    eps = 1e-7
+    pc = np.clip(p, eps, 1.0 - eps)
+    inside = (p >= eps) & (p <= 1.0 - eps)
+    n = p.shape[0]
+    ax = (1, 2, 3)
+    bce = (-(y_true * np.log(pc) + (1.0 - y_true) * np.log(1.0 - pc))).mean()
+    inter = (y_true * pc).sum(axis=ax, keepdims=True)
+    den = (y_true + pc).sum(axis=ax, keepdims=True) + smooth
+    dice = ((2.0 * inter + smooth) / den)
+    loss = bce_weight * bce + dice_weight * (1.0 - dice.mean())
+    dbce = (-(y_true / pc) + (1.0 - y_true) / (1.0 - pc)) / p.size
+    ddice = (2.0 * y_true * den - (2.0 * inter + smooth)) / (den * den)
+    dp = (bce_weight * dbce - dice_weight * ddice / n) * inside
+    return loss, dp
+
+
 def glorot_uniform(rng: np.random.Generator, shape, dtype=np.float32) -> np.ndarray:
     """Keras GlorotUniform for a conv kernel [kh, kw, cin, cout]."""
     rf = int(np.prod(shape[:-2])) if len(shape) > 2 else 1

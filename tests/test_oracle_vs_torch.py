@@ -180,3 +180,20 @@ def test_whole_model_gradients_by_torch_autograd():
     for k in params:
         g = P[k].grad.numpy()
         assert np.abs(g - grads[k]).max() <= 2e-5 * max(np.abs(g).max(), 1e-12) + 1e-12, k
+
+
+def test_seg_loss_gradient_by_torch_autograd():
+    y = (RNG.random((3, 6, 5, 1)) < 0.4).astype(np.float64)
+    p = RNG.uniform(0.02, 0.98, y.shape)
+    for wb, wd in ((0.4, 0.6), (0.5, 1.0)):
+        pt = t(p)
+        pc = torch.clamp(pt, 1e-7, 1 - 1e-7)
+        yt = torch.tensor(y)
+        bce = F.binary_cross_entropy(pc, yt)
+        inter = (yt * pc).sum(dim=(1, 2, 3))
+        dice = ((2 * inter + 1e-6) / ((yt + pc).sum(dim=(1, 2, 3)) + 1e-6)).mean()
+        loss = wb * bce + wd * (1 - dice)
+        loss.backward()
+        want_loss, dp = ops.seg_loss_fwd_bwd(y, p, wb, wd)
+        assert np.isclose(want_loss, float(loss.detach())) and np.allclose(dp, pt.grad.numpy(), atol=1e-12)
+        assert np.isclose(ops.dice_coefficient(y, p), float(dice.detach()))
