@@ -495,21 +495,23 @@ class Model:
         _, loss, psnr, _ = self.forward_loss(lr_img, hr_img, keep=False)
         return loss, psnr
 
+    def _metric_keys(self) -> List[str]:
+        return self.metrics_names if len(self.metrics_names) >= 2 else ["loss", "psnr"]
+
     def evaluate(self, dataset: Iterable, steps: Optional[int] = None, return_dict: bool = False, verbose: int = 0):
-        tot_l = tot_p = None
+        keys = self._metric_keys()
+        tot = None
         nb = 0
         for batch in dataset:
-            lr_img, hr_img = batch[0], batch[1]
-            l, p = self.test_on_batch(lr_img, hr_img)
-            tot_l = l if tot_l is None else tot_l + l
-            tot_p = p if tot_p is None else tot_p + p
+            vals = self.test_on_batch(batch[0], batch[1])
+            tot = list(vals) if tot is None else [a + b for a, b in zip(tot, vals)]
             nb += 1
             if steps is not None and nb >= steps:
                 break
         if nb == 0:
             raise ValueError("evaluate() received an empty dataset")
-        res = {"loss": float(tot_l) / nb, "psnr": float(tot_p) / nb}
-        return res if return_dict else [res["loss"], res["psnr"]]
+        res = {k: float(v) / nb for k, v in zip(keys, tot)}
+        return res if return_dict else [res[k] for k in keys]
 
     def fit(self, dataset: Iterable, epochs: int = 1, initial_epoch: int = 0, steps_per_epoch: Optional[int] = None,
             validation_data: Optional[Iterable] = None, validation_steps: Optional[int] = None,
@@ -533,7 +535,8 @@ class Model:
             if verbose:
                 print(f"Epoch {epoch + 1}/{epochs}", flush=True)
             t0 = time.time()
-            tot_l = tot_p = None
+            keys = self._metric_keys()
+            tot = None
             nb = 0
             while steps_per_epoch is None or nb < steps_per_epoch:
                 try:
@@ -546,23 +549,23 @@ class Model:
                         batch = next(it)
                     except StopIteration:
                         raise ValueError("fit() received an empty dataset") from None
-                l, p = self.train_on_batch(batch[0], batch[1])
-                tot_l = l if tot_l is None else tot_l + l
-                tot_p = p if tot_p is None else tot_p + p
+                vals = self.train_on_batch(batch[0], batch[1])
+                tot = list(vals) if tot is None else [a + b for a, b in zip(tot, vals)]
                 nb += 1
             if steps_per_epoch is None:
                 it = iter(dataset)
             if nb == 0:
                 raise ValueError("fit() received an empty dataset")
-            logs = {"loss": float(tot_l) / nb, "psnr": float(tot_p) / nb}
+            logs = {k: float(v) / nb for k, v in zip(keys, tot)}
             if validation_data is not None:
                 if val_it is not None:
                     vl = [self.test_on_batch(*next(val_it)[:2]) for _ in range(validation_steps)]
-                    logs["val_loss"] = float(sum(v[0] for v in vl)) / len(vl)
-                    logs["val_psnr"] = float(sum(v[1] for v in vl)) / len(vl)
+                    for i, k in enumerate(keys):
+                        logs["val_" + k] = float(sum(v[i] for v in vl)) / len(vl)
                 else:
                     res = self.evaluate(validation_data, return_dict=True)
-                    logs["val_loss"], logs["val_psnr"] = res["loss"], res["psnr"]
+                    for k in keys:
+                        logs["val_" + k] = res[k]
             dt = time.time() - t0
             if verbose:
                 ms = dt * 1000.0 / nb

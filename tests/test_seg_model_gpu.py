@@ -1,0 +1,103 @@
+"""GPU parity of the segmentation model family (tier 2) vs the NumPy oracle: forward probabilities, loss, dice / IoU,
+every gradient tensor, BatchNorm moving statistics and inference mode, Adam steps with the protocol-A cosine schedule."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ops as ref
+from oracle.seg_unet import SegUNetOracle
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(got, want):
+    return float(np.abs(np.asarray(got, np.float64) - want).max() / (np.abs(want).max() + 1e-30))
+
+
+def build(kind, dtype, device, p=32, depth=2):
+    from adunet_amd import seg_model as S
+    if kind == "bn":
+        model = S.build_adaptive_depth_unet(p, 64, depth, dtype=dtype, device=device)
+        oracle = SegUNetOracle(p, 64, depth, "bn", "bilinear")
+    else:
+        model = S.build_unet(p, 1, 64, depth, dtype=dtype, device=device)
+        oracle = SegUNetOracle(p, 64, depth, "ln", "convT")
+    rng = np.random.default_rng(11)
+    params, state = oracle.init_params(rng)
+    params = {k: v.astype(np.float32).astype(np.float64) for k, v in params.items()}
+    assert list(model.index) == list(oracle.param_shapes) and list(model.state_index) == list(oracle.state_shapes)
+    model.set_weights({**{k: v.astype(np.float32) for k, v in params.items()}, **{k: v.astype(np.float32) for k, v in state.items()}})
+    img = rng.random((3, p, p, 3), dtype=np.float32)
+    mask = (rng.random((3, p, p, 1)) < 0.35).astype(np.float32)
+    return S, model, oracle, params, state, img, mask
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("kind", ["bn", "ln"])
+def test_seg_forward_loss_gradients(device, dtype, kind):
+    S, model, oracle, params, state, img, mask = build(kind, dtype, device)
+    proto = S.PROTOCOLS["A"]
+    loss_obj = proto.loss_builder()
+    model.compile(optimizer=S.build_optimizer(proto, steps_per_epoch=10, epochs=2), loss=loss_obj)
+    st = dict(state)
+    want_loss, grads, p, dice, iou = oracle.loss_and_grads(params, st, img.astype(np.float64), mask.astype(np.float64), 0.4, 0.6)
+    x, m = model._to_dev(img), model._to_dev_mask(mask)
+    prob, sums, tape = model._forward_seg(x, m, training=True, keep=True)
+    model._backward_seg(tape, m)
+    f32 = dtype == torch.float32
+    assert rel(prob.cpu().numpy(), p) < (1e-3 if f32 else 3e-2)
+    loss, d, i = model._metrics_from(sums, float(m.numel()))
+    assert abs(float(loss) - want_loss) < (1e-3 if f32 else 3e-2) * want_loss
+    assert abs(float(d) - dice) < (1e-4 if f32 else 5e-3) and abs(float(i) - iou) < (1e-4 if f32 else 5e-3)
+    got = model.get_grads()
+    worst = max((rel(got[k], grads[k]), k) for k in grads if np.abs(grads[k]).max() > 1e-9)
+    # bf16 + BatchNorm over a tiny batch (3 x 8 x 8 pixels at the bottleneck) amplifies 8-bit operand noise in single
+    # tensors; the per-tensor bound is therefore loose and the flat gradient direction (cosine) is the real check
+    assert worst[0] < (2e-3 if f32 else 0.6), worst
+    ga = np.concatenate([got[k].reshape(-1) for k in grads]).astype(np.float64)
+    gb = np.concatenate([grads[k].reshape(-1) for k in grads])
+    # (BatchNorm's backward subtracts two batch means from the incoming gradient; with 8-bit bf16 operands and a
+    #  192-pixel bottleneck batch that cancellation leaves visibly noisier gradients than LayerNorm: 0.96 vs 0.998)
+    cos = float(ga @ gb / (np.linalg.norm(ga) * np.linalg.norm(gb)))
+    assert cos > (0.99999 if f32 else (0.95 if kind == "bn" else 0.99)), cos
+    if kind == "bn":
+        w = model.get_weights()
+        for k in state:                                  # Keras moving averages after one training batch
+            assert rel(w[k], st[k]) < (1e-4 if f32 else 2e-2), k
+        want_inf = oracle.forward(params, st, img.astype(np.float64), training=False)
+        assert rel(model(img, training=False), want_inf) < (1e-3 if f32 else 3e-2)
+
+
+def test_seg_training_steps_cosine_schedule(device):
+    S, model, oracle, params, state, img, mask = build("bn", torch.float32, device)
+    proto = S.PROTOCOLS["A"]
+    opt = S.build_optimizer(proto, steps_per_epoch=2, epochs=2)          # 4 decay steps
+    assert [round(opt.learning_rate(s), 6) for s in (0, 2, 4, 9)] == [1e-3, 5e-4, 0.0, 0.0]
+    model.compile(optimizer=opt, loss=proto.loss_builder())
+    st, adam = dict(state), {}
+    for step in range(3):
+        want_loss, grads, _, dice, _ = oracle.loss_and_grads(params, st, img.astype(np.float64), mask.astype(np.float64), 0.4, 0.6)
+        for name in params:
+            mm = adam.setdefault("m/" + name, np.zeros_like(params[name]))
+            vv = adam.setdefault("v/" + name, np.zeros_like(params[name]))
+            ref.adam_step(params[name], grads[name], mm, vv, step + 1, lr=opt.learning_rate(step))
+        loss, d, _ = model.train_on_batch(img, mask)
+        assert abs(float(loss) - want_loss) < 2e-3 * want_loss and abs(float(d) - dice) < 1e-3, step
+    hist = model.fit([(img, mask)] * 2, epochs=1, verbose=0, validation_data=[(img, mask)])
+    assert set(hist.history) == {"loss", "dice", "iou", "val_loss", "val_dice", "val_iou"}
+    assert model.evaluate([(img, mask)], return_dict=True).keys() == {"loss", "dice", "iou"}
+
+
+def test_seg_builders_contract():
+    from adunet_amd import seg_model as S
+    m = S.build_adaptive_depth_unet(256, 64, 4)
+    assert m.name == "adaptive_unet_depth4_c64" and m.count_params() == SegUNetOracle(256, 64, 4).count_params() + sum(
+        int(np.prod(s)) for s in SegUNetOracle(256, 64, 4).state_shapes.values())
+    assert S.build_unet(128, 1, 64, 3).name == "unet_isic_baseline"
+    with pytest.raises(ValueError):
+        S.build_adaptive_depth_unet(100, 64, 4)          # input_size % 2**depth != 0
+    with pytest.raises(ValueError):
+        S.build_unet(128, 1, 32, 4)
+    with pytest.raises(NotImplementedError):
+        S.build_unet(128, 19, 64, 4)
+    assert S.PROTOCOLS["B"].loss_builder().dice_weight == 1.0 and S.PROTOCOLS["B"].batch_size == 16
