@@ -461,6 +461,220 @@ __global__ __launch_bounds__(FT, XS <= 6 ? 2 : 1) void conv3x3_fwd_kernel(ConvAr
 #endif
 }
 
+// ------------------------------------------------------------------ forward / dgrad, weights resident
+// Cin = 64 (two channel chunks) and 16x16 tiles: the 64 -> 64 layers that dominate the full-resolution levels
+// (and the dgrads of 128 -> 64).  One workgroup owns a CU and ONE 64-channel output block for the whole launch:
+//   * its 9 x 64 x 64 weights (73.7 KB) are staged in LDS once;
+//   * halo chunks are prefetched TWO stages ahead through two named register sets (A: chunk 0, B: chunk 1) and two
+//     LDS buffers, so a load has a full stage (store + barrier + MFMA phase + epilogue) to land;
+//   * one barrier per chunk; the epilogue transposes wave-privately through LDS (32 pixels at a time), so it needs
+//     no barrier and writes 16-byte pieces of full 128-byte NHWC rows.
+// LDS: [gtab0][gtab1][X0][X1][W chunk0][W chunk1][4 waves x 32 px x 144 B epilogue scratch] = 157.7 KB.
+constexpr int WR_XS = 6;                       // halo slots per thread (324 pixels x 4 parts / 256)
+constexpr int WR_NPHP = WR_XS * FT / 4;        // 384
+constexpr int WR_XB = (324 * PIXB + 15) & ~15; // one halo buffer (31,104 B)
+constexpr int WR_OS = BN * 2 + 16;             // epilogue scratch row stride (bf16)
+constexpr size_t WR_LDS = 2 * WR_NPHP * 4 + 2 * WR_XB + 2 * WT_BYTES + 4 * 32 * WR_OS;
+
+template <typename P>
+__global__ __launch_bounds__(FT, 1) void conv3x3_fwd_wres_kernel(ConvArgs a) {
+    typedef typename P::T T;
+    static_assert(sizeof(T) == 2, "the weights-resident kernel is the bf16 throughput path");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const Geo& g = a.g;      // geometry is (1, 16, 16): HW = HH = 18, NPH = 324
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int* gtab0 = reinterpret_cast<int*>(smem);
+    int* gtab1 = gtab0 + WR_NPHP;
+    char* xb0 = smem + 2 * WR_NPHP * 4;
+    char* xb1 = xb0 + WR_XB;
+    char* wt = xb1 + WR_XB;
+    char* ot = wt + 2 * WT_BYTES + wave * (32 * WR_OS);
+    constexpr int TSZ = 2;
+    constexpr int HWB = 18 * PIXB;
+
+    const int nblk = a.cout / BN;
+    const int nitems = a.ntiles * nblk;
+    const int nb = blockIdx.x % nblk;               // gridDim.x is a multiple of nblk: fixed for this workgroup
+    const int kc_total = (a.c1 + a.c2) / P::KV;
+
+    // weights of this output block: both chunks, once
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+        for (int i = 0; i < FWS; ++i)
+            *reinterpret_cast<uint4*>(wt + ch * WT_BYTES + (tid + i * FT) * 16) =
+                load_w_slot(a.wp, kc_total, ch, a.cout, nb, tid + i * FT);
+    float4 bv[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+        bv[nt] = a.bias ? *reinterpret_cast<const float4*>(a.bias + nb * BN + nt * 16 + (lane >> 4) * 4)
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
+    char* yp; int cy, coff;
+    if (nb * BN < a.cy1) { yp = a.y1; cy = a.cy1; coff = nb * BN; }
+    else { yp = a.y2; cy = a.cout - a.cy1; coff = nb * BN - a.cy1; }
+
+    int abase[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int m = wave * 64 + mt * 16 + (lane & 15);
+        abase[mt] = (((m >> 4) + 1) * 18 + (m & 15) + 1) * PIXB + P::a_lane_off(lane);
+    }
+    // halo coordinates of this thread's two gtab entries (tile independent; no divisions per tile)
+    const int hp0 = tid, hp1 = tid + FT;
+    const int hy0 = hp0 / 18, hx0 = hp0 - hy0 * 18, hy1 = hp1 / 18, hx1 = hp1 - hy1 * 18;
+    auto build = [&](int* gt, int tile) {
+        const int txi = tile % g.tiles_x;
+        const int r = tile / g.tiles_x;
+        const int tyi = r % g.tiles_y, nn = r / g.tiles_y;
+        const int y0 = (tyi << 4) - 1, x0 = (txi << 4) - 1;
+        {
+            const int y = y0 + hy0, x = x0 + hx0;
+            const bool ok = y >= 0 && y < a.h && x >= 0 && x < a.w;
+            const int idx = (nn * a.h + min(max(y, 0), a.h - 1)) * a.w + min(max(x, 0), a.w - 1);
+            gt[hp0] = ok ? idx : ~idx;
+        }
+        if (hp1 < WR_NPHP) {
+            const int y = y0 + hy1, x = x0 + hx1;
+            const bool ok = hp1 < 324 && y >= 0 && y < a.h && x >= 0 && x < a.w;
+            const int idx = (nn * a.h + min(max(y, 0), a.h - 1)) * a.w + min(max(x, 0), a.w - 1);
+            gt[hp1] = ok ? idx : ~idx;
+        }
+    };
+
+    uint4 xa0, xa1, xa2, xa3, xa4, xa5, xb_0, xb_1, xb_2, xb_3, xb_4, xb_5;
+#define WR_SRC(CH)                                                              \
+    const bool first_ = (CH) * P::CK < a.c1;                                    \
+    const char* src_ = first_ ? a.x1 : a.x2;                                    \
+    const int rb_ = (first_ ? a.c1 : a.c2) * TSZ;                               \
+    const int ob_ = (first_ ? (CH) * P::CK : (CH) * P::CK - a.c1) * TSZ;
+#define WR_ISSUE_A(GT)                                                          \
+    {                                                                           \
+        WR_SRC(0)                                                               \
+        xa0 = load_halo_slot((GT), src_, rb_, ob_, tid);                        \
+        xa1 = load_halo_slot((GT), src_, rb_, ob_, tid + FT);                   \
+        xa2 = load_halo_slot((GT), src_, rb_, ob_, tid + 2 * FT);               \
+        xa3 = load_halo_slot((GT), src_, rb_, ob_, tid + 3 * FT);               \
+        xa4 = load_halo_slot((GT), src_, rb_, ob_, tid + 4 * FT);               \
+        xa5 = load_halo_slot((GT), src_, rb_, ob_, tid + 5 * FT);               \
+    }
+#define WR_ISSUE_B(GT)                                                          \
+    {                                                                           \
+        WR_SRC(1)                                                               \
+        xb_0 = load_halo_slot((GT), src_, rb_, ob_, tid);                       \
+        xb_1 = load_halo_slot((GT), src_, rb_, ob_, tid + FT);                  \
+        xb_2 = load_halo_slot((GT), src_, rb_, ob_, tid + 2 * FT);              \
+        xb_3 = load_halo_slot((GT), src_, rb_, ob_, tid + 3 * FT);              \
+        xb_4 = load_halo_slot((GT), src_, rb_, ob_, tid + 4 * FT);              \
+        xb_5 = load_halo_slot((GT), src_, rb_, ob_, tid + 5 * FT);              \
+    }
+
+#ifdef AD_STAMP
+    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t_last = clock64();
+    const unsigned long long t_begin = t_last;
+#endif
+    int item = blockIdx.x;
+    int cur = 0;
+    if (item < nitems) {
+        build(gtab0, item / nblk);
+        lds_barrier();
+        WR_ISSUE_A(gtab0)
+        WR_ISSUE_B(gtab0)
+    }
+    for (; item < nitems; item += gridDim.x) {
+        const int tile = item / nblk;
+        const int next = item + gridDim.x;
+        const bool has_next = next < nitems;
+        int* gt_cur = cur ? gtab1 : gtab0;
+        int* gt_nxt = cur ? gtab0 : gtab1;
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        // ---- stage (item, chunk 0): set A -> X0
+        store_halo_slot(xa0, xb0, gt_cur, 324, tid);
+        store_halo_slot(xa1, xb0, gt_cur, 324, tid + FT);
+        store_halo_slot(xa2, xb0, gt_cur, 324, tid + 2 * FT);
+        store_halo_slot(xa3, xb0, gt_cur, 324, tid + 3 * FT);
+        store_halo_slot(xa4, xb0, gt_cur, 324, tid + 4 * FT);
+        store_halo_slot(xa5, xb0, gt_cur, 324, tid + 5 * FT);
+        STAMP(1);
+        if (has_next) build(gt_nxt, next / nblk);
+        STAMP(2);
+        lds_barrier();
+        STAMP(3);
+        if (has_next) WR_ISSUE_A(gt_nxt)              // chunk 0 of the NEXT item: two stages ahead
+        STAMP(4);
+        P::template mma_chunk<4, true>(acc, xb0, abase, HWB, wt, lane);
+        STAMP(5);
+
+        // ---- stage (item, chunk 1): set B -> X1
+        store_halo_slot(xb_0, xb1, gt_cur, 324, tid);
+        store_halo_slot(xb_1, xb1, gt_cur, 324, tid + FT);
+        store_halo_slot(xb_2, xb1, gt_cur, 324, tid + 2 * FT);
+        store_halo_slot(xb_3, xb1, gt_cur, 324, tid + 3 * FT);
+        store_halo_slot(xb_4, xb1, gt_cur, 324, tid + 4 * FT);
+        store_halo_slot(xb_5, xb1, gt_cur, 324, tid + 5 * FT);
+        STAMP(1);
+        lds_barrier();
+        STAMP(3);
+        if (has_next) WR_ISSUE_B(gt_nxt)
+        STAMP(4);
+        P::template mma_chunk<4, true>(acc, xb1, abase, HWB, wt + WT_BYTES, lane);
+        STAMP(5);
+
+        // ---- epilogue: wave-private LDS transpose, two passes of 32 pixels (tile rows 4w+2p, 4w+2p+1)
+        {
+            const int txi = tile % g.tiles_x;
+            const int r = tile / g.tiles_x;
+            const int tyi = r % g.tiles_y, nn = r / g.tiles_y;
+            const int y0 = tyi << 4, x0 = txi << 4;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+#pragma unroll
+                for (int mh = 0; mh < 2; ++mh) {
+                    const int mt = 2 * p + mh;
+                    const int pl = mh * 16 + (lane & 15);
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        float v[4] = {acc[mt][nt][0] + bv[nt].x, acc[mt][nt][1] + bv[nt].y, acc[mt][nt][2] + bv[nt].z,
+                                      acc[mt][nt][3] + bv[nt].w};
+                        if (a.epilogue == AD_EPI_RELU) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+                        }
+                        bf16x4 pk = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+                        *reinterpret_cast<bf16x4*>(ot + pl * WR_OS + (nt * 16 + (lane >> 4) * 4) * TSZ) = pk;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int pl = j * 8 + (lane >> 3), part = lane & 7;
+                    const int y = y0 + wave * 4 + 2 * p + (pl >> 4), x = x0 + (pl & 15);
+                    if (y < a.h && x < a.w) {
+                        const size_t gp = ((size_t)nn * a.h + y) * a.w + x;
+                        *reinterpret_cast<uint4*>(yp + (gp * cy + coff) * TSZ + part * 16) =
+                            *reinterpret_cast<const uint4*>(ot + pl * WR_OS + part * 16);
+                    }
+                }
+            }
+        }
+        STAMP(7);
+        cur ^= 1;
+    }
+#ifdef AD_STAMP
+    if (tid == 0 && a.dbg) {
+        for (int i = 0; i < 8; ++i) a.dbg[blockIdx.x * 9 + i] = st[i];
+        a.dbg[blockIdx.x * 9 + 8] = clock64() - t_begin;
+    }
+#endif
+#undef WR_SRC
+#undef WR_ISSUE_A
+#undef WR_ISSUE_B
+}
+
 // ------------------------------------------------------------------ wgrad
 struct WgradArgs {
     const char* x1; const char* x2; int c1, c2;
@@ -709,22 +923,34 @@ int launch_fwd(ConvArgs a, hipStream_t s) {
     Geo& g = a.g;
     const int xs = g.NPH * 4 <= 6 * FT ? 6 : 16;
     g.NPHP = xs * FT / 4;
-    size_t lds = 2 * (size_t)g.NPHP * 4 + 2 * BN * 4 + (((size_t)g.NPH * PIXB + 15) & ~15) + (size_t)FWS * FT * 16;
-    if (lds > 160 * 1024) return ad_set_error(AD_ERR_ARG, "conv3x3_fwd: LDS %zu too large", lds);
+    const bool halo = g.ph && g.pw;
+    if (!halo && (g.ph || g.pw || xs != 6))
+        return ad_set_error(AD_ERR_ARG, "conv3x3_fwd: feature maps with exactly one unit extent (%dx%d) are not supported", a.h, a.w);
+    const int nblk = a.cout / BN;
+    const int nch = (a.c1 + a.c2) / P::CK;
+    const int nitems = a.ntiles * nblk;
     static bool attr_set = false;
     if (!attr_set) {
         allow_big_lds(conv3x3_fwd_kernel<P, 6, true>);
         allow_big_lds(conv3x3_fwd_kernel<P, 16, true>);
         allow_big_lds(conv3x3_fwd_kernel<P, 6, false>);
+        if constexpr (sizeof(typename P::T) == 2) allow_big_lds(conv3x3_fwd_wres_kernel<P>);
         attr_set = true;
     }
-    const int nitems = a.ntiles * (a.cout / BN);
+    if constexpr (sizeof(typename P::T) == 2) {
+        // weights-resident kernel: two channel chunks, 16x16 tiles, enough tiles to give every CU several items
+        const bool geo16 = g.lti == 0 && g.lth == 4 && g.ltw == 4;
+        if (halo && geo16 && nch == 2 && NUM_CU % nblk == 0 && nitems >= 4 * NUM_CU) {
+            conv3x3_fwd_wres_kernel<P><<<NUM_CU, FT, WR_LDS, s>>>(a);
+            AD_LAUNCH_CHECK("conv3x3_fwd_wres");
+            return AD_OK;
+        }
+    }
+    size_t lds = 2 * (size_t)g.NPHP * 4 + 2 * BN * 4 + (((size_t)g.NPH * PIXB + 15) & ~15) + (size_t)FWS * FT * 16;
+    if (lds > 160 * 1024) return ad_set_error(AD_ERR_ARG, "conv3x3_fwd: LDS %zu too large", lds);
     const int per_cu = lds <= 80 * 1024 ? 2 : 1;
     int grid = NUM_CU * per_cu;
     if (grid > nitems) grid = nitems;
-    const bool halo = g.ph && g.pw;
-    if (!halo && (g.ph || g.pw || xs != 6))
-        return ad_set_error(AD_ERR_ARG, "conv3x3_fwd: feature maps with exactly one unit extent (%dx%d) are not supported", a.h, a.w);
     if (!halo)
         conv3x3_fwd_kernel<P, 6, false><<<grid, FT, lds, s>>>(a);
     else if (xs == 6)
