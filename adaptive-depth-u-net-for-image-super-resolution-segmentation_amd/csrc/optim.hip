@@ -7,7 +7,9 @@ namespace {
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, int64_t count,
-                                                   float alpha, float omb1, float omb2, float eps, float gscale) {
+                                                   float alpha_host, const float* __restrict__ alpha_dev, float omb1,
+                                                   float omb2, float eps, float gscale) {
+    const float alpha = alpha_dev ? alpha_dev[0] : alpha_host;
     const int64_t nvec = count / 4;
     const int64_t stride = (int64_t)gridDim.x * 256;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += stride) {
@@ -51,7 +53,23 @@ extern "C" int ad_adam_step(float* p, const float* g, float* m, float* v, int64_
     double alpha = (double)lr * sqrt(1.0 - pow((double)b2, step)) / (1.0 - pow((double)b1, step));
     int64_t nvec = (count + 3) / 4;
     int blocks = (int)((nvec + 255) / 256 < 4096 ? (nvec + 255) / 256 : 4096);
-    adam_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(p, g, m, v, count, (float)alpha, 1.0f - b1, 1.0f - b2, eps, gscale);
+    adam_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(p, g, m, v, count, (float)alpha, nullptr, 1.0f - b1, 1.0f - b2, eps, gscale);
     AD_LAUNCH_CHECK("ad_adam_step");
+    return AD_OK;
+}
+
+extern "C" float ad_adam_alpha(float lr, float b1, float b2, int step) {
+    return (float)((double)lr * sqrt(1.0 - pow((double)b2, step)) / (1.0 - pow((double)b1, step)));
+}
+
+extern "C" int ad_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t count, const float* alpha_dev,
+                                float b1, float b2, float eps, float gscale, void* stream) {
+    AD_REQUIRE(count >= 0 && alpha_dev != nullptr, "ad_adam_step_dev: count=%ld", (long)count);
+    AD_REQUIRE(((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16 == 0, "ad_adam_step_dev: buffers must be 16-byte aligned");
+    if (count == 0) return AD_OK;
+    int64_t nvec = (count + 3) / 4;
+    int blocks = (int)((nvec + 255) / 256 < 4096 ? (nvec + 255) / 256 : 4096);
+    adam_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(p, g, m, v, count, 0.f, alpha_dev, 1.0f - b1, 1.0f - b2, eps, gscale);
+    AD_LAUNCH_CHECK("ad_adam_step_dev");
     return AD_OK;
 }

@@ -347,7 +347,7 @@ class Model:
             if cs.k != 3:
                 continue
             self._packs[cs.name] = ops.conv3x3_pack(self.param(cs.name + "/kernel"), self._cin_pad(cs), self.dtype,
-                                                    want_dgrad=cs.need_dgrad)
+                                                    want_dgrad=cs.need_dgrad, out=self._packs.get(cs.name))
 
     # ------------------------------------------------------------------ forward / backward
     def _to_dev(self, a) -> torch.Tensor:
@@ -494,6 +494,55 @@ class Model:
     def test_on_batch(self, lr_img, hr_img):
         _, loss, psnr, _ = self.forward_loss(lr_img, hr_img, keep=False)
         return loss, psnr
+
+    def make_graphed_train_step(self, lr_example, hr_example):
+        """Capture one full train step (forward, loss, backward, Adam, repack: ~190 launches) into a hipGraph and
+        return `step(lr, hr) -> (loss, psnr)` that copies the batch into the graph's static inputs and replays it.
+        The launch-bound host loop disappears; the step-dependent Adam factor is fed through device memory.
+        Single-process only (the data-parallel exchange stays eager)."""
+        if self.optimizer is None:
+            raise RuntimeError("call compile() first")
+        if self.grad_sync is not None:
+            raise RuntimeError("graph capture is not combined with the data-parallel gradient exchange")
+        self._require_device()
+        sx, st = self._to_dev(lr_example).clone(), self._to_dev(hr_example).clone()
+        alpha_dev = torch.zeros(1, dtype=torch.float32, device=self.device)
+        opt = self.optimizer
+
+        def body():
+            out, loss, psnr, (tape, x, t) = self.forward_loss(sx, st, keep=True)
+            self._backward(tape, x, t, 1.0 / float(x.numel()))
+            ops.adam_step_dev(self.P, self.G, self.M, self.V, alpha_dev, b1=opt.beta_1, b2=opt.beta_2, eps=opt.epsilon)
+            self._repack()
+            return loss, psnr
+
+        def set_alpha():
+            opt.iterations += 1
+            alpha_dev.fill_(ops.adam_alpha(opt.lr_at(opt.iterations - 1), opt.beta_1, opt.beta_2, opt.iterations))
+
+        side = torch.cuda.Stream(device=self.device)       # warm-up on a side stream, as torch's capture recipe asks
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            set_alpha()
+            body()                                          # sizes every workspace / attribute before capture
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        set_alpha()
+        with torch.cuda.graph(graph):
+            loss, psnr = body()
+        # the capture itself did not execute the step: run it once so that iteration counts stay truthful
+        graph.replay()
+
+        def step(lr_img, hr_img):
+            sx.copy_(self._to_dev(lr_img), non_blocking=True)
+            st.copy_(self._to_dev(hr_img), non_blocking=True)
+            set_alpha()
+            graph.replay()
+            return loss, psnr
+
+        step.graph = graph
+        return step
 
     def _metric_keys(self) -> List[str]:
         return self.metrics_names if len(self.metrics_names) >= 2 else ["loss", "psnr"]

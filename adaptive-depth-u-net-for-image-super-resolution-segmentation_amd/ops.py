@@ -110,12 +110,16 @@ def pad_channels(x: torch.Tensor, cpad: int, dtype: torch.dtype) -> torch.Tensor
     return y
 
 
-def conv3x3_pack(w_hwio: torch.Tensor, cin_pad: int, dtype: torch.dtype, want_dgrad: bool = True):
-    """fp32 Keras kernel [3,3,cin,cout] -> (w_fwd, w_dgrad) operand tensors."""
+def conv3x3_pack(w_hwio: torch.Tensor, cin_pad: int, dtype: torch.dtype, want_dgrad: bool = True, out=None):
+    """fp32 Keras kernel [3,3,cin,cout] -> (w_fwd, w_dgrad) operand tensors.  `out` = a previous result to refresh
+    in place (the packs keep their addresses, which a captured hipGraph relies on)."""
     kh, kw, cin, cout = w_hwio.shape
     assert (kh, kw) == (3, 3) and w_hwio.dtype == torch.float32
-    wf = torch.empty(9 * cin_pad * cout, dtype=dtype, device=w_hwio.device)
-    wd = torch.empty(9 * cout * cin_pad, dtype=dtype, device=w_hwio.device) if want_dgrad else None
+    if out is not None:
+        wf, wd = out
+    else:
+        wf = torch.empty(9 * cin_pad * cout, dtype=dtype, device=w_hwio.device)
+        wd = torch.empty(9 * cout * cin_pad, dtype=dtype, device=w_hwio.device) if want_dgrad else None
     with _timed("conv3x3_pack"):
         check(_lib.load().ad_conv3x3_pack(_p(w_hwio), cin, cout, cin_pad, _p(wf), _p(wd), dt(dtype), _stream()),
               "ad_conv3x3_pack")
@@ -245,6 +249,17 @@ def adam_step(p, g, m, v, step: int, lr=1e-4, b1=0.9, b2=0.999, eps=1e-7, gscale
     with _timed("adam_step"):
         check(_lib.load().ad_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, b1, b2, eps, step, gscale, _stream()),
               "ad_adam_step")
+
+
+def adam_alpha(lr: float, b1: float, b2: float, step: int) -> float:
+    return float(_lib.load().ad_adam_alpha(lr, b1, b2, step))
+
+
+def adam_step_dev(p, g, m, v, alpha_dev: torch.Tensor, b1=0.9, b2=0.999, eps=1e-7, gscale: float = 1.0):
+    """Adam update whose step-dependent factor is read from device memory (hipGraph-replayable)."""
+    with _timed("adam_step"):
+        check(_lib.load().ad_adam_step_dev(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(alpha_dev), b1, b2, eps, gscale,
+                                           _stream()), "ad_adam_step_dev")
 
 
 def cast(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:

@@ -202,6 +202,13 @@ int ad_seg_head_bwd(const void* xh, const float* w, const float* target, const f
                     float bce_weight, float dice_weight, float smooth,
                     void* ws, size_t ws_bytes, int dtype, void* stream);
 
+/* Same update with the step-dependent factor alpha = lr*sqrt(1-b2^t)/(1-b1^t) read from DEVICE memory, so that a
+ * train step captured in a hipGraph can be replayed with a new learning rate / step index (the host writes
+ * ad_adam_alpha(lr, b1, b2, t) into alpha_dev before each replay). */
+float ad_adam_alpha(float lr, float b1, float b2, int step);
+int ad_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t count, const float* alpha_dev,
+                     float b1, float b2, float eps, float gscale, void* stream);
+
 /* -------------------------------------------------------------- utilities -- */
 
 int ad_cast(const void* x, int dtype_in, void* y, int dtype_out, int64_t count, void* stream);

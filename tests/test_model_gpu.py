@@ -148,3 +148,27 @@ def test_fit_evaluate_and_checkpoint(device, tmp_path):
     assert other.evaluate(data, return_dict=True) == res
     with pytest.raises(RuntimeError):
         other.load_weights(str(tmp_path / "missing.keras"))
+
+
+def test_graph_replayed_step_equals_eager_step(device):
+    """The hipGraph-captured train step (device-resident Adam factor) must follow the eager trajectory bit for bit."""
+    from adunet_amd.model import Adam, build_losses_and_metrics, build_super_resolution_unet
+    rng = np.random.default_rng(21)
+    batches = [synth(rng, 3, 32) for _ in range(4)]
+    results = []
+    for graphed in (False, True):
+        model, _ = build_super_resolution_unet(0.5, depth_override=2, input_size=32, dtype=torch.bfloat16, device=device)
+        loss, metrics = build_losses_and_metrics("charbonnier")
+        model.compile(optimizer=Adam(1e-3), loss=loss, metrics=metrics)
+        model._require_device()
+        model.set_weights(model.initial_weights(np.random.default_rng(1), head_uniform=0.05))
+        if graphed:
+            step = model.make_graphed_train_step(*batches[0])       # runs batches[0] twice (warm-up + first replay)
+        else:
+            step = model.train_on_batch
+            step(*batches[0]); step(*batches[0])
+        losses = [float(step(*b)[0]) for b in batches[1:]]
+        results.append((losses, model.P.clone(), model.optimizer.iterations))
+    assert results[0][2] == results[1][2] == 5
+    assert results[0][0] == results[1][0]
+    assert torch.equal(results[0][1], results[1][1])
