@@ -699,33 +699,79 @@ template <> struct WgradPol<PolBF16> {
         short8_t r = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         return __builtin_bit_cast(bf16x8, r);
     }
-    // one tile (256 pixels) of K for this workgroup: 8 k-steps of 32 pixels
-    static __device__ __forceinline__ void tile(f32x4 (&acc)[9][NACC], const char* xt, const char* dzt, const int* hbase,
-                                                const Geo& g, int lane, int wave) {
+    // Per-lane LDS offsets of the 8 k-steps (tile independent): k index 8*grp + j of a k-step <-> pixel
+    // ks*32 + 16*(j>>2) + 4*grp + (j&3), so each transposed read covers 8 consecutive pixels per 32-lane half
+    // (conflict-free); the x (A) and dz (B) operands use the same map.
+    struct Lane {
+        int xa[TM / 32], xb[TM / 32];   // halo-tile byte offsets of the two transposed reads of the A fragment
+        int dz;                         // dz-tile byte offset of k-step 0 (k-steps are 32 * DZS apart)
+    };
+    static __device__ __forceinline__ Lane lane_setup(const int* hbase, int lane, int wave) {
         const int grp = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
         const int mt = wave & 1, nt0 = (wave >> 1) * 2;
-#pragma unroll 2
+        Lane l;
+#pragma unroll
         for (int ks = 0; ks < TM / 32; ++ks) {
-            // k index 8*grp + j of this k-step <-> pixel ks*32 + 16*(j>>2) + 4*grp + (j&3): each transposed read
-            // then covers 8 consecutive pixels per 32-lane half (conflict-free); A and B use the same map.
             const int m = ks * 32 + grp * 4 + q;
-            const int hb0 = hbase[m] * PIXB + mt * 32 + p * 8;
-            const int hb1 = hbase[m + 16] * PIXB + mt * 32 + p * 8;
-            bf16x8 bfr[NACC];
+            l.xa[ks] = hbase[m] * PIXB + mt * 32 + p * 8;
+            l.xb[ks] = hbase[m + 16] * PIXB + mt * 32 + p * 8;
+        }
+        l.dz = (grp * 4 + q) * DZS + nt0 * 32 + p * 8;
+        return l;
+    }
+    // One tile (256 pixels) of K: 8 k-steps x (9 taps x 2 MFMAs).  Software pipelined inside the wave: a ring of
+    // NPRE A fragments is read NPRE taps ahead and the B fragments one k-step ahead, so the transposed LDS reads
+    // overlap the MFMAs of earlier taps instead of stalling every pair of them.
+    template <bool HALO>
+    static __device__ __forceinline__ void tile(f32x4 (&acc)[9][NACC], const char* xt, const char* dzt, const Lane& l,
+                                                int row_bytes) {
+        constexpr int NT = HALO ? 9 : 1;
+        constexpr int NS = (TM / 32) * NT;     // stages = (k-step, tap)
+        constexpr int NPRE = 4;
+        bf16x8 afr[NPRE];
+        bf16x8 bfr[2][NACC];
+#define AD_LOAD_A(S)                                                                                          \
+    {                                                                                                         \
+        constexpr int ks_ = (S) / NT, t_ = (S) % NT;                                                          \
+        const int toff_ = HALO ? (t_ / 3 - 1) * row_bytes + (t_ % 3 - 1) * PIXB : 0;                          \
+        afr[(S) % NPRE] = tr_pair(xt + l.xa[ks_] + toff_, xt + l.xb[ks_] + toff_);                            \
+    }
+#define AD_LOAD_B(KS)                                                                                         \
+    _Pragma("unroll") for (int j = 0; j < NACC; ++j)                                                          \
+        bfr[(KS) & 1][j] = tr_pair(dzt + l.dz + (KS) * 32 * DZS + j * 32, dzt + l.dz + ((KS) * 32 + 16) * DZS + j * 32);
+        AD_LOAD_B(0)
+        AD_LOAD_A(0) AD_LOAD_A(1 < NS ? 1 : 0) AD_LOAD_A(2 < NS ? 2 : 0) AD_LOAD_A(3 < NS ? 3 : 0)
+        ad_tile_stages<HALO, 0>(acc, xt, dzt, l, row_bytes, afr, bfr);
+#undef AD_LOAD_A
+#undef AD_LOAD_B
+    }
+    // compile-time recursion over the stages keeps every fragment index a constant (no scratch arrays)
+    template <bool HALO, int S>
+    static __device__ __forceinline__ void ad_tile_stages(f32x4 (&acc)[9][NACC], const char* xt, const char* dzt,
+                                                          const Lane& l, int row_bytes, bf16x8 (&afr)[4],
+                                                          bf16x8 (&bfr)[2][NACC]) {
+        constexpr int NT = HALO ? 9 : 1;
+        constexpr int NS = (TM / 32) * NT;
+        constexpr int NPRE = 4;
+        if constexpr (S < NS) {
+            constexpr int ks = S / NT, t = S % NT;
+            constexpr int tap = HALO ? t : 4;
+            if constexpr (t == 0 && ks + 1 < TM / 32) {
+#pragma unroll
+                for (int j = 0; j < NACC; ++j)
+                    bfr[(ks + 1) & 1][j] = tr_pair(dzt + l.dz + (ks + 1) * 32 * DZS + j * 32,
+                                                   dzt + l.dz + ((ks + 1) * 32 + 16) * DZS + j * 32);
+            }
+            const bf16x8 a_cur = afr[S % NPRE];
+            if constexpr (S + NPRE < NS) {
+                constexpr int ks2 = (S + NPRE) / NT, t2 = (S + NPRE) % NT;
+                const int toff2 = HALO ? (t2 / 3 - 1) * row_bytes + (t2 % 3 - 1) * PIXB : 0;
+                afr[S % NPRE] = tr_pair(xt + l.xa[ks2] + toff2, xt + l.xb[ks2] + toff2);
+            }
 #pragma unroll
             for (int j = 0; j < NACC; ++j)
-                bfr[j] = tr_pair(dzt + m * DZS + (nt0 + j) * 32 + p * 8, dzt + (m + 16) * DZS + (nt0 + j) * 32 + p * 8);
-#pragma unroll
-            for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    if ((!g.ph && kh != 1) || (!g.pw && kw != 1)) continue;
-                    const int toff = ((kh - 1) * g.HW + (kw - 1)) * PIXB;
-                    bf16x8 af = tr_pair(xt + hb0 + toff, xt + hb1 + toff);
-#pragma unroll
-                    for (int j = 0; j < NACC; ++j)
-                        acc[kh * 3 + kw][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[j], acc[kh * 3 + kw][j], 0, 0, 0);
-                }
+                acc[tap][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_cur, bfr[ks & 1][j], acc[tap][j], 0, 0, 0);
+            ad_tile_stages<HALO, S + 1>(acc, xt, dzt, l, row_bytes, afr, bfr);
         }
     }
     // slab element (ci_local, co_local) held by (wave, lane, j, r)
@@ -739,22 +785,27 @@ template <> struct WgradPol<PolF32> {
     static constexpr int NACC = 1;
     static constexpr int DZS = BN * 4 + 16;
     static constexpr int DSLOTS = BN * 4 / 16;
-    static __device__ __forceinline__ void tile(f32x4 (&acc)[9][NACC], const char* xt, const char* dzt, const int* hbase,
-                                                const Geo& g, int lane, int wave) {
-        const int kk = lane >> 4, i = lane & 15;
+    struct Lane {
+        const int* hbase;
+        int kk, i, wave;
+    };
+    static __device__ __forceinline__ Lane lane_setup(const int* hbase, int lane, int wave) {
+        return Lane{hbase, lane >> 4, lane & 15, wave};
+    }
+    template <bool HALO>
+    static __device__ __forceinline__ void tile(f32x4 (&acc)[9][NACC], const char* xt, const char* dzt, const Lane& l,
+                                                int row_bytes) {
         for (int ks = 0; ks < TM / 4; ++ks) {
-            const int m = ks * 4 + kk;
-            const int hb = hbase[m] * PIXB + i * 4;
-            const float bfr = *reinterpret_cast<const float*>(dzt + m * DZS + (wave * 16 + i) * 4);
+            const int m = ks * 4 + l.kk;
+            const int hb = l.hbase[m] * PIXB + l.i * 4;
+            const float bfr = *reinterpret_cast<const float*>(dzt + m * DZS + (l.wave * 16 + l.i) * 4);
 #pragma unroll
-            for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    if ((!g.ph && kh != 1) || (!g.pw && kw != 1)) continue;
-                    const int toff = ((kh - 1) * g.HW + (kw - 1)) * PIXB;
-                    const float af = *reinterpret_cast<const float*>(xt + hb + toff);
-                    acc[kh * 3 + kw][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bfr, acc[kh * 3 + kw][0], 0, 0, 0);
-                }
+            for (int t = 0; t < (HALO ? 9 : 1); ++t) {
+                const int tap = HALO ? t : 4;
+                const int toff = HALO ? (t / 3 - 1) * row_bytes + (t % 3 - 1) * PIXB : 0;
+                const float af = *reinterpret_cast<const float*>(xt + hb + toff);
+                acc[tap][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bfr, acc[tap][0], 0, 0, 0);
+            }
         }
     }
     static __device__ __forceinline__ void coords(int wave, int lane, int j, int r, int* ci, int* co) {
@@ -766,7 +817,7 @@ template <> struct WgradPol<PolF32> {
 // grid: x = K split, y = input-channel block (P::CK channels), z = output-channel block (64)
 // ws slab layout: [split][cib][cob][tap][P::CK][64] fp32
 // LDS: [gtab0][gtab1][hbase 256][x halo chunk][dz tile]; next tile's data waits in registers.
-template <typename P, int XS>
+template <typename P, int XS, bool HALO>
 __global__ __launch_bounds__(256, XS <= 6 ? 2 : 1) void conv3x3_wgrad_kernel(WgradArgs a) {
     typedef typename P::T T;
     typedef WgradPol<P> WP;
@@ -788,6 +839,8 @@ __global__ __launch_bounds__(256, XS <= 6 ? 2 : 1) void conv3x3_wgrad_kernel(Wgr
     else { src = a.x2; row_bytes = a.c2 * TSZ; off_bytes = (c0 - a.c1) * TSZ; }
 
     for (int m = tid; m < TM; m += 256) hbase[m] = halo_of(m, g);
+    lds_barrier();
+    const typename WP::Lane lsetup = WP::lane_setup(hbase, lane, wave);
     // dz slot s = tid + 256*i -> pixel s / DSLOTS, part s % DSLOTS; its halo index is tile independent
     int dz_hb[WP::DSLOTS];
 #pragma unroll
@@ -836,7 +889,7 @@ __global__ __launch_bounds__(256, XS <= 6 ? 2 : 1) void conv3x3_wgrad_kernel(Wgr
         if (has_next) build_gtab(gt_nxt, g, decode_tile(tile + 1, g), a.n, a.h, a.w, tid);
         lds_barrier();
         if (has_next) WG_ISSUE(gt_nxt);
-        WP::tile(acc, xt, dzt, hbase, g, lane, wave);
+        WP::template tile<HALO>(acc, xt, dzt, lsetup, g.HW * PIXB);
         lds_barrier();
         cur ^= 1;
     }
@@ -991,15 +1044,21 @@ int launch_wgrad(WgradArgs a, const WgradPlan& p, hipStream_t s) {
     if (lds > 160 * 1024) return ad_set_error(AD_ERR_ARG, "conv3x3_wgrad: LDS %zu too large", lds);
     static bool attr_set = false;
     if (!attr_set) {
-        allow_big_lds(conv3x3_wgrad_kernel<P, 6>);
-        allow_big_lds(conv3x3_wgrad_kernel<P, 16>);
+        allow_big_lds(conv3x3_wgrad_kernel<P, 6, true>);
+        allow_big_lds(conv3x3_wgrad_kernel<P, 16, true>);
+        allow_big_lds(conv3x3_wgrad_kernel<P, 6, false>);
         attr_set = true;
     }
     dim3 grid(p.nsplit, p.ncib, p.ncob);
-    if (xs == 6)
-        conv3x3_wgrad_kernel<P, 6><<<grid, 256, lds, s>>>(a);
+    const bool halo = g.ph && g.pw;
+    if (!halo && (g.ph || g.pw || xs != 6))
+        return ad_set_error(AD_ERR_ARG, "conv3x3_wgrad: feature maps with exactly one unit extent (%dx%d) are not supported", a.h, a.w);
+    if (!halo)
+        conv3x3_wgrad_kernel<P, 6, false><<<grid, 256, lds, s>>>(a);
+    else if (xs == 6)
+        conv3x3_wgrad_kernel<P, 6, true><<<grid, 256, lds, s>>>(a);
     else
-        conv3x3_wgrad_kernel<P, 16><<<grid, 256, lds, s>>>(a);
+        conv3x3_wgrad_kernel<P, 16, true><<<grid, 256, lds, s>>>(a);
     AD_LAUNCH_CHECK("conv3x3_wgrad");
     return AD_OK;
 }
