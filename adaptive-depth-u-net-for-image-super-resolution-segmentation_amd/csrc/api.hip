@@ -43,23 +43,33 @@ extern "C" int ad_cast(const void* x, int dtype_in, void* y, int dtype_out, int6
     return AD_OK;
 }
 
+// one thread per 16-byte output vector (EPT channels): the 3 real channels sit in the first vector of a pixel
 template <typename T>
 __global__ void pad_channels_kernel(const float* __restrict__ x, T* __restrict__ y, int64_t npix, int c, int cpad) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int64_t total = npix * cpad;
-    int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; i < total; i += stride) {
-        int64_t p = i / cpad;
-        int ch = (int)(i - p * cpad);
-        y[i] = (T)(ch < c ? x[p * c + ch] : 0.0f);
+    constexpr int EPT = ElemTraits<T>::EPT;
+    const int vecs = cpad / EPT;
+    const int64_t total = npix * vecs;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t p = i / vecs;
+        const int v = (int)(i - p * vecs);
+        float f[EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int ch = v * EPT + e;
+            f[e] = ch < c ? x[p * c + ch] : 0.0f;
+        }
+        Vec16<T> st;
+        st.from_f32(f);
+        st.store(y + i * EPT);
     }
 }
 
 extern "C" int ad_pad_channels(const float* x, void* y, int64_t npix, int c, int cpad, int dtype, void* stream) {
-    AD_REQUIRE(c > 0 && cpad >= c, "ad_pad_channels: c=%d cpad=%d", c, cpad);
+    AD_REQUIRE(c > 0 && cpad >= c && cpad % (dtype == AD_BF16 ? 8 : 4) == 0, "ad_pad_channels: c=%d cpad=%d", c, cpad);
     if (npix <= 0) return AD_OK;
     hipStream_t s = (hipStream_t)stream;
-    int64_t total = npix * cpad;
+    int64_t total = npix * (cpad / (dtype == AD_BF16 ? 8 : 4));
     int blocks = (int)((total + 255) / 256);
     if (blocks > 8192) blocks = 8192;
     if (dtype == AD_BF16)

@@ -6,7 +6,7 @@
 
 namespace {
 
-constexpr int BPI_MAX = 64;  // blocks per image
+constexpr int BPI_MAX = 32;  // blocks per image
 
 template <int G>
 __device__ __forceinline__ float gsum(float v) {
@@ -171,21 +171,21 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ xh,
     }
 }
 
-// out[col] = sum over rows of part[row][col], fixed order (16 columns x 16 row-groups per block)
+// out[col] = sum over rows of part[row][col], fixed order (4 columns x 64 row-groups per block)
 __global__ __launch_bounds__(256) void rows_reduce_kernel(const float* __restrict__ part, int nrows, int ncols,
                                                           float* __restrict__ o0, int n0, float* __restrict__ o1) {
-    __shared__ float sm[16][17];
-    const int tid = threadIdx.x, cl = tid & 15, rg = tid >> 4;
-    const int i = blockIdx.x * 16 + cl;
+    __shared__ float sm[64][5];
+    const int tid = threadIdx.x, cl = tid & 3, rg = tid >> 2;
+    const int i = blockIdx.x * 4 + cl;
     float s = 0.f;
     if (i < ncols)
-        for (int r = rg; r < nrows; r += 16) s += part[(size_t)r * ncols + i];
+        for (int r = rg; r < nrows; r += 64) s += part[(size_t)r * ncols + i];
     sm[rg][cl] = s;
     __syncthreads();
     if (rg == 0 && i < ncols) {
         float t = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) t += sm[r][cl];
+        for (int r = 0; r < 64; ++r) t += sm[r][cl];
         if (i < n0) o0[i] = t; else o1[i - n0] = t;
     }
 }
@@ -276,7 +276,7 @@ extern "C" int ad_head_bwd(const void* xh, const float* w, const float* b, const
                                                                         grad_scale);)
     }
     AD_LAUNCH_CHECK("ad_head_bwd");
-    rows_reduce_kernel<<<(ncol + 15) / 16, 256, 0, s>>>((const float*)ws, n * bpi, ncol, dw, ch * 3, db);
+    rows_reduce_kernel<<<(ncol + 3) / 4, 256, 0, s>>>((const float*)ws, n * bpi, ncol, dw, ch * 3, db);
     AD_LAUNCH_CHECK("head rows_reduce");
     return AD_OK;
 }

@@ -174,22 +174,23 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     }
 }
 
-// Sum the per-block partials [nblocks][3][c] in a fixed order: 16 columns x 16 row-groups per block.
+// Sum the per-block partials [nblocks][3][c] in a fixed order: 4 columns x 64 row-groups per block (the job is
+// latency bound -- a few hundred KB -- so the rows are spread over many lanes and folded through LDS).
 __global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ part, int nblocks, int c,
                                                             float* __restrict__ o0, float* __restrict__ o1,
                                                             float* __restrict__ o2) {
-    __shared__ float sm[16][17];
-    const int tid = threadIdx.x, cl = tid & 15, rg = tid >> 4;
-    const int i = blockIdx.x * 16 + cl;
+    __shared__ float sm[64][5];
+    const int tid = threadIdx.x, cl = tid & 3, rg = tid >> 2;
+    const int i = blockIdx.x * 4 + cl;
     float s = 0.f;
     if (i < 3 * c)
-        for (int b = rg; b < nblocks; b += 16) s += part[(size_t)b * 3 * c + i];
+        for (int b = rg; b < nblocks; b += 64) s += part[(size_t)b * 3 * c + i];
     sm[rg][cl] = s;
     __syncthreads();
     if (rg == 0 && i < 3 * c) {
         float t = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) t += sm[r][cl];
+        for (int r = 0; r < 64; ++r) t += sm[r][cl];
         int which = i / c, ch = i % c;
         float* dst = which == 0 ? o0 : (which == 1 ? o1 : o2);
         if (dst) dst[ch] = t;
@@ -270,7 +271,7 @@ int ln_bwd_launch(const void* dy, const void* z, const float* mean, const float*
                                       160 * 1024);
         kern<<<blocks, 256, lds, s>>>((const T*)dy, (const T*)z, mean, rstd, gamma, beta, (T*)dz, (float*)ws, npix, c);)
     AD_LAUNCH_CHECK("layernorm bwd");
-    colsum_reduce_kernel<<<(3 * c + 15) / 16, 256, 0, s>>>((const float*)ws, blocks, c, dgamma, dbeta, dbias);
+    colsum_reduce_kernel<<<(3 * c + 3) / 4, 256, 0, s>>>((const float*)ws, blocks, c, dgamma, dbeta, dbias);
     AD_LAUNCH_CHECK("colsum_reduce");
     return AD_OK;
 }
