@@ -6,43 +6,43 @@
 
 namespace {
 
+// grid: x = blocks over one output row (ox, channel vector), y = output row, z = image.  No 64-bit divisions: the
+// row/image come from the block index, (ox, vector) from one 32-bit division by the vectors-per-pixel count.
 template <typename T>
 __global__ __launch_bounds__(256) void resample_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                        const int* __restrict__ sy, const float* __restrict__ wy, int ky,
                                                        const int* __restrict__ sx, const float* __restrict__ wx, int kx,
-                                                       int n, int h, int w, int oh, int ow, int c, int accumulate) {
+                                                       int h, int w, int oh, int ow, int c, int accumulate) {
     constexpr int EPT = ElemTraits<T>::EPT;
     const int vecs = c / EPT;
-    const int64_t total = (int64_t)n * oh * ow * vecs;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        int v = (int)(i % vecs);
-        int64_t p = i / vecs;
-        int ox = (int)(p % ow);
-        int64_t r = p / ow;
-        int oy = (int)(r % oh);
-        int nn = (int)(r / oh);
+    const int oy = blockIdx.y, nn = blockIdx.z;
+    const int y0 = sy[oy];
+    const float* wyr = wy + oy * ky;
+    const T* xn = x + (size_t)nn * h * w * c;
+    T* yrow = y + ((size_t)nn * oh + oy) * ow * c;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < ow * vecs; i += gridDim.x * 256) {
+        const int ox = i / vecs, v = i - ox * vecs;
+        const int x0 = sx[ox];
+        const float* wxr = wx + ox * kx;
         float acc[EPT];
 #pragma unroll
         for (int e = 0; e < EPT; ++e) acc[e] = 0.f;
-        const int y0 = sy[oy], x0 = sx[ox];
         for (int a = 0; a < ky; ++a) {
-            const float fy = wy[oy * ky + a];
+            const float fy = wyr[a];
             if (fy == 0.f) continue;
-            const int iy = min(y0 + a, h - 1);
-            const T* row = x + ((int64_t)nn * h + iy) * w * c + v * EPT;
+            const T* row = xn + (size_t)min(y0 + a, h - 1) * w * c + v * EPT;
             for (int b = 0; b < kx; ++b) {
-                const float f = fy * wx[ox * kx + b];
+                const float f = fy * wxr[b];
                 if (f == 0.f) continue;
-                const int ix = min(x0 + b, w - 1);
                 Vec16<T> ld;
                 float t[EPT];
-                ld.load(row + (int64_t)ix * c);
+                ld.load(row + (size_t)min(x0 + b, w - 1) * c);
                 ld.to_f32(t);
 #pragma unroll
                 for (int e = 0; e < EPT; ++e) acc[e] += f * t[e];
             }
         }
-        T* dst = y + p * c + v * EPT;
+        T* dst = yrow + (size_t)i * EPT;
         if (accumulate) {
             Vec16<T> old;
             float t[EPT];
@@ -66,15 +66,16 @@ extern "C" int ad_resample(const void* x, void* y, const int* sy, const float* w
     AD_REQUIRE(n > 0 && h > 0 && w > 0 && oh > 0 && ow > 0 && ky > 0 && kx > 0, "ad_resample: bad shape");
     const int ept = dtype == AD_BF16 ? 8 : 4;
     AD_REQUIRE(c > 0 && c % ept == 0, "ad_resample: c=%d must be a multiple of %d", c, ept);
+    AD_REQUIRE(oh <= 65535 && n <= 65535, "ad_resample: oh=%d n=%d exceed the grid limits", oh, n);
     hipStream_t s = (hipStream_t)stream;
-    int64_t total = (int64_t)n * oh * ow * (c / ept);
-    int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    const int row_items = ow * (c / ept);
+    dim3 grid((row_items + 255) / 256, oh, n);
     if (dtype == AD_BF16)
-        resample_kernel<bf16_t><<<blocks, 256, 0, s>>>((const bf16_t*)x, (bf16_t*)y, sy, wy, ky, sx, wx, kx, n, h, w, oh,
-                                                        ow, c, accumulate);
+        resample_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)x, (bf16_t*)y, sy, wy, ky, sx, wx, kx, h, w, oh, ow, c,
+                                                      accumulate);
     else
-        resample_kernel<float><<<blocks, 256, 0, s>>>((const float*)x, (float*)y, sy, wy, ky, sx, wx, kx, n, h, w, oh, ow,
-                                                       c, accumulate);
+        resample_kernel<float><<<grid, 256, 0, s>>>((const float*)x, (float*)y, sy, wy, ky, sx, wx, kx, h, w, oh, ow, c,
+                                                     accumulate);
     AD_LAUNCH_CHECK("ad_resample");
     return AD_OK;
 }
