@@ -24,7 +24,8 @@ SIGNATURES = {
     "ad_cin_granule": (_i, [_i]),
     "ad_pad_channels": (_i, [_vp, _vp, _i64, _i, _i, _i, _vp]),
     "ad_conv3x3_pack": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp]),
-    "ad_conv3x3_fwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "ad_conv3x3_fwd_ws_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "ad_conv3x3_fwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _sz, _i, _vp]),
     "ad_conv3x3_wgrad_ws_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "ad_conv3x3_wgrad": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _i, _vp]),
     "ad_layernorm_relu_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _i, _i, _vp]),

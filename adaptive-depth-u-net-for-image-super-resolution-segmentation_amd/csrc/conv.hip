@@ -236,6 +236,8 @@ struct ConvArgs {
     char* y1; char* y2; int cy1;
     int n, h, w, cout, epilogue;
     int ntiles;
+    int ksplit;                // > 1: the channel chunks of an item are split over ksplit workgroups (tiny maps)
+    float* slab;               // split-K partial sums [ksplit][n*h*w][cout] fp32
     unsigned long long* dbg;   // diagnostic builds only (-DAD_STAMP): per-workgroup phase cycle sums
     Geo g;
 };
@@ -274,7 +276,8 @@ __global__ __launch_bounds__(FT, XS <= 6 ? 2 : 1) void conv3x3_fwd_kernel(ConvAr
     char* wt = xt + ((g.NPH * PIXB + 15) & ~15);
 
     const int nblk = a.cout / BN;
-    const int nitems = a.ntiles * nblk;
+    const int ksplit = a.ksplit;
+    const int nitems = a.ntiles * nblk * ksplit;     // item = (tile, output block, K slice)
     const int cin = a.c1 + a.c2;
     const int nch = cin / P::CK;
     const int kc_total = cin / P::KV;
@@ -295,14 +298,14 @@ __global__ __launch_bounds__(FT, XS <= 6 ? 2 : 1) void conv3x3_fwd_kernel(ConvAr
                       // would sit behind the prefetch in the in-order vmcnt queue and drain it)
 
     // issue the global loads of (tile described by gt, channel chunk ch, output block nb) into registers
-#define FWD_ISSUE(GT, CH, NB)                                                                         \
+#define FWD_ISSUE(GT, CH, NB, FIRST)                                                                      \
     do {                                                                                              \
         const int c0_ = (CH) * P::CK;                                                                 \
         const bool first_ = c0_ < a.c1;                                                               \
         const char* src_ = first_ ? a.x1 : a.x2;                                                      \
         const int rb_ = (first_ ? a.c1 : a.c2) * TSZ;                                                 \
         const int ob_ = (first_ ? c0_ : c0_ - a.c1) * TSZ;                                            \
-        if ((CH) == 0 && a.bias) bq = a.bias[(NB) * BN + (tid & 63)];                                 \
+        if ((FIRST) && a.bias) bq = a.bias[(NB) * BN + (tid & 63)];                                   \
         if constexpr (XS > 0) x0 = load_halo_slot((GT), src_, rb_, ob_, tid + 0 * FT);                                  \
         if constexpr (XS > 1) x1 = load_halo_slot((GT), src_, rb_, ob_, tid + 1 * FT);                                  \
         if constexpr (XS > 2) x2 = load_halo_slot((GT), src_, rb_, ob_, tid + 2 * FT);                                  \
@@ -338,15 +341,16 @@ __global__ __launch_bounds__(FT, XS <= 6 ? 2 : 1) void conv3x3_fwd_kernel(ConvAr
     int item = blockIdx.x;
     int cur = 0;
     if (item < nitems) {
-        const TileCtx t0 = decode_tile(item / nblk, g);
+        const TileCtx t0 = decode_tile(item / (nblk * ksplit), g);
         build_gtab<FT>(gtab0, g, t0, a.n, a.h, a.w, tid);
         lds_barrier();
-        FWD_ISSUE(gtab0, 0, item % nblk);
+        FWD_ISSUE(gtab0, (item % ksplit) * nch / ksplit, (item / ksplit) % nblk, true);
     }
     STAMP(0);
 
     for (; item < nitems; item += gridDim.x) {
-        const int tile = item / nblk, nb = item % nblk;
+        const int tile = item / (nblk * ksplit), nb = (item / ksplit) % nblk, ksl = item % ksplit;
+        const int ch_lo = ksl * nch / ksplit, ch_hi = (ksl + 1) * nch / ksplit;
         const TileCtx t = decode_tile(tile, g);
         const int next = item + gridDim.x;
         const bool has_next = next < nitems;
@@ -359,7 +363,7 @@ __global__ __launch_bounds__(FT, XS <= 6 ? 2 : 1) void conv3x3_fwd_kernel(ConvAr
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        for (int ch = 0; ch < nch; ++ch) {
+        for (int ch = ch_lo; ch < ch_hi; ++ch) {
             // registers hold (item, ch): publish them to LDS (previous readers are past their barrier)
             if constexpr (XS > 0) store_halo_slot(x0, xt, gt_cur, g.NPH, tid + 0 * FT);
             if constexpr (XS > 1) store_halo_slot(x1, xt, gt_cur, g.NPH, tid + 1 * FT);
@@ -386,11 +390,11 @@ __global__ __launch_bounds__(FT, XS <= 6 ? 2 : 1) void conv3x3_fwd_kernel(ConvAr
             *reinterpret_cast<uint4*>(wt + (tid + 6 * FT) * 16) = w6;
             *reinterpret_cast<uint4*>(wt + (tid + 7 * FT) * 16) = w7;
             *reinterpret_cast<uint4*>(wt + (tid + 8 * FT) * 16) = w8;
-            if (ch == 0 && tid < BN) bias_lds[(cur ? BN : 0) + tid] = bq;
+            if (ch == ch_lo && tid < BN) bias_lds[(cur ? BN : 0) + tid] = bq;
             STAMP(1);   // wait for prefetched loads + LDS stores
-            const bool last = ch == nch - 1;
+            const bool last = ch == ch_hi - 1;
             if (last && has_next) {
-                const TileCtx tn = decode_tile(next / nblk, g);
+                const TileCtx tn = decode_tile(next / (nblk * ksplit), g);
                 build_gtab<FT>(gt_nxt, g, tn, a.n, a.h, a.w, tid);
             }
             STAMP(2);   // gtab build
@@ -399,9 +403,9 @@ __global__ __launch_bounds__(FT, XS <= 6 ? 2 : 1) void conv3x3_fwd_kernel(ConvAr
             // prefetch the next chunk (or the next item's first chunk) while this one is multiplied
             if (!last || has_next) {
                 const int* gt_p = last ? gt_nxt : gt_cur;
-                const int ch_p = last ? 0 : ch + 1;
-                const int nb_p = last ? next % nblk : nb;
-                FWD_ISSUE(gt_p, ch_p, nb_p);
+                const int ch_p = last ? (next % ksplit) * nch / ksplit : ch + 1;
+                const int nb_p = last ? (next / ksplit) % nblk : nb;
+                FWD_ISSUE(gt_p, ch_p, nb_p, last);
             }
             STAMP(4);   // issue prefetch
             P::template mma_chunk<FMT, HALO>(acc, xt, abase, g.HW * PIXB, wt, lane);
@@ -428,7 +432,15 @@ __global__ __launch_bounds__(FT, XS <= 6 ? 2 : 1) void conv3x3_fwd_kernel(ConvAr
                 const int ty = (pix >> g.ltw) & ((1 << g.lth) - 1);
                 const int img = pix >> (g.ltw + g.lth);
                 const int nn = t.n0 + img, y = t.y0 + ty, x = t.x0 + tx;
-                if (nn < a.n && y < a.h && x < a.w) {
+                if (nn < a.n && y < a.h && x < a.w && ksplit > 1) {
+                    // split-K: raw fp32 partial sums; bias / ReLU / conversion happen in splitk_finalize_kernel
+                    const size_t gp = ((size_t)nn * a.h + y) * a.w + x;
+                    float* dst = a.slab + ((size_t)ksl * a.n * a.h * a.w + gp) * a.cout + nb * BN + (lane >> 4) * 4;
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+                        *reinterpret_cast<float4*>(dst + nt * 16) =
+                            make_float4(acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]);
+                } else if (nn < a.n && y < a.h && x < a.w) {
                     const size_t gp = ((size_t)nn * a.h + y) * a.w + x;
                     T* dst = reinterpret_cast<T*>(yp) + gp * cy + coff + (lane >> 4) * 4;
 #pragma unroll
@@ -459,6 +471,35 @@ __global__ __launch_bounds__(FT, XS <= 6 ? 2 : 1) void conv3x3_fwd_kernel(ConvAr
         a.dbg[blockIdx.x * 9 + 8] = clock64() - t_begin;
     }
 #endif
+}
+
+// y = convert(relu?(bias + sum over K slices of the fp32 partials)), fixed summation order; 4 channels per thread
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_finalize_kernel(const float* __restrict__ slab, const float* __restrict__ bias,
+                                                              T* __restrict__ y1, T* __restrict__ y2, int cy1, int64_t npix,
+                                                              int cout, int ksplit, int relu) {
+    const int vecs = cout / 4;
+    const int64_t total = npix * vecs;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t p = i / vecs;
+        const int co = (int)(i - p * vecs) * 4;
+        float4 s = bias ? *reinterpret_cast<const float4*>(bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < ksplit; ++k) {
+            const float4 v = *reinterpret_cast<const float4*>(slab + ((size_t)k * npix + p) * cout + co);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        if (relu) { s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f); }
+        T* dst = co < cy1 ? y1 + p * cy1 + co : y2 + p * (cout - cy1) + (co - cy1);
+        dst[0] = (T)s.x; dst[1] = (T)s.y; dst[2] = (T)s.z; dst[3] = (T)s.w;
+    }
+}
+
+// K slices for a launch with few (tile, output block) items: aim at ~2 workgroups per CU, at least 2 chunks a slice
+static int pick_ksplit(int nitems, int nch) {
+    if (nitems >= NUM_CU || nch < 4) return 1;
+    int ks = (2 * NUM_CU + nitems - 1) / nitems;
+    if (ks > nch / 2) ks = nch / 2;
+    return ks < 2 ? 1 : ks;
 }
 
 // ------------------------------------------------------------------ forward / dgrad, weights resident
@@ -972,7 +1013,7 @@ static void allow_big_lds(K kern) {
 }
 
 template <typename P>
-int launch_fwd(ConvArgs a, hipStream_t s) {
+int launch_fwd(ConvArgs a, void* ws, size_t ws_bytes, hipStream_t s) {
     Geo& g = a.g;
     const int xs = g.NPH * 4 <= 6 * FT ? 6 : 16;
     g.NPHP = xs * FT / 4;
@@ -993,6 +1034,7 @@ int launch_fwd(ConvArgs a, hipStream_t s) {
     if constexpr (sizeof(typename P::T) == 2) {
         // weights-resident kernel: two channel chunks, 16x16 tiles, enough tiles to give every CU several items
         const bool geo16 = g.lti == 0 && g.lth == 4 && g.ltw == 4;
+        a.ksplit = 1; a.slab = nullptr;
         if (halo && geo16 && nch == 2 && NUM_CU % nblk == 0 && nitems >= 4 * NUM_CU) {
             conv3x3_fwd_wres_kernel<P><<<NUM_CU, FT, WR_LDS, s>>>(a);
             AD_LAUNCH_CHECK("conv3x3_fwd_wres");
@@ -1002,8 +1044,12 @@ int launch_fwd(ConvArgs a, hipStream_t s) {
     size_t lds = 2 * (size_t)g.NPHP * 4 + 2 * BN * 4 + (((size_t)g.NPH * PIXB + 15) & ~15) + (size_t)FWS * FT * 16;
     if (lds > 160 * 1024) return ad_set_error(AD_ERR_ARG, "conv3x3_fwd: LDS %zu too large", lds);
     const int per_cu = lds <= 80 * 1024 ? 2 : 1;
+    const int64_t npix = (int64_t)a.n * a.h * a.w;
+    a.ksplit = pick_ksplit(nitems, nch);
+    if (a.ksplit > 1 && (ws == nullptr || ws_bytes < (size_t)a.ksplit * npix * a.cout * sizeof(float))) a.ksplit = 1;
+    a.slab = (float*)ws;
     int grid = NUM_CU * per_cu;
-    if (grid > nitems) grid = nitems;
+    if (grid > nitems * a.ksplit) grid = nitems * a.ksplit;
     if (!halo)
         conv3x3_fwd_kernel<P, 6, false><<<grid, FT, lds, s>>>(a);
     else if (xs == 6)
@@ -1011,6 +1057,14 @@ int launch_fwd(ConvArgs a, hipStream_t s) {
     else
         conv3x3_fwd_kernel<P, 16, true><<<grid, FT, lds, s>>>(a);
     AD_LAUNCH_CHECK("conv3x3_fwd");
+    if (a.ksplit > 1) {
+        typedef typename P::T T;
+        const int64_t total = npix * (a.cout / 4);
+        const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+        splitk_finalize_kernel<T><<<blocks, 256, 0, s>>>(a.slab, a.bias, (T*)a.y1, (T*)a.y2, a.cy1, npix, a.cout, a.ksplit,
+                                                         a.epilogue == AD_EPI_RELU);
+        AD_LAUNCH_CHECK("splitk_finalize");
+    }
     return AD_OK;
 }
 
@@ -1091,8 +1145,8 @@ extern "C" int ad_conv3x3_pack(const float* w_hwio, int cin, int cout, int cin_p
 }
 
 extern "C" int ad_conv3x3_fwd(const void* x1, int c1, const void* x2, int c2, const void* w_packed, const float* bias,
-                              void* y1, int cy1, void* y2, int n, int h, int w, int cout, int epilogue, int dtype,
-                              void* stream) {
+                              void* y1, int cy1, void* y2, int n, int h, int w, int cout, int epilogue, void* ws,
+                              size_t ws_bytes, int dtype, void* stream) {
     AD_REQUIRE(dtype == AD_BF16 || dtype == AD_F32, "ad_conv3x3_fwd: bad dtype %d", dtype);
     const int gran = ad_cin_granule(dtype);
     AD_REQUIRE(n > 0 && h > 0 && w > 0, "ad_conv3x3_fwd: bad shape n=%d h=%d w=%d", n, h, w);
@@ -1109,10 +1163,20 @@ extern "C" int ad_conv3x3_fwd(const void* x1, int c1, const void* x2, int c2, co
     a.y1 = (char*)y1; a.y2 = (char*)y2; a.cy1 = cy1;
     a.n = n; a.h = h; a.w = w; a.cout = cout; a.epilogue = epilogue;
     a.dbg = g_dbg;
+    a.ksplit = 1; a.slab = nullptr;
     pick_geo(n, h, w, &a.g);
     a.ntiles = a.g.tiles_x * a.g.tiles_y * a.g.tiles_i;
     hipStream_t s = (hipStream_t)stream;
-    return dtype == AD_BF16 ? launch_fwd<PolBF16>(a, s) : launch_fwd<PolF32>(a, s);
+    return dtype == AD_BF16 ? launch_fwd<PolBF16>(a, ws, ws_bytes, s) : launch_fwd<PolF32>(a, ws, ws_bytes, s);
+}
+
+extern "C" size_t ad_conv3x3_fwd_ws_bytes(int n, int h, int w, int cin, int cout, int dtype) {
+    if (n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0 || cout % BN) return 0;
+    Geo g;
+    pick_geo(n, h, w, &g);
+    const int nitems = g.tiles_x * g.tiles_y * g.tiles_i * (cout / BN);
+    const int ks = pick_ksplit(nitems, cin / (dtype == AD_BF16 ? PolBF16::CK : PolF32::CK));
+    return ks > 1 ? (size_t)ks * n * h * w * cout * sizeof(float) : 0;
 }
 
 extern "C" size_t ad_conv3x3_wgrad_ws_bytes(int n, int h, int w, int cin, int cout, int dtype) {

@@ -126,6 +126,17 @@ def conv3x3_pack(w_hwio: torch.Tensor, cin_pad: int, dtype: torch.dtype, want_dg
     return wf, wd
 
 
+_conv_ws: dict = {}   # per-device scratch for the split-K path of tiny feature maps
+
+
+def _conv_workspace(device, nbytes: int):
+    ws = _conv_ws.get(device)
+    if ws is None:
+        ws = _conv_ws[device] = Workspace(device, max(nbytes, 32 << 20))
+    ws.ensure(nbytes)
+    return ws
+
+
 def conv3x3_fwd(x1: torch.Tensor, x2: Optional[torch.Tensor], w_packed: torch.Tensor, bias: Optional[torch.Tensor],
                 cout: int, relu: bool = False, split: Optional[int] = None):
     """y = conv3x3_same(concat(x1, x2)) (+bias) (+ReLU).  With `split`, returns (y[..., :split], y[..., split:])
@@ -135,9 +146,13 @@ def conv3x3_fwd(x1: torch.Tensor, x2: Optional[torch.Tensor], w_packed: torch.Te
     cy1 = split if split is not None else cout
     y1 = torch.empty((n, h, w, cy1), dtype=x1.dtype, device=x1.device)
     y2 = torch.empty((n, h, w, cout - cy1), dtype=x1.dtype, device=x1.device) if cy1 < cout else None
+    lib = _lib.load()
+    need = lib.ad_conv3x3_fwd_ws_bytes(n, h, w, c1 + c2, cout, dt(x1.dtype))
+    ws = _conv_workspace(x1.device, need) if need else None
     with _timed("conv3x3_fwd"):
-        check(_lib.load().ad_conv3x3_fwd(_p(x1), c1, _p(x2), c2, _p(w_packed), _p(bias), _p(y1), cy1, _p(y2),
-                                         n, h, w, cout, EPI_RELU if relu else EPI_NONE, dt(x1.dtype), _stream()),
+        check(lib.ad_conv3x3_fwd(_p(x1), c1, _p(x2), c2, _p(w_packed), _p(bias), _p(y1), cy1, _p(y2),
+                                 n, h, w, cout, EPI_RELU if relu else EPI_NONE, ws.ptr if ws else None,
+                                 ws.nbytes if ws else 0, dt(x1.dtype), _stream()),
               "ad_conv3x3_fwd")
     return (y1, y2) if split is not None else y1
 

@@ -72,12 +72,16 @@ int ad_conv3x3_pack(const float* w_hwio, int cin, int cout, int cin_pad,
  * Output channels [0,cy1) go to y1[n,h,w,cy1], the rest to y2[n,h,w,cout-cy1]
  * (used when the same kernel runs as dgrad of a concatenated input); pass
  * y2 = NULL, cy1 = cout normally.  cout % 64 == 0, c1 % granule == 0, c2 % granule == 0,
- * cy1 % 64 == 0. */
+ * cy1 % 64 == 0.
+ * Launches with very few spatial tiles (the 4x4 / 1x1 bottleneck maps) split the channel contraction over
+ * several workgroups and sum fp32 partial slabs in a fixed order; that path needs ad_conv3x3_fwd_ws_bytes()
+ * of workspace (0 for all other shapes; with ws = NULL the unsplit kernel is used). */
+size_t ad_conv3x3_fwd_ws_bytes(int n, int h, int w, int cin, int cout, int dtype);
 int ad_conv3x3_fwd(const void* x1, int c1, const void* x2, int c2,
                    const void* w_packed, const float* bias,
                    void* y1, int cy1, void* y2,
                    int n, int h, int w, int cout, int epilogue,
-                   int dtype, void* stream);
+                   void* ws, size_t ws_bytes, int dtype, void* stream);
 
 /* Weight gradient of the same convolution (TF Conv2DBackpropFilter):
  *   dw_hwio[3,3,c1+c2,cout] (fp32, Keras layout) = sum_pixels x(+tap) * dz
