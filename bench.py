@@ -51,8 +51,30 @@ def synth_batch(rank, n, p, device):
     return torch.from_numpy(lr).to(device), torch.from_numpy(hr).to(device)
 
 
-def cpu_baseline(scale, depth, patch, budget_images=1):
-    """Oracle ("port") timed on the host cores: `budget_images` images, one fp32 train step each."""
+def conv_bytes_per_image(model, elem=2):
+    """Algorithmic HBM bytes of the forward/dgrad conv launches per image: every 3x3 conv reads its input once and
+    writes its output once in each direction (weights are noise at these sizes); the first conv has no dgrad."""
+    total = 0.0
+    for i, cs in enumerate(model.convs.values()):
+        if cs.k != 3:
+            continue
+        b = float(cs.hw * cs.hw * (max(cs.cin, 16) + cs.cout) * elem)
+        total += b if i == 0 else 2.0 * b
+    return total
+
+
+def pmc_traffic(workload, dtype, batch):
+    """HBM bytes per launch of the conv3x3_fwd family from the committed rocprofv3 PMC passes (profiles/README.md);
+    None when the run is not the configuration those passes were taken on."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if (workload, dtype, batch) != ("K2p", "bf16", 64) or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f)["families"]["conv3x3_fwd"]["hbm_bytes_per_launch"]
+
+
+def cpu_baseline(scale, depth, patch, budget_seconds=12.0):
+    """Oracle ("port") timed on the host cores: whole fp32 train steps of batch 1 until `budget_seconds` have passed."""
     from oracle.sr_unet import SRUNetOracle
     try:
         from threadpoolctl import threadpool_info
@@ -66,8 +88,10 @@ def cpu_baseline(scale, depth, patch, budget_images=1):
     hr = rng.random((1, patch, patch, 3), dtype=np.float32)
     lr = np.clip(hr + 0.05 * rng.standard_normal(hr.shape, dtype=np.float32), 0, 1).astype(np.float32)
     t0 = time.time()
-    for _ in range(budget_images):
+    budget_images = 0
+    while budget_images == 0 or time.time() - t0 < budget_seconds:
         m.train_step(params, state, lr, hr, lr=1e-4)
+        budget_images += 1
     dt = time.time() - t0
     return {"value": budget_images / dt, "unit": "images/s", "cores": int(cores), "kind": "port",
             "sample": f"{budget_images} train step(s) of batch 1 on the same model (NumPy float32 oracle, {dt:.1f} s)"}
@@ -180,9 +204,14 @@ def main():
                        "parallelism": f"dp{world}", "launch": "hipGraph replay" if graphed else "eager", "conv_gflop_per_image_step": f_step / 1e9,
                        "model_tflops": img_s * f_step / 1e12, "final_loss": float(last_loss),
                        "final_psnr": float(last_psnr)},
-            "roofline": {"bound": "mfma", "kernel": "conv3x3_fwd_kernel<PolBF16> (forward + dgrad launches)",
+            "roofline": {"bound": "mfma",
+                         "kernel": "conv3x3_fwd_kernel + conv3x3_fwd_wres_kernel (+ splitk_finalize_kernel): every "
+                                   "forward conv and dgrad launch of the step",
                          "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_BF16_TFLOPS,
+                         "traffic": pmc_traffic(args.workload, args.dtype, batch),
+                         "algorithmic_bytes_per_launch": conv_bytes_per_image(model, 2 if args.dtype == "bf16" else 4)
+                         * batch * timed_steps / n_launch,
                          "launches_per_step": n_launch / timed_steps, "avg_launch_ms": ms / n_launch,
                          "timing": ("HIP events around every launch of %d eager steps run right after the graph-replayed "
                                     "timed region" % timed_steps) if graphed else "HIP events inside the timed region",

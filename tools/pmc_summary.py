@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Join the two single-counter rocprofv3 passes (FETCH_SIZE, WRITE_SIZE: tools/pmc.sh) into per-kernel HBM traffic.
+
+usage: tools/pmc_summary.py <fetch_dir> <write_dir> <out.json>
+
+Units and correction follow /opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3 section): both counters are in
+KiB; on gfx950 FETCH_SIZE tallies the 128-byte requests of wide streaming reads at 64 bytes, so reads are doubled:
+    hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024
+Dispatches of the two passes are matched by order (same deterministic program) and checked by kernel name.
+"""
+import collections
+import csv
+import glob
+import json
+import re
+import sys
+
+FAMILIES = {       # kernel-name prefix -> op family used by bench.py's roofline
+    "conv3x3_fwd_wres_kernel": "conv3x3_fwd", "conv3x3_fwd_kernel": "conv3x3_fwd", "splitk_finalize_kernel": "conv3x3_fwd",
+    "conv3x3_wgrad_kernel": "conv3x3_wgrad", "wgrad_reduce_kernel": "conv3x3_wgrad",
+}
+
+
+def short(name):
+    name = re.sub(r"^void ", "", name).replace("(anonymous namespace)::", "")
+    m = re.match(r"_ZN12_GLOBAL__N_1\d+([a-z0-9_]+?_kernel)", name)
+    if m:
+        return m.group(1)
+    m = re.match(r"_Z\d+([a-z0-9_]+?_kernel)", name)
+    if m:
+        return m.group(1)
+    return re.sub(r"[<(].*", "", name)
+
+
+def load(d):
+    return list(csv.DictReader(open(glob.glob(d + "/*/*_counter_collection.csv")[0])))
+
+
+def main():
+    fetch, write, out = sys.argv[1:4]
+    f, w = load(fetch), load(write)
+    assert len(f) == len(w), "the two passes dispatched different numbers of kernels"
+    per = collections.OrderedDict()
+    for a, b in zip(f, w):
+        assert a["Kernel_Name"] == b["Kernel_Name"] and a["Counter_Name"] == "FETCH_SIZE" and b["Counter_Name"] == "WRITE_SIZE"
+        k = per.setdefault(short(a["Kernel_Name"]), {"launches": 0, "fetch_kib_raw": 0.0, "write_kib": 0.0})
+        k["launches"] += 1
+        k["fetch_kib_raw"] += float(a["Counter_Value"])
+        k["write_kib"] += float(b["Counter_Value"])
+    fam = collections.OrderedDict()
+    for name, k in per.items():
+        k["hbm_bytes_per_launch"] = (2.0 * k["fetch_kib_raw"] + k["write_kib"]) * 1024.0 / k["launches"]
+        if name in FAMILIES:
+            g = fam.setdefault(FAMILIES[name], {"launches": 0, "hbm_bytes": 0.0})
+            if name != "splitk_finalize_kernel" and name != "wgrad_reduce_kernel":
+                g["launches"] += k["launches"]          # helpers count towards the bytes of the launch they finish
+            g["hbm_bytes"] += (2.0 * k["fetch_kib_raw"] + k["write_kib"]) * 1024.0
+    for g in fam.values():
+        g["hbm_bytes_per_launch"] = g["hbm_bytes"] / g["launches"]
+    json.dump({"correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950, MI355X_MICROARCH.md)",
+               "kernels": per, "families": fam}, open(out, "w"), indent=1)
+    for name, k in sorted(per.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"]):
+        print(f"{name:34s} launches={k['launches']:4d}  {k['hbm_bytes_per_launch'] / 1e6:10.2f} MB/launch")
+
+
+if __name__ == "__main__":
+    main()
