@@ -45,6 +45,8 @@ def aa_spans(in_size: int, out_size: int) -> Tuple[np.ndarray, np.ndarray]:
     wgt = np.where(ok[:, None], wgt * (f32(1.0) / np.where(ok, total, f32(1.0)))[:, None], f32(0.0)).astype(np.float32)
     outside = (centre < 0) | (centre > in_size)
     wgt[outside] = 0.0
+    used = np.flatnonzero((wgt != 0).any(axis=0))          # the nominal span is one tap wider than integer ratios use
+    wgt = np.ascontiguousarray(wgt[:, :max(int(used[-1]) + 1 if used.size else 1, 1)])
     return lo.astype(np.int32), wgt
 
 

@@ -85,7 +85,8 @@ def test_resize_tables_match_oracle_bit_for_bit(sizes):
     i, o = sizes
     s, w = rt.aa_spans(i, o)
     s2, w2 = ops.aa_triangle_spans(i, o)
-    assert np.array_equal(s, s2) and np.array_equal(w, w2)
+    # the product drops the all-zero trailing tap column the nominal span carries at integer ratios
+    assert np.array_equal(s, s2) and np.array_equal(w, w2[:, :w.shape[1]]) and not w2[:, w.shape[1]:].any()
     assert np.allclose(w.sum(1), 1.0, atol=1e-6)
     st, wt = rt.aa_spans_transposed(i, o)
     dense_t = np.zeros((i, o), np.float32)

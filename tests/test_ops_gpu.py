@@ -198,6 +198,29 @@ def test_resize_aa_fwd_bwd(device, dtype, sizes):
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("case", [(33, 131, 125, 16), (33, 31, 125, 16), (40, 127, 103, 8), (2, 200, 9, 16), (2, 60, 11, 16),
+                                  (2, 9, 200, 16)])
+def test_resize_row_groups_and_wide_taps(device, dtype, case):
+    """oh*n >= 4096 takes the 4-rows-per-thread variant (ragged last group included); spans wider than 16 taps
+    take the gather fallback; 9..16 taps the padded-tap variants."""
+    from adunet_amd import ops, resize_tables as rt
+    n, hin, hout, c = case
+    rng = np.random.default_rng(n * 1000 + hin + hout)
+    x = rnd(rng.standard_normal((n, hin, hin, c)), dtype)
+    want = ref.resize_aa_fwd(x, hout, hout)
+    s, wgt = rt.aa_spans(hin, hout)
+    y = ops.resample(to_dev(x, dtype, device), ops.ResampleTables(s, wgt, s, wgt, device))
+    assert relerr(y, want) < (1e-5 if dtype == F32 else TOL[BF16])
+    dy = rnd(rng.standard_normal(want.shape), dtype)
+    wantb = ref.resize_aa_bwd(dy, hin, hin)
+    st, wt = rt.aa_spans_transposed(hin, hout)
+    base = rnd(rng.standard_normal(x.shape), dtype)
+    acc = to_dev(base, dtype, device)
+    ops.resample(to_dev(dy, dtype, device), ops.ResampleTables(st, wt, st, wt, device), out=acc, accumulate=True)
+    assert relerr(acc, wantb + base) < (1e-5 if dtype == F32 else TOL[BF16])
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
 @pytest.mark.parametrize("loss_kind", [0, 1])
 def test_head_fwd_bwd(device, ws, dtype, loss_kind):
     from adunet_amd import ops
