@@ -104,6 +104,44 @@ struct PolBF16 {
         }
 #undef AD_LOAD_TAP
     }
+    // 16-pixel-wide tiles with 4 m-tiles per wave: m-tile mt is tile row 4*wave + mt, so tap (dy, dx) of m-tile mt
+    // reads halo row mt + dy at column offset dx.  The six halo rows a wave touches are fetched once per dx and
+    // reused by the three dy taps: 9*4 weight + 3*6 pixel fragment reads per chunk instead of 9*4 + 9*4 -- the LDS
+    // pipe, not the MFMA, is what saturates first in this kernel.  abase0 = centre-tap offset of m-tile 0.
+    // hook(st) is called after the MFMAs of step st (compile-time st): the caller spreads other work (the global
+    // stores of the previous item's results) through the MFMA stream.
+    template <typename Hook>
+    static __device__ __forceinline__ void mma_chunk_rows(f32x4 (&acc)[4][4], const char* xt, int abase0, int row_bytes,
+                                                          const char* wt, int lane, const Hook& hook) {
+        bf16x8 wf[2][4], xr[2][6];
+        const char* wl = wt + (((lane >> 4) * BN) + (lane & 15)) * 16;
+        const char* xl = xt + abase0 - row_bytes - PIXB;       // halo row -1, column -1 of m-tile 0
+#define AD_LOAD_W(BUF, TAP)                                                                               \
+    _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                      \
+        wf[BUF][nt] = *reinterpret_cast<const bf16x8*>(wl + (TAP) * (4 * BN * 16) + nt * 256);
+#define AD_LOAD_R(BUF, DX)                                                                                \
+    _Pragma("unroll") for (int r = 0; r < 6; ++r)                                                         \
+        xr[BUF][r] = *reinterpret_cast<const bf16x8*>(xl + r * row_bytes + (DX) * PIXB);
+        AD_LOAD_R(0, 0)
+        AD_LOAD_W(0, 0)
+#pragma unroll
+        for (int st = 0; st < 9; ++st) {
+            const int dx = st / 3, dy = st % 3;
+            if (st + 1 < 9) {
+                const int ndx = (st + 1) / 3, ndy = (st + 1) % 3;
+                AD_LOAD_W((st + 1) & 1, ndy * 3 + ndx)
+                if (ndy == 0) AD_LOAD_R(ndx & 1, ndx)
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[st & 1][nt], xr[dx & 1][mt + dy], acc[mt][nt], 0, 0, 0);
+            hook(st);
+        }
+#undef AD_LOAD_W
+#undef AD_LOAD_R
+    }
 };
 
 struct PolF32 {
@@ -504,32 +542,52 @@ static int pick_ksplit(int nitems, int nch) {
 
 // ------------------------------------------------------------------ forward / dgrad, weights resident
 // Cin = 64 (two channel chunks) and 16x16 tiles: the 64 -> 64 layers that dominate the full-resolution levels
-// (and the dgrads of 128 -> 64).  One workgroup owns a CU and ONE 64-channel output block for the whole launch:
-//   * its 9 x 64 x 64 weights (73.7 KB) are staged in LDS once;
-//   * halo chunks are prefetched TWO stages ahead through two named register sets (A: chunk 0, B: chunk 1) and two
-//     LDS buffers, so a load has a full stage (store + barrier + MFMA phase + epilogue) to land;
-//   * one barrier per chunk; the epilogue transposes wave-privately through LDS (32 pixels at a time), so it needs
-//     no barrier and writes 16-byte pieces of full 128-byte NHWC rows.
-// LDS: [gtab0][gtab1][X0][X1][W chunk0][W chunk1][4 waves x 32 px x 144 B epilogue scratch] = 157.7 KB.
-constexpr int WR_XS = 6;                       // halo slots per thread (324 pixels x 4 parts / 256)
-constexpr int WR_NPHP = WR_XS * FT / 4;        // 384
+// (and the dgrads of 128 -> 64).  One 512-thread workgroup owns a CU and ONE 64-channel output block for the whole
+// launch; its 9 x 64 x 64 weights (73.7 KB) are staged in LDS once.  The eight waves are specialised:
+//   * waves 0-3 (one per SIMD) only read fragments, issue MFMAs and store their 64 pixels x 64 channels straight
+//     from the accumulators (each lane owns 4 consecutive channels of a pixel: 8-byte pieces of NHWC rows);
+//   * waves 4-7 (the second wave of each SIMD) only move data: they compute the halo addresses, keep the next
+//     item's two channel chunks in flight in registers a full item ahead, and write them to the two LDS halo
+//     buffers in the shadow of the MFMA phases.
+// Two workgroup barriers per item hand the buffers over: B0 (X0 = chunk 0 of this item is complete, X1 may be
+// refilled) and B1 (X1 = chunk 1 is complete, X0 may be refilled).
+// Every global access is a BUFFER load/store issued unconditionally: out-of-image halo pixels and out-of-tile
+// output pixels get the offset 0x80000000, which the hardware range check turns into "load zeros" / "drop the
+// store".  That gives the zero padding for free and keeps the number of memory operations per iteration a
+// compile-time constant: with loads or stores under a branch hipcc can no longer count what is in flight and
+// falls back to s_waitcnt vmcnt(0), which drains the prefetch at every stage.  (Hence the launcher's 2 GiB limit
+// on each tensor for this path.)
+// LDS: [X0][X1][W chunk0][W chunk1] = 135.9 KB.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+constexpr int WR_T = 512;                      // threads: 4 MFMA waves + 4 loader waves
+constexpr int WR_XS = 6;                       // halo slots per loader thread (324 pixels x 4 parts / 256)
 constexpr int WR_XB = (324 * PIXB + 15) & ~15; // one halo buffer (31,104 B)
-constexpr int WR_OS = BN * 2 + 16;             // epilogue scratch row stride (bf16)
-constexpr size_t WR_LDS = 2 * WR_NPHP * 4 + 2 * WR_XB + 2 * WT_BYTES + 4 * 32 * WR_OS;
+constexpr size_t WR_LDS = 2 * WR_XB + 2 * WT_BYTES;
+constexpr unsigned WR_OOB = 0x80000000u;
+constexpr long long WR_MAX_BYTES = 0x7fffffffLL;
 
-template <typename P>
-__global__ __launch_bounds__(FT, 1) void conv3x3_fwd_wres_kernel(ConvArgs a) {
+// Raw buffer descriptor over [p, p + bytes) held in SGPRs.  The readfirstlane pins it as wave-uniform: without it a
+// descriptor that depends on blockIdx arithmetic is treated as divergent and every access gets a waterfall loop.
+__device__ __forceinline__ auto wave_uniform_rsrc(const void* p, int bytes) {
+    const unsigned long long u = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0,
+                                             __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+
+template <typename P, bool RELU>
+__global__ __launch_bounds__(WR_T, 1) void conv3x3_fwd_wres_kernel(ConvArgs a) {
     typedef typename P::T T;
     static_assert(sizeof(T) == 2, "the weights-resident kernel is the bf16 throughput path");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Geo& g = a.g;      // geometry is (1, 16, 16): HW = HH = 18, NPH = 324
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int* gtab0 = reinterpret_cast<int*>(smem);
-    int* gtab1 = gtab0 + WR_NPHP;
-    char* xb0 = smem + 2 * WR_NPHP * 4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    char* xb0 = smem;
     char* xb1 = xb0 + WR_XB;
     char* wt = xb1 + WR_XB;
-    char* ot = wt + 2 * WT_BYTES + wave * (32 * WR_OS);
     constexpr int TSZ = 2;
     constexpr int HWB = 18 * PIXB;
 
@@ -537,76 +595,14 @@ __global__ __launch_bounds__(FT, 1) void conv3x3_fwd_wres_kernel(ConvArgs a) {
     const int nitems = a.ntiles * nblk;
     const int nb = blockIdx.x % nblk;               // gridDim.x is a multiple of nblk: fixed for this workgroup
     const int kc_total = (a.c1 + a.c2) / P::KV;
+    const int npix = a.n * a.h * a.w;
 
-    // weights of this output block: both chunks, once
+    // weights of this output block: both chunks, once (all 512 threads)
 #pragma unroll
-    for (int ch = 0; ch < 2; ++ch)
-#pragma unroll
-        for (int i = 0; i < FWS; ++i)
-            *reinterpret_cast<uint4*>(wt + ch * WT_BYTES + (tid + i * FT) * 16) =
-                load_w_slot(a.wp, kc_total, ch, a.cout, nb, tid + i * FT);
-    float4 bv[4];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-        bv[nt] = a.bias ? *reinterpret_cast<const float4*>(a.bias + nb * BN + nt * 16 + (lane >> 4) * 4)
-                        : make_float4(0.f, 0.f, 0.f, 0.f);
-    char* yp; int cy, coff;
-    if (nb * BN < a.cy1) { yp = a.y1; cy = a.cy1; coff = nb * BN; }
-    else { yp = a.y2; cy = a.cout - a.cy1; coff = nb * BN - a.cy1; }
-
-    int abase[4];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int m = wave * 64 + mt * 16 + (lane & 15);
-        abase[mt] = (((m >> 4) + 1) * 18 + (m & 15) + 1) * PIXB + P::a_lane_off(lane);
-    }
-    // halo coordinates of this thread's two gtab entries (tile independent; no divisions per tile)
-    const int hp0 = tid, hp1 = tid + FT;
-    const int hy0 = hp0 / 18, hx0 = hp0 - hy0 * 18, hy1 = hp1 / 18, hx1 = hp1 - hy1 * 18;
-    auto build = [&](int* gt, int tile) {
-        const int txi = tile % g.tiles_x;
-        const int r = tile / g.tiles_x;
-        const int tyi = r % g.tiles_y, nn = r / g.tiles_y;
-        const int y0 = (tyi << 4) - 1, x0 = (txi << 4) - 1;
-        {
-            const int y = y0 + hy0, x = x0 + hx0;
-            const bool ok = y >= 0 && y < a.h && x >= 0 && x < a.w;
-            const int idx = (nn * a.h + min(max(y, 0), a.h - 1)) * a.w + min(max(x, 0), a.w - 1);
-            gt[hp0] = ok ? idx : ~idx;
-        }
-        if (hp1 < WR_NPHP) {
-            const int y = y0 + hy1, x = x0 + hx1;
-            const bool ok = hp1 < 324 && y >= 0 && y < a.h && x >= 0 && x < a.w;
-            const int idx = (nn * a.h + min(max(y, 0), a.h - 1)) * a.w + min(max(x, 0), a.w - 1);
-            gt[hp1] = ok ? idx : ~idx;
-        }
-    };
-
-    uint4 xa0, xa1, xa2, xa3, xa4, xa5, xb_0, xb_1, xb_2, xb_3, xb_4, xb_5;
-#define WR_SRC(CH)                                                              \
-    const bool first_ = (CH) * P::CK < a.c1;                                    \
-    const char* src_ = first_ ? a.x1 : a.x2;                                    \
-    const int rb_ = (first_ ? a.c1 : a.c2) * TSZ;                               \
-    const int ob_ = (first_ ? (CH) * P::CK : (CH) * P::CK - a.c1) * TSZ;
-#define WR_ISSUE_A(GT)                                                          \
-    {                                                                           \
-        WR_SRC(0)                                                               \
-        xa0 = load_halo_slot((GT), src_, rb_, ob_, tid);                        \
-        xa1 = load_halo_slot((GT), src_, rb_, ob_, tid + FT);                   \
-        xa2 = load_halo_slot((GT), src_, rb_, ob_, tid + 2 * FT);               \
-        xa3 = load_halo_slot((GT), src_, rb_, ob_, tid + 3 * FT);               \
-        xa4 = load_halo_slot((GT), src_, rb_, ob_, tid + 4 * FT);               \
-        xa5 = load_halo_slot((GT), src_, rb_, ob_, tid + 5 * FT);               \
-    }
-#define WR_ISSUE_B(GT)                                                          \
-    {                                                                           \
-        WR_SRC(1)                                                               \
-        xb_0 = load_halo_slot((GT), src_, rb_, ob_, tid);                       \
-        xb_1 = load_halo_slot((GT), src_, rb_, ob_, tid + FT);                  \
-        xb_2 = load_halo_slot((GT), src_, rb_, ob_, tid + 2 * FT);              \
-        xb_3 = load_halo_slot((GT), src_, rb_, ob_, tid + 3 * FT);              \
-        xb_4 = load_halo_slot((GT), src_, rb_, ob_, tid + 4 * FT);              \
-        xb_5 = load_halo_slot((GT), src_, rb_, ob_, tid + 5 * FT);              \
+    for (int i = 0; i < 2 * 9 * 4 * BN / WR_T; ++i) {
+        const int s = tid + i * WR_T;               // 0 .. 4607: chunk s / 2304, slot s % 2304
+        const int ch = s >= 9 * 4 * BN;
+        *reinterpret_cast<uint4*>(wt + s * 16) = load_w_slot(a.wp, kc_total, ch, a.cout, nb, s - ch * 9 * 4 * BN);
     }
 
 #ifdef AD_STAMP
@@ -614,96 +610,178 @@ __global__ __launch_bounds__(FT, 1) void conv3x3_fwd_wres_kernel(ConvArgs a) {
     unsigned long long t_last = clock64();
     const unsigned long long t_begin = t_last;
 #endif
-    int item = blockIdx.x;
-    int cur = 0;
-    if (item < nitems) {
-        build(gtab0, item / nblk);
-        lds_barrier();
-        WR_ISSUE_A(gtab0)
-        WR_ISSUE_B(gtab0)
+    if (wave >= 4) {
+        // ------------------------------------------------------------ loader waves
+        const int lt = tid - 256;
+        const bool one_src = P::CK < a.c1;          // virtual concat: chunk 1 may come from x2
+        const int rb0 = a.c1 * TSZ;
+        const int rb1 = (one_src ? a.c1 : a.c2) * TSZ;
+        const int ob1 = one_src ? P::CK * TSZ : 0;
+        const auto rs0 = wave_uniform_rsrc(a.x1, npix * rb0);
+        const auto rs1 = wave_uniform_rsrc(one_src ? a.x1 : a.x2, npix * rb1);
+        // this thread's six halo slots: pixel hp = lt/4 + 64 i (row hy, column hx of the 18 x 18 halo), part lt&3
+        const int part16 = (lt & 3) * 16;
+        int hyx[WR_XS];
+#pragma unroll
+        for (int i = 0; i < WR_XS; ++i) {
+            const int hp = (lt >> 2) + 64 * i;
+            const int hy = hp / 18;
+            hyx[i] = hp < 324 ? (hy << 8) | (hp - hy * 18) : (64 << 8);   // row 64: never inside an image
+        }
+        const int lds_slot = (lt >> 2) * PIXB + part16;                  // + 64 i * PIXB
+        int pix0, pix1, pix2, pix3, pix4, pix5;     // flat pixel index of each slot for the tile being fetched, or -1
+#define WR_PIX(I, NN, Y0, X0)                                                                    \
+    {                                                                                            \
+        const int y_ = (Y0) - 1 + (hyx[I] >> 8), x_ = (X0) - 1 + (hyx[I] & 255);                 \
+        const bool ok_ = (unsigned)y_ < (unsigned)a.h && (unsigned)x_ < (unsigned)a.w;           \
+        pix##I = ok_ ? ((NN) * a.h + y_) * a.w + x_ : -1;                                        \
     }
-    for (; item < nitems; item += gridDim.x) {
-        const int tile = item / nblk;
-        const int next = item + gridDim.x;
-        const bool has_next = next < nitems;
-        int* gt_cur = cur ? gtab1 : gtab0;
-        int* gt_nxt = cur ? gtab0 : gtab1;
-        f32x4 acc[4][4];
+#define WR_PIXELS(ITEM)                                                                          \
+    {                                                                                            \
+        const int tile_ = min((ITEM), nitems - 1) / nblk;   /* past the end: re-fetch the last tile, loads stay unconditional */ \
+        const int r_ = tile_ / g.tiles_x;                                                        \
+        const int x0_ = (tile_ - r_ * g.tiles_x) << 4;                                           \
+        const int nn_ = r_ / g.tiles_y;                                                          \
+        const int y0_ = (r_ - nn_ * g.tiles_y) << 4;                                             \
+        WR_PIX(0, nn_, y0_, x0_) WR_PIX(1, nn_, y0_, x0_) WR_PIX(2, nn_, y0_, x0_)               \
+        WR_PIX(3, nn_, y0_, x0_) WR_PIX(4, nn_, y0_, x0_) WR_PIX(5, nn_, y0_, x0_)               \
+    }
+#define WR_LD(RS, RB, OB, PIXV) \
+    __builtin_amdgcn_raw_buffer_load_b128((RS), (PIXV) >= 0 ? (unsigned)((PIXV) * (RB) + (OB) + part16) : WR_OOB, 0, 0)
+        u32x4 xa0, xa1, xa2, xa3, xa4, xa5, xb_0, xb_1, xb_2, xb_3, xb_4, xb_5;
+#define WR_ISSUE_A                                                                               \
+    xa0 = WR_LD(rs0, rb0, 0, pix0); xa1 = WR_LD(rs0, rb0, 0, pix1); xa2 = WR_LD(rs0, rb0, 0, pix2); \
+    xa3 = WR_LD(rs0, rb0, 0, pix3); xa4 = WR_LD(rs0, rb0, 0, pix4); xa5 = WR_LD(rs0, rb0, 0, pix5); \
+    asm volatile("" ::: "memory");
+#define WR_ISSUE_B                                                                               \
+    xb_0 = WR_LD(rs1, rb1, ob1, pix0); xb_1 = WR_LD(rs1, rb1, ob1, pix1); xb_2 = WR_LD(rs1, rb1, ob1, pix2); \
+    xb_3 = WR_LD(rs1, rb1, ob1, pix3); xb_4 = WR_LD(rs1, rb1, ob1, pix4); xb_5 = WR_LD(rs1, rb1, ob1, pix5); \
+    asm volatile("" ::: "memory");
+#define WR_STORE(XT, V0, V1, V2, V3, V4, V5)                                                     \
+    *reinterpret_cast<u32x4*>((XT) + lds_slot) = V0;                                             \
+    *reinterpret_cast<u32x4*>((XT) + lds_slot + 64 * PIXB) = V1;                                 \
+    *reinterpret_cast<u32x4*>((XT) + lds_slot + 128 * PIXB) = V2;                                \
+    *reinterpret_cast<u32x4*>((XT) + lds_slot + 192 * PIXB) = V3;                                \
+    *reinterpret_cast<u32x4*>((XT) + lds_slot + 256 * PIXB) = V4;                                \
+    if (lt < 16) *reinterpret_cast<u32x4*>((XT) + lds_slot + 320 * PIXB) = V5;
+
+        // load order (the vmcnt arithmetic depends on it): A(0) B(0) A(1) | B(1) A(2) | B(2) A(3) | ...
+        int item = blockIdx.x;
+        WR_PIXELS(item)
+        WR_ISSUE_A
+        WR_ISSUE_B
+        WR_STORE(xb0, xa0, xa1, xa2, xa3, xa4, xa5)
+        WR_PIXELS(item + (int)gridDim.x)            // pix* now describe item + 1 until B(item + 1) has been issued
+        WR_ISSUE_A
+        for (; item < nitems; item += gridDim.x) {
+            lds_barrier();                           // B0: X0 = chunk 0 of this item is complete; X1 is free
+            WR_STORE(xb1, xb_0, xb_1, xb_2, xb_3, xb_4, xb_5)
+            WR_ISSUE_B                               // chunk 1 of the next item
+            lds_barrier();                           // B1: X1 complete; X0 is free
+            WR_STORE(xb0, xa0, xa1, xa2, xa3, xa4, xa5)
+            WR_PIXELS(item + 2 * (int)gridDim.x)
+            WR_ISSUE_A                               // chunk 0 of the item after next
+        }
+#undef WR_PIX
+#undef WR_PIXELS
+#undef WR_LD
+#undef WR_ISSUE_A
+#undef WR_ISSUE_B
+#undef WR_STORE
+    } else {
+        // ------------------------------------------------------------ MFMA waves
+        float4 bv[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int nt = 0; nt < 4; ++nt) {
+            bv[nt] = a.bias ? *reinterpret_cast<const float4*>(a.bias + nb * BN + nt * 16 + (lane >> 4) * 4)
+                            : make_float4(0.f, 0.f, 0.f, 0.f);
+            // consumed here, so that the wait for it is placed before the loop and not (as vmcnt(0)) inside it
+            asm volatile("" : "+v"(bv[nt].x), "+v"(bv[nt].y), "+v"(bv[nt].z), "+v"(bv[nt].w));
+        }
+        char* yp; int cy, coff;
+        if (nb * BN < a.cy1) { yp = a.y1; cy = a.cy1; coff = nb * BN; }
+        else { yp = a.y2; cy = a.cout - a.cy1; coff = nb * BN - a.cy1; }
+        const auto rsy = wave_uniform_rsrc(yp, npix * cy * TSZ);
+        int abase[4], soff[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-        // ---- stage (item, chunk 0): set A -> X0
-        store_halo_slot(xa0, xb0, gt_cur, 324, tid);
-        store_halo_slot(xa1, xb0, gt_cur, 324, tid + FT);
-        store_halo_slot(xa2, xb0, gt_cur, 324, tid + 2 * FT);
-        store_halo_slot(xa3, xb0, gt_cur, 324, tid + 3 * FT);
-        store_halo_slot(xa4, xb0, gt_cur, 324, tid + 4 * FT);
-        store_halo_slot(xa5, xb0, gt_cur, 324, tid + 5 * FT);
-        STAMP(1);
-        if (has_next) build(gt_nxt, next / nblk);
-        STAMP(2);
-        lds_barrier();
-        STAMP(3);
-        if (has_next) WR_ISSUE_A(gt_nxt)              // chunk 0 of the NEXT item: two stages ahead
-        STAMP(4);
-        P::template mma_chunk<4, true>(acc, xb0, abase, HWB, wt, lane);
-        STAMP(5);
-
-        // ---- stage (item, chunk 1): set B -> X1
-        store_halo_slot(xb_0, xb1, gt_cur, 324, tid);
-        store_halo_slot(xb_1, xb1, gt_cur, 324, tid + FT);
-        store_halo_slot(xb_2, xb1, gt_cur, 324, tid + 2 * FT);
-        store_halo_slot(xb_3, xb1, gt_cur, 324, tid + 3 * FT);
-        store_halo_slot(xb_4, xb1, gt_cur, 324, tid + 4 * FT);
-        store_halo_slot(xb_5, xb1, gt_cur, 324, tid + 5 * FT);
-        STAMP(1);
-        lds_barrier();
-        STAMP(3);
-        if (has_next) WR_ISSUE_B(gt_nxt)
-        STAMP(4);
-        P::template mma_chunk<4, true>(acc, xb1, abase, HWB, wt + WT_BYTES, lane);
-        STAMP(5);
-
-        // ---- epilogue: wave-private LDS transpose, two passes of 32 pixels (tile rows 4w+2p, 4w+2p+1)
-        {
-            const int txi = tile % g.tiles_x;
+        for (int mt = 0; mt < 4; ++mt) {
+            const int ty = wave * 4 + mt, tx = lane & 15;          // tile pixel m = wave*64 + mt*16 + (lane&15)
+            abase[mt] = ((ty + 1) * 18 + tx + 1) * PIXB + P::a_lane_off(lane);
+            // after the row swap, lane group g = lane>>4 holds channels (g&1)*16 + (g>>1)*8 .. +7 of the n-tile pair
+            soff[mt] = ((ty * a.w + tx) * cy + coff + ((lane >> 4) & 1) * 16 + (lane >> 5) * 8) * TSZ;
+        }
+        // The results of item i leave the registers during the MFMA phases of item i+1: packed to bf16 they wait in
+        // pend[] and one 16-byte store is issued every other tap step, so the store queue never backs up into the
+        // MFMA issue.  Before the first item the offsets are out of range (stores dropped).
+        u32x4 pend[8];
+        unsigned pvo[4] = {WR_OOB, WR_OOB, WR_OOB, WR_OOB};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) pend[i] = u32x4{0u, 0u, 0u, 0u};
+#define WR_PEND_STORE(IDX)                                                                                    \
+    do {                                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);   /* pin the store between two tap steps (hipcc would bunch them) */ \
+        __builtin_amdgcn_raw_buffer_store_b128(pend[IDX], rsy, pvo[(IDX) >> 1], ((IDX) & 1) * 32 * TSZ, 0);     \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+    } while (0)
+        for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+            const int tile = item / nblk;
             const int r = tile / g.tiles_x;
-            const int tyi = r % g.tiles_y, nn = r / g.tiles_y;
-            const int y0 = tyi << 4, x0 = txi << 4;
+            const int x0 = (tile - r * g.tiles_x) << 4;
+            const int nn = r / g.tiles_y;
+            const int y0 = (r - nn * g.tiles_y) << 4;
+            f32x4 acc[4][4];
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int mh = 0; mh < 2; ++mh) {
-                    const int mt = 2 * p + mh;
-                    const int pl = mh * 16 + (lane & 15);
+                for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{bv[j].x, bv[j].y, bv[j].z, bv[j].w};
+            STAMP(1);
+            lds_barrier();                           // B0
+            STAMP(3);
+            P::mma_chunk_rows(acc, xb0, abase[0], HWB, wt, lane, [&](int st) {
+                if (st == 1) WR_PEND_STORE(0); else if (st == 3) WR_PEND_STORE(1);
+                else if (st == 5) WR_PEND_STORE(2); else if (st == 7) WR_PEND_STORE(3);
+            });
+            STAMP(5);
+            lds_barrier();                           // B1
+            STAMP(4);
+            P::mma_chunk_rows(acc, xb1, abase[0], HWB, wt + WT_BYTES, lane, [&](int st) {
+                if (st == 1) WR_PEND_STORE(4); else if (st == 3) WR_PEND_STORE(5);
+                else if (st == 5) WR_PEND_STORE(6); else if (st == 7) WR_PEND_STORE(7);
+            });
+            STAMP(5);
+            // Pack the accumulators for the deferred stores.  A lane owns 4 consecutive channels (8 B) of pixel
+            // (mt, lane & 15) per n-tile; v_permlane16_swap trades the odd 16-lane rows of one n-tile with the even
+            // rows of the next, after which every lane holds 8 consecutive channels: 16-byte stores, two
+            // instructions per 128-byte NHWC row instead of four.
+            const int tbase = ((nn * a.h + y0) * a.w + x0) * cy * TSZ;
+            const bool xok = (lane & 15) < a.w - x0;
 #pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) {
-                        float v[4] = {acc[mt][nt][0] + bv[nt].x, acc[mt][nt][1] + bv[nt].y, acc[mt][nt][2] + bv[nt].z,
-                                      acc[mt][nt][3] + bv[nt].w};
-                        if (a.epilogue == AD_EPI_RELU) {
+            for (int mt = 0; mt < 4; ++mt) {
+                const bool ok = xok && wave * 4 + mt < a.h - y0;
+                pvo[mt] = ok ? (unsigned)(tbase + soff[mt]) : WR_OOB;
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+                for (int np = 0; np < 2; ++np) {
+                    union { bf16x4 h; u32x2 u; } pa, pb;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float va = acc[mt][2 * np][q], vb = acc[mt][2 * np + 1][q];
+                        if (RELU) {
+                            va = __builtin_amdgcn_fmed3f(va, 0.f, __builtin_inff());
+                            vb = __builtin_amdgcn_fmed3f(vb, 0.f, __builtin_inff());
                         }
-                        bf16x4 pk = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-                        *reinterpret_cast<bf16x4*>(ot + pl * WR_OS + (nt * 16 + (lane >> 4) * 4) * TSZ) = pk;
+                        pa.h[q] = (bf16_t)va;
+                        pb.h[q] = (bf16_t)vb;
                     }
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int pl = j * 8 + (lane >> 3), part = lane & 7;
-                    const int y = y0 + wave * 4 + 2 * p + (pl >> 4), x = x0 + (pl & 15);
-                    if (y < a.h && x < a.w) {
-                        const size_t gp = ((size_t)nn * a.h + y) * a.w + x;
-                        *reinterpret_cast<uint4*>(yp + (gp * cy + coff) * TSZ + part * 16) =
-                            *reinterpret_cast<const uint4*>(ot + pl * WR_OS + part * 16);
-                    }
+                    const u32x2 s0 = __builtin_amdgcn_permlane16_swap(pa.u[0], pb.u[0], false, false);
+                    const u32x2 s1 = __builtin_amdgcn_permlane16_swap(pa.u[1], pb.u[1], false, false);
+                    pend[mt * 2 + np] = u32x4{s0[0], s1[0], s0[1], s1[1]};
                 }
             }
+            STAMP(7);
         }
-        STAMP(7);
-        cur ^= 1;
+        WR_PEND_STORE(0); WR_PEND_STORE(1); WR_PEND_STORE(2); WR_PEND_STORE(3);
+        WR_PEND_STORE(4); WR_PEND_STORE(5); WR_PEND_STORE(6); WR_PEND_STORE(7);
+#undef WR_PEND_STORE
     }
 #ifdef AD_STAMP
     if (tid == 0 && a.dbg) {
@@ -711,9 +789,6 @@ __global__ __launch_bounds__(FT, 1) void conv3x3_fwd_wres_kernel(ConvArgs a) {
         a.dbg[blockIdx.x * 9 + 8] = clock64() - t_begin;
     }
 #endif
-#undef WR_SRC
-#undef WR_ISSUE_A
-#undef WR_ISSUE_B
 }
 
 // ------------------------------------------------------------------ wgrad
@@ -1028,15 +1103,22 @@ int launch_fwd(ConvArgs a, void* ws, size_t ws_bytes, hipStream_t s) {
         allow_big_lds(conv3x3_fwd_kernel<P, 6, true>);
         allow_big_lds(conv3x3_fwd_kernel<P, 16, true>);
         allow_big_lds(conv3x3_fwd_kernel<P, 6, false>);
-        if constexpr (sizeof(typename P::T) == 2) allow_big_lds(conv3x3_fwd_wres_kernel<P>);
+        if constexpr (sizeof(typename P::T) == 2) {
+            allow_big_lds(conv3x3_fwd_wres_kernel<P, false>);
+            allow_big_lds(conv3x3_fwd_wres_kernel<P, true>);
+        }
         attr_set = true;
     }
     if constexpr (sizeof(typename P::T) == 2) {
         // weights-resident kernel: two channel chunks, 16x16 tiles, enough tiles to give every CU several items
         const bool geo16 = g.lti == 0 && g.lth == 4 && g.ltw == 4;
         a.ksplit = 1; a.slab = nullptr;
-        if (halo && geo16 && nch == 2 && NUM_CU % nblk == 0 && nitems >= 4 * NUM_CU) {
-            conv3x3_fwd_wres_kernel<P><<<NUM_CU, FT, WR_LDS, s>>>(a);
+        const long long npix_ = (long long)a.n * a.h * a.w;
+        const long long widest = a.c1 > a.c2 ? (a.c1 > a.cout ? a.c1 : a.cout) : (a.c2 > a.cout ? a.c2 : a.cout);
+        const bool fits = npix_ * widest * 2 <= WR_MAX_BYTES;      // 32-bit buffer offsets
+        if (halo && geo16 && nch == 2 && NUM_CU % nblk == 0 && nitems >= 4 * NUM_CU && fits) {
+            if (a.epilogue == AD_EPI_RELU) conv3x3_fwd_wres_kernel<P, true><<<NUM_CU, WR_T, WR_LDS, s>>>(a);
+            else conv3x3_fwd_wres_kernel<P, false><<<NUM_CU, WR_T, WR_LDS, s>>>(a);
             AD_LAUNCH_CHECK("conv3x3_fwd_wres");
             return AD_OK;
         }
