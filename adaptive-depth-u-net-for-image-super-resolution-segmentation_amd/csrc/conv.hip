@@ -1024,6 +1024,224 @@ __global__ __launch_bounds__(256, XS <= 6 ? 2 : 1) void conv3x3_wgrad_kernel(Wgr
             }
 }
 
+// ------------------------------------------------------------------ wgrad, wave specialised (bf16, 16x16 tiles)
+// One 512-thread workgroup accumulates 9 taps x 64 input channels x 64 output channels over its share of tiles.
+//   * waves 0-3 (MFMA): wave w owns input channels 16w..16w+15 and ALL 64 output channels, 9 x 4 accumulator tiles
+//     (144 registers).  Per k-step that is 9 transposed A reads (one per tap) + 4 B reads for 36 MFMAs, against
+//     9 + 2 for 18 in conv3x3_wgrad_kernel: the LDS traffic per MFMA, which bounds that kernel, drops by 40 %, and
+//     dz is fetched once per 64 input channels instead of once per 32.
+//   * waves 4-7 (loaders): buffer loads (out-of-image -> zeros) a full stage ahead, then LDS stores in the shadow of
+//     the MFMA phases.
+// A tile is processed as two halves (tile rows 0-7 = k-steps 0-3, rows 8-15 = k-steps 4-7), each with its own x
+// halo buffer (10 halo rows x 18 columns, two 32-channel chunks) and dz buffer, so one half is refilled while the
+// other is consumed; two barriers per tile.  LDS: 4 x 17,280 + 2 x 20,480 = 110,080 B.
+constexpr int W2_T = 512;
+constexpr int W2_XPIX = 10 * 18;                 // halo pixels per half
+constexpr int W2_XB = W2_XPIX * PIXB;            // one 32-channel chunk of one half (17,280 B)
+constexpr int W2_DZS = BN * 2 + 32;              // dz pixel stride (160 B), as WgradPol<PolBF16>::DZS
+constexpr int W2_DZB = 128 * W2_DZS;             // dz half tile (20,480 B)
+constexpr size_t W2_LDS = 4 * W2_XB + 2 * W2_DZB;
+constexpr int W2_XSL = 6;                        // x slots per loader thread and half (1440 of 1536 used)
+constexpr int W2_DSL = 4;                        // dz slots per loader thread and half
+
+// One half tile (4 k-steps) of K for one MFMA wave.  xh: this wave's 32-channel chunk of the half's halo buffer,
+// already offset to its 16 channels; dzh: the half's dz buffer.  Same k <-> pixel map and fragment ring as
+// WgradPol<PolBF16>::tile.
+template <int S>
+__device__ __forceinline__ void w2_stages(f32x4 (&acc)[9][4], const char* xh, const char* dzh, const int (&xa)[4],
+                                          const int (&xb)[4], int dzo, bf16x8 (&afr)[4], bf16x8 (&bfr)[2][4]) {
+    typedef WgradPol<PolBF16> WP;
+    constexpr int NS = 4 * 9, NPRE = 4, RB = 18 * PIXB;
+    if constexpr (S < NS) {
+        constexpr int ks = S / 9, t = S % 9;
+        if constexpr (t == 0 && ks + 1 < 4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                bfr[(ks + 1) & 1][j] = WP::tr_pair(dzh + dzo + (ks + 1) * 32 * W2_DZS + j * 32,
+                                                   dzh + dzo + ((ks + 1) * 32 + 16) * W2_DZS + j * 32);
+        }
+        const bf16x8 a_cur = afr[S % NPRE];
+        if constexpr (S + NPRE < NS) {
+            constexpr int ks2 = (S + NPRE) / 9, t2 = (S + NPRE) % 9;
+            constexpr int toff2 = (t2 / 3 - 1) * RB + (t2 % 3 - 1) * PIXB;
+            afr[S % NPRE] = WP::tr_pair(xh + xa[ks2] + toff2, xh + xb[ks2] + toff2);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_cur, bfr[ks & 1][j], acc[t][j], 0, 0, 0);
+        w2_stages<S + 1>(acc, xh, dzh, xa, xb, dzo, afr, bfr);
+    }
+}
+
+__device__ __forceinline__ void w2_half(f32x4 (&acc)[9][4], const char* xh, const char* dzh, const int (&xa)[4],
+                                        const int (&xb)[4], int dzo) {
+    typedef WgradPol<PolBF16> WP;
+    constexpr int RB = 18 * PIXB;
+    bf16x8 afr[4], bfr[2][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        bfr[0][j] = WP::tr_pair(dzh + dzo + j * 32, dzh + dzo + 16 * W2_DZS + j * 32);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int toff = (t / 3 - 1) * RB + (t % 3 - 1) * PIXB;
+        afr[t] = WP::tr_pair(xh + xa[0] + toff, xh + xb[0] + toff);
+    }
+    w2_stages<0>(acc, xh, dzh, xa, xb, dzo, afr, bfr);
+}
+
+// grid: x = K split, y = 64-input-channel block, z = 64-output-channel block
+// ws slab layout: [split][cib][cob][tap][64][64] fp32
+__global__ __launch_bounds__(W2_T, 1) void conv3x3_wgrad_ws_kernel(WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const Geo& g = a.g;      // geometry is (1, 16, 16)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int TSZ = 2;
+    const int split = blockIdx.x, cib = blockIdx.y, cob = blockIdx.z;
+    const int t_begin = split * a.tiles_per_split;
+    const int t_end = min(a.ntiles, t_begin + a.tiles_per_split);
+    const int npix = a.n * a.h * a.w;
+    // LDS: half hf: x chunk c at smem + (2*hf + c) * W2_XB, dz at smem + 4*W2_XB + hf * W2_DZB
+
+    if (wave >= 4) {
+        // ------------------------------------------------------------ loader waves
+        const int lt = tid - 256;
+        // the two 32-channel chunks of this input block (virtual concat: either may come from x2)
+        const int c0 = cib * 64, c1 = c0 + 32;
+        const bool s0 = c0 < a.c1, s1 = c1 < a.c1;
+        const int rb0 = (s0 ? a.c1 : a.c2) * TSZ, ob0 = (s0 ? c0 : c0 - a.c1) * TSZ;
+        const int rb1 = (s1 ? a.c1 : a.c2) * TSZ, ob1 = (s1 ? c1 : c1 - a.c1) * TSZ;
+        const auto rs0 = wave_uniform_rsrc(s0 ? a.x1 : a.x2, npix * rb0);
+        const auto rs1 = wave_uniform_rsrc(s1 ? a.x1 : a.x2, npix * rb1);
+        const int rbz = a.cout * TSZ;
+        const auto rsz = wave_uniform_rsrc(a.dz, npix * rbz);
+        // x slot i: chunk i / 3 (compile time, so each load names one descriptor), s = lt + 256 (i % 3) < 720 ->
+        // halo pixel s / 4 = (row hy, col hx), part s % 4
+        int xdesc[W2_XSL], xlds[W2_XSL];
+#pragma unroll
+        for (int i = 0; i < W2_XSL; ++i) {
+            const int sidx = lt + 256 * (i % 3);
+            const int px = sidx >> 2, part = sidx & 3;
+            const int hy = px / 18, hx = px - hy * 18;
+            const bool used = sidx < 720;
+            xdesc[i] = used ? (hy << 8) | hx : (64 << 8);                      // row 64: never inside an image
+            xlds[i] = used ? (i / 3) * W2_XB + px * PIXB + part * 16 : -1;
+        }
+        const int xpart = (lt & 3) * 16;        // 256 % 4 == 0: the part is lt & 3 for every slot
+        // dz slot i: s = lt + 256 i -> half-tile pixel s / 8 (row s / 128, col (s / 8) % 16), part s % 8
+        const int dpart = (lt & 7) * 16;
+        const int dcol = (lt >> 3) & 15;
+        const int drow0 = lt >> 7;              // + 2 i
+        const int dlds = (lt >> 3) * W2_DZS + dpart;      // + 32 i * W2_DZS
+        u32x4 pa0, pa1, pa2, pa3, pa4, pa5, pb0, pb1, pb2, pb3, pb4, pb5;   // x slots of half A / half B
+        u32x4 qa0, qa1, qa2, qa3, qb0, qb1, qb2, qb3;                       // dz slots
+#define W2_XLD(I, NN, YB, X0)                                                                              \
+    ({                                                                                                     \
+        const int y_ = (YB) + (xdesc[I] >> 8), x_ = (X0) - 1 + (xdesc[I] & 255);                           \
+        const bool ok_ = (unsigned)y_ < (unsigned)a.h && (unsigned)x_ < (unsigned)a.w;                     \
+        const int pix_ = ((NN) * a.h + y_) * a.w + x_;                                                     \
+        (I) < 3 ? __builtin_amdgcn_raw_buffer_load_b128(rs0, ok_ ? (unsigned)(pix_ * rb0 + ob0 + xpart) : WR_OOB, 0, 0) \
+                : __builtin_amdgcn_raw_buffer_load_b128(rs1, ok_ ? (unsigned)(pix_ * rb1 + ob1 + xpart) : WR_OOB, 0, 0); \
+    })
+#define W2_ZLD(I, NN, YB, X0)                                                                              \
+    ({                                                                                                     \
+        const int y_ = (YB) + drow0 + 2 * (I), x_ = (X0) + dcol;                                           \
+        const bool ok_ = y_ < a.h && x_ < a.w;                                                             \
+        const int pix_ = ((NN) * a.h + y_) * a.w + x_;                                                     \
+        __builtin_amdgcn_raw_buffer_load_b128(rsz, ok_ ? (unsigned)(pix_ * rbz + cob * BN * TSZ + dpart) : WR_OOB, 0, 0); \
+    })
+#define W2_TILE(TILE)                                                                                      \
+    const int tile_ = min((TILE), t_end - 1);   /* past the end: re-fetch the last tile, loads stay unconditional */ \
+    const int r_ = tile_ / g.tiles_x;                                                                      \
+    const int x0_ = (tile_ - r_ * g.tiles_x) << 4;                                                         \
+    const int nn_ = r_ / g.tiles_y;                                                                        \
+    const int y0_ = (r_ - nn_ * g.tiles_y) << 4;
+#define W2_ISSUE_A(TILE)                                                                                   \
+    {                                                                                                      \
+        W2_TILE(TILE)                                                                                      \
+        const int yb_ = y0_ - 1;                                                                           \
+        pa0 = W2_XLD(0, nn_, yb_, x0_); pa1 = W2_XLD(1, nn_, yb_, x0_); pa2 = W2_XLD(2, nn_, yb_, x0_);    \
+        pa3 = W2_XLD(3, nn_, yb_, x0_); pa4 = W2_XLD(4, nn_, yb_, x0_); pa5 = W2_XLD(5, nn_, yb_, x0_);    \
+        qa0 = W2_ZLD(0, nn_, y0_, x0_); qa1 = W2_ZLD(1, nn_, y0_, x0_);                                    \
+        qa2 = W2_ZLD(2, nn_, y0_, x0_); qa3 = W2_ZLD(3, nn_, y0_, x0_);                                    \
+        asm volatile("" ::: "memory");                                                                     \
+    }
+#define W2_ISSUE_B(TILE)                                                                                   \
+    {                                                                                                      \
+        W2_TILE(TILE)                                                                                      \
+        const int yb_ = y0_ + 7;                                                                           \
+        pb0 = W2_XLD(0, nn_, yb_, x0_); pb1 = W2_XLD(1, nn_, yb_, x0_); pb2 = W2_XLD(2, nn_, yb_, x0_);    \
+        pb3 = W2_XLD(3, nn_, yb_, x0_); pb4 = W2_XLD(4, nn_, yb_, x0_); pb5 = W2_XLD(5, nn_, yb_, x0_);    \
+        qb0 = W2_ZLD(0, nn_, y0_ + 8, x0_); qb1 = W2_ZLD(1, nn_, y0_ + 8, x0_);                            \
+        qb2 = W2_ZLD(2, nn_, y0_ + 8, x0_); qb3 = W2_ZLD(3, nn_, y0_ + 8, x0_);                            \
+        asm volatile("" ::: "memory");                                                                     \
+    }
+#define W2_STORE(HF, P0, P1, P2, P3, P4, P5, Q0, Q1, Q2, Q3)                                               \
+    {                                                                                                      \
+        char* xh_ = smem + 2 * (HF) * W2_XB;                                                               \
+        char* zh_ = smem + 4 * W2_XB + (HF) * W2_DZB + dlds;                                               \
+        *reinterpret_cast<u32x4*>(xh_ + xlds[0]) = P0; *reinterpret_cast<u32x4*>(xh_ + xlds[1]) = P1;     \
+        *reinterpret_cast<u32x4*>(xh_ + xlds[3]) = P3; *reinterpret_cast<u32x4*>(xh_ + xlds[4]) = P4;     \
+        if (xlds[2] >= 0) {                                                                                \
+            *reinterpret_cast<u32x4*>(xh_ + xlds[2]) = P2; *reinterpret_cast<u32x4*>(xh_ + xlds[5]) = P5; \
+        }                                                                                                  \
+        *reinterpret_cast<u32x4*>(zh_) = Q0; *reinterpret_cast<u32x4*>(zh_ + 32 * W2_DZS) = Q1;            \
+        *reinterpret_cast<u32x4*>(zh_ + 64 * W2_DZS) = Q2; *reinterpret_cast<u32x4*>(zh_ + 96 * W2_DZS) = Q3; \
+    }
+        // load order (the vmcnt arithmetic depends on it): A(0) B(0) A(1) | B(1) A(2) | ...
+        int tile = t_begin;
+        W2_ISSUE_A(tile)
+        W2_ISSUE_B(tile)
+        W2_STORE(0, pa0, pa1, pa2, pa3, pa4, pa5, qa0, qa1, qa2, qa3)
+        W2_ISSUE_A(tile + 1)
+        for (; tile < t_end; ++tile) {
+            lds_barrier();                           // B0: half A of this tile is complete; half B is free
+            W2_STORE(1, pb0, pb1, pb2, pb3, pb4, pb5, qb0, qb1, qb2, qb3)
+            W2_ISSUE_B(tile + 1)
+            lds_barrier();                           // B1: half B complete; half A is free
+            W2_STORE(0, pa0, pa1, pa2, pa3, pa4, pa5, qa0, qa1, qa2, qa3)
+            W2_ISSUE_A(tile + 2)
+        }
+#undef W2_XLD
+#undef W2_ZLD
+#undef W2_TILE
+#undef W2_ISSUE_A
+#undef W2_ISSUE_B
+#undef W2_STORE
+    } else {
+        // ------------------------------------------------------------ MFMA waves
+        const int grp = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+        int xa[4], xb[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int m = ks * 32 + grp * 4 + q;                      // pixel of the half tile (row m>>4, col m&15)
+            xa[ks] = (((m >> 4) + 1) * 18 + (m & 15) + 1) * PIXB + p * 8;
+            xb[ks] = (((m >> 4) + 2) * 18 + (m & 15) + 1) * PIXB + p * 8;
+        }
+        const int dzo = (grp * 4 + q) * W2_DZS + p * 8;
+        const int xw = (wave >> 1) * W2_XB + (wave & 1) * 32;        // this wave's chunk and 16-channel half of it
+        f32x4 acc[9][4];
+#pragma unroll
+        for (int i = 0; i < 9; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int tile = t_begin; tile < t_end; ++tile) {
+            lds_barrier();                           // B0
+            w2_half(acc, smem + xw, smem + 4 * W2_XB, xa, xb, dzo);
+            lds_barrier();                           // B1
+            w2_half(acc, smem + 2 * W2_XB + xw, smem + 4 * W2_XB + W2_DZB, xa, xb, dzo);
+        }
+        float* slab = a.ws + ((size_t)(split * a.ncib + cib) * a.ncob + cob) * (9 * 64 * BN);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    slab[(tap * 64 + wave * 16 + (lane >> 4) * 4 + r) * BN + j * 16 + (lane & 15)] = acc[tap][j][r];
+    }
+}
+
 // dw_hwio[tap][ci][co] = sum over splits of the slabs, fixed order (deterministic).
 // block = 64 consecutive (tap, ci, co) columns x 4 split groups.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
@@ -1153,16 +1371,21 @@ int launch_fwd(ConvArgs a, void* ws, size_t ws_bytes, hipStream_t s) {
 struct WgradPlan {
     Geo g;
     int ntiles, nsplit, tiles_per_split, ncib, ncob, ck;
+    bool specialised;          // conv3x3_wgrad_ws_kernel (bf16, 16x16 tiles, 64-channel input blocks)
     size_t ws_bytes;
 };
 
-static void plan_wgrad(int n, int h, int w, int cin, int cout, int dtype, WgradPlan* p) {
+static void plan_wgrad(int n, int h, int w, int c1, int c2, int cout, int dtype, WgradPlan* p) {
+    const int cin = c1 + c2;
     pick_geo(n, h, w, &p->g);
-    p->ck = dtype == AD_BF16 ? PolBF16::CK : PolF32::CK;
-    p->ncib = cin / p->ck;
-    p->ncob = cout / BN;
     p->ntiles = p->g.tiles_x * p->g.tiles_y * p->g.tiles_i;
-    int want = (2 * NUM_CU) / (p->ncib * p->ncob);   // ~2 workgroups per CU in total
+    p->ncob = cout / BN;
+    const long long widest = (long long)n * h * w * (c1 > c2 ? (c1 > cout ? c1 : cout) : (c2 > cout ? c2 : cout)) * 2;
+    p->specialised = dtype == AD_BF16 && p->g.lti == 0 && p->g.lth == 4 && p->g.ltw == 4 && cin % 64 == 0 &&
+                     c1 % 32 == 0 && widest <= WR_MAX_BYTES && p->ntiles >= 4 * NUM_CU / ((cin / 64) * p->ncob);
+    p->ck = p->specialised ? 64 : dtype == AD_BF16 ? PolBF16::CK : PolF32::CK;
+    p->ncib = cin / p->ck;
+    int want = ((p->specialised ? 1 : 2) * NUM_CU) / (p->ncib * p->ncob);   // workgroups per CU in total
     if (want < 1) want = 1;
     if (want > p->ntiles) want = p->ntiles;
     p->tiles_per_split = (p->ntiles + want - 1) / want;
@@ -1186,6 +1409,15 @@ int launch_wgrad(WgradArgs a, const WgradPlan& p, hipStream_t s) {
         attr_set = true;
     }
     dim3 grid(p.nsplit, p.ncib, p.ncob);
+    if constexpr (sizeof(typename P::T) == 2) {
+        if (p.specialised) {
+            static bool attr2 = false;
+            if (!attr2) { allow_big_lds(conv3x3_wgrad_ws_kernel); attr2 = true; }
+            conv3x3_wgrad_ws_kernel<<<grid, W2_T, W2_LDS, s>>>(a);
+            AD_LAUNCH_CHECK("conv3x3_wgrad_ws");
+            return AD_OK;
+        }
+    }
     const bool halo = g.ph && g.pw;
     if (!halo && (g.ph || g.pw || xs != 6))
         return ad_set_error(AD_ERR_ARG, "conv3x3_wgrad: feature maps with exactly one unit extent (%dx%d) are not supported", a.h, a.w);
@@ -1264,7 +1496,7 @@ extern "C" size_t ad_conv3x3_fwd_ws_bytes(int n, int h, int w, int cin, int cout
 extern "C" size_t ad_conv3x3_wgrad_ws_bytes(int n, int h, int w, int cin, int cout, int dtype) {
     WgradPlan p;
     if (n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0 || cout % BN) return 0;
-    plan_wgrad(n, h, w, cin, cout, dtype, &p);
+    plan_wgrad(n, h, w, cin, 0, cout, dtype, &p);     // the split of cin does not change the slab size
     return p.ws_bytes;
 }
 
@@ -1281,7 +1513,7 @@ extern "C" int ad_conv3x3_wgrad(const void* x1, int c1, const void* x2, int c2, 
     const int cin = c1 + c2;
     AD_REQUIRE(cin_real > 0 && cin_real <= cin, "ad_conv3x3_wgrad: cin_real=%d", cin_real);
     WgradPlan p;
-    plan_wgrad(n, h, w, cin, cout, dtype, &p);
+    plan_wgrad(n, h, w, c1, c2, cout, dtype, &p);
     if (ws == nullptr || ws_bytes < p.ws_bytes)
         return ad_set_error(AD_ERR_WS, "ad_conv3x3_wgrad: workspace %zu < %zu bytes", ws_bytes, p.ws_bytes);
     WgradArgs a;

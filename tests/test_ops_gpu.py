@@ -108,6 +108,104 @@ def test_conv3x3_wgrad(device, ws, dtype, shape):
     assert torch.equal(dw, dw2), "wgrad must be bitwise deterministic"
 
 
+# ---- large launches: the wave-specialised kernels (weights-resident forward/dgrad, 64-channel-block wgrad) only run
+# when a launch has >= 4 tiles per CU, far beyond what the NumPy oracle can convolve whole.  A 3x3 conv is local, so
+# the oracle is evaluated on windows (corners, edges, ragged last tiles, interior) and, for the whole tensor, the
+# specialised launch is compared with the oracle-checked generic kernel run image by image (small launches).
+BIG = (5, 250, 246)      # 16 x 16 tiles per image, ragged on both axes: 1280 tiles
+WINDOWS = [(0, 0, 0), (0, 228, 224), (2, 100, 0), (3, 0, 117), (4, 231, 100), (1, 120, 130), (4, 228, 224)]
+WIN = 22
+
+
+def _window_check(y_dev, x_full, wk, b, relu, tol):
+    """Oracle conv on WIN x WIN crops; positions whose 3x3 support leaves the crop but not the image are skipped."""
+    n, h, w = BIG
+    for img, y0, x0 in WINDOWS:
+        y1, x1 = min(y0 + WIN, h), min(x0 + WIN, w)
+        want = ref.conv2d_same_fwd(x_full[img:img + 1, y0:y1, x0:x1], wk, b)[0]
+        if relu:
+            want = np.maximum(want, 0)
+        ys = slice(0 if y0 == 0 else 1, (y1 - y0) if y1 == h else (y1 - y0 - 1))
+        xs = slice(0 if x0 == 0 else 1, (x1 - x0) if x1 == w else (x1 - x0 - 1))
+        got = y_dev[img, y0:y1, x0:x1].to(torch.float64).cpu().numpy()
+        err = np.abs(got[ys, xs] - want[ys, xs]).max() / (np.abs(want).max() + 1e-30)
+        assert err < tol, (img, y0, x0, err)
+
+
+@pytest.mark.parametrize("case", [(64, 0, 64, False), (64, 0, 64, True), (32, 32, 64, False), (64, 0, 128, False)])
+def test_conv3x3_fwd_large_launch(device, case):
+    from adunet_amd import ops
+    c1, c2, cout, relu = case
+    n, h, w = BIG
+    rng = np.random.default_rng(11)
+    x = rnd(rng.standard_normal((n, h, w, c1 + c2)), BF16)
+    wk = rnd(rng.standard_normal((3, 3, c1 + c2, cout)) * 0.1, BF16)
+    b = rng.standard_normal(cout).astype(np.float32).astype(np.float64)
+    x1 = to_dev(x[..., :c1], BF16, device)
+    x2 = to_dev(x[..., c1:], BF16, device) if c2 else None
+    wf, _ = ops.conv3x3_pack(torch.tensor(wk, dtype=F32, device=device), c1 + c2, BF16, want_dgrad=False)
+    bias = torch.tensor(b, dtype=F32, device=device)
+    y = ops.conv3x3_fwd(x1, x2, wf, bias, cout, relu=relu)
+    _window_check(y, x, wk, b, relu, TOL[BF16])
+    for i in range(n):          # whole tensor against the generic kernel (256 tiles per launch)
+        yi = ops.conv3x3_fwd(x1[i:i + 1].contiguous(), x2[i:i + 1].contiguous() if c2 else None, wf, bias, cout, relu=relu)
+        d = (y[i].float() - yi[0].float()).abs().max() / yi.float().abs().max()
+        assert float(d) < 2 ** -7, (i, float(d))     # same fp32 sums in another order, one bf16 rounding each
+    y2 = ops.conv3x3_fwd(x1, x2, wf, bias, cout, relu=relu)
+    assert torch.equal(y, y2)
+
+
+def test_conv3x3_dgrad_large_launch_split_outputs(device):
+    """dgrad of the 64+64 -> 64 concat conv: Cin(dgrad) = 64, two 64-channel output blocks into two tensors."""
+    from adunet_amd import ops
+    n, h, w = BIG
+    rng = np.random.default_rng(12)
+    wk = rnd(rng.standard_normal((3, 3, 128, 64)) * 0.1, BF16)
+    dz = rnd(rng.standard_normal((n, h, w, 64)), BF16)
+    _, wd = ops.conv3x3_pack(torch.tensor(wk, dtype=F32, device=device), 128, BF16)
+    d1, d2 = ops.conv3x3_fwd(to_dev(dz, BF16, device), None, wd, None, 128, split=64)
+    wt = np.ascontiguousarray(np.transpose(wk[::-1, ::-1], (0, 1, 3, 2)))     # dgrad = conv with the rotated, transposed kernel
+    _window_check(torch.cat([d1, d2], dim=-1), dz, wt, None, False, TOL[BF16])
+
+
+@pytest.mark.parametrize("case", [(64, 0, 64), (64, 64, 64), (32, 32, 128)])
+def test_conv3x3_wgrad_large_launch(device, ws, case):
+    from adunet_amd import ops
+    c1, c2, cout = case
+    cin = c1 + c2
+    n, h, w = BIG
+    rng = np.random.default_rng(13)
+    x = rnd(rng.standard_normal((n, h, w, cin)), BF16)
+    # dz is non-zero only inside the windows, so the oracle needs the windows alone (wgrad is linear in dz) ...
+    dz = np.zeros((n, h, w, cout))
+    want = np.zeros((3, 3, cin, cout))
+    for img, y0, x0 in WINDOWS[:-1]:
+        y1, x1 = min(y0 + WIN, h), min(x0 + WIN, w)
+        dz[img, y0:y1, x0:x1] = rnd(rng.standard_normal((y1 - y0, x1 - x0, cout)), BF16)
+        ya, xa, yb, xb = max(y0 - 1, 0), max(x0 - 1, 0), min(y1 + 1, h), min(x1 + 1, w)
+        dzc = np.zeros((1, yb - ya, xb - xa, cout))
+        dzc[0, y0 - ya:y1 - ya, x0 - xa:x1 - xa] = dz[img, y0:y1, x0:x1]
+        want += ref.conv2d_same_bwd(x[img:img + 1, ya:yb, xa:xb], np.zeros((3, 3, cin, cout)), dzc, need_dx=False)[1]
+    x1d = to_dev(x[..., :c1], BF16, device)
+    x2d = to_dev(x[..., c1:], BF16, device) if c2 else None
+    dw = torch.full((3, 3, cin, cout), float("nan"), dtype=F32, device=device)
+    ops.conv3x3_wgrad(x1d, x2d, to_dev(dz, BF16, device), dw, cin, ws)
+    assert relerr(dw, want) < 1e-3
+    # ... and with dense dz the whole contraction is compared with the generic kernel summed image by image
+    dzd = to_dev(rnd(rng.standard_normal((n, h, w, cout)), BF16), BF16, device)
+    ops.conv3x3_wgrad(x1d, x2d, dzd, dw, cin, ws)
+    acc = torch.zeros_like(dw)
+    part = torch.empty_like(dw)
+    for i in range(n):
+        ops.conv3x3_wgrad(x1d[i:i + 1].contiguous(), x2d[i:i + 1].contiguous() if c2 else None, dzd[i:i + 1].contiguous(),
+                          part, cin, ws)
+        acc += part
+    assert float((dw - acc).abs().max() / acc.abs().max()) < 1e-4
+    dw2 = torch.empty_like(dw)
+    ops.conv3x3_wgrad(x1d, x2d, dzd, dw2, cin, ws)
+    assert torch.equal(dw, dw2), "wgrad must be bitwise deterministic"
+
+
 @pytest.mark.parametrize("dtype", [F32, BF16])
 def test_first_layer_padded_channels(device, ws, dtype):
     """3-channel network input zero-padded to the conv granule; wgrad writes only the 3 real rows."""
