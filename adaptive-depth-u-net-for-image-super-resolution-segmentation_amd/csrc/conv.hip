@@ -791,6 +791,222 @@ __global__ __launch_bounds__(WR_T, 1) void conv3x3_fwd_wres_kernel(ConvArgs a) {
 #endif
 }
 
+// ------------------------------------------------------------------ forward / dgrad, wave specialised, streamed weights
+// The same organisation as conv3x3_fwd_wres_kernel for any EVEN number of 32-channel chunks (Cin = 128 ... 1024 on
+// 16x16 tiles): the loader waves stream the weight chunk (36.9 KB, L2 resident) together with the halo chunk, one
+// stage = one channel chunk, stages alternate between two [X][W] buffer pairs, one barrier per stage, loads issued
+// two stages ahead of their LDS store.  The pending output stores of an item drain during the first two stages of
+// the next one.  LDS: as above, 135.9 KB.
+template <typename P, bool RELU>
+__global__ __launch_bounds__(WR_T, 1) void conv3x3_fwd_ws_kernel(ConvArgs a) {
+    typedef typename P::T T;
+    static_assert(sizeof(T) == 2, "bf16 throughput path");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const Geo& g = a.g;      // geometry is (1, 16, 16)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    char* xb0 = smem;
+    char* xb1 = xb0 + WR_XB;
+    char* wt0 = xb1 + WR_XB;
+    char* wt1 = wt0 + WT_BYTES;
+    constexpr int TSZ = 2;
+    constexpr int HWB = 18 * PIXB;
+
+    const int nblk = a.cout / BN;
+    const int nitems = a.ntiles * nblk;
+    const int nb = blockIdx.x % nblk;               // gridDim.x is a multiple of nblk: fixed for this workgroup
+    const int cin = a.c1 + a.c2;
+    const int kc_total = cin / P::KV;
+    const int nch = cin / P::CK;                    // even
+    const int npix = a.n * a.h * a.w;
+    const int nloc = (nitems - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // items of this workgroup (>= 1)
+
+    if (wave >= 4) {
+        // ------------------------------------------------------------ loader waves
+        const int lt = tid - 256;
+        const auto rsx1 = wave_uniform_rsrc(a.x1, npix * a.c1 * TSZ);
+        const auto rsx2 = wave_uniform_rsrc(a.c2 ? a.x2 : a.x1, npix * (a.c2 ? a.c2 : a.c1) * TSZ);
+        const auto rsw = wave_uniform_rsrc(a.wp, 9 * cin * a.cout * TSZ);
+        const int part16 = (lt & 3) * 16;
+        int hyx[WR_XS];
+#pragma unroll
+        for (int i = 0; i < WR_XS; ++i) {
+            const int hp = (lt >> 2) + 64 * i;
+            const int hy = hp / 18;
+            hyx[i] = hp < 324 ? (hy << 8) | (hp - hy * 18) : (64 << 8);   // row 64 beyond the tile: never stored
+        }
+        const int lds_slot = (lt >> 2) * PIXB + part16;
+        // weight slot i: s = lt + 256 i -> (tap s>>8 = i, kc (s>>6)&3, co s&63): byte offset inside chunk 0, block nb
+        const int woff = ((((lt >> 6) & 3) * a.cout) + nb * BN + (lt & 63)) * 16;       // + i * kc_total * cout * 16
+        const int wtap = kc_total * a.cout * 16;
+        int pix0, pix1, pix2, pix3, pix4, pix5;
+#define WS_PIX(I, NN, Y0, X0)                                                                    \
+    {                                                                                            \
+        const int y_ = (Y0) - 1 + (hyx[I] >> 8), x_ = (X0) - 1 + (hyx[I] & 255);                 \
+        const bool ok_ = (unsigned)y_ < (unsigned)a.h && (unsigned)x_ < (unsigned)a.w;           \
+        pix##I = ok_ ? ((NN) * a.h + y_) * a.w + x_ : -1;                                        \
+    }
+        // stage cursor of the next issue: local item k (clamped to the last one), chunk ch
+#define WS_PIXELS(K)                                                                             \
+    {                                                                                            \
+        const int tile_ = ((int)blockIdx.x + min((K), nloc - 1) * (int)gridDim.x) / nblk;        \
+        const int r_ = tile_ / g.tiles_x;                                                        \
+        const int x0_ = (tile_ - r_ * g.tiles_x) << 4;                                           \
+        const int nn_ = r_ / g.tiles_y;                                                          \
+        const int y0_ = (r_ - nn_ * g.tiles_y) << 4;                                             \
+        WS_PIX(0, nn_, y0_, x0_) WS_PIX(1, nn_, y0_, x0_) WS_PIX(2, nn_, y0_, x0_)               \
+        WS_PIX(3, nn_, y0_, x0_) WS_PIX(4, nn_, y0_, x0_) WS_PIX(5, nn_, y0_, x0_)               \
+    }
+#define WS_XLD(RS, RB, OB, PIXV) \
+    __builtin_amdgcn_raw_buffer_load_b128((RS), (PIXV) >= 0 ? (unsigned)((PIXV) * (RB) + (OB) + part16) : WR_OOB, 0, 0)
+#define WS_WLD(I, CH) __builtin_amdgcn_raw_buffer_load_b128(rsw, (unsigned)(woff + (I) * wtap + (CH) * 4 * a.cout * 16), 0, 0)
+        u32x4 xa0, xa1, xa2, xa3, xa4, xa5, wa0, wa1, wa2, wa3, wa4, wa5, wa6, wa7, wa8;
+        u32x4 xb_0, xb_1, xb_2, xb_3, xb_4, xb_5, wb0, wb1, wb2, wb3, wb4, wb5, wb6, wb7, wb8;
+#define WS_ISSUE(X0_, X1_, X2_, X3_, X4_, X5_, W0_, W1_, W2_, W3_, W4_, W5_, W6_, W7_, W8_, CH)              \
+    {                                                                                                        \
+        const bool first_ = (CH) * P::CK < a.c1;                                                             \
+        const auto rs_ = first_ ? rsx1 : rsx2;                                                               \
+        const int rb_ = (first_ ? a.c1 : a.c2) * TSZ;                                                        \
+        const int ob_ = (first_ ? (CH) * P::CK : (CH) * P::CK - a.c1) * TSZ;                                 \
+        X0_ = WS_XLD(rs_, rb_, ob_, pix0); X1_ = WS_XLD(rs_, rb_, ob_, pix1); X2_ = WS_XLD(rs_, rb_, ob_, pix2); \
+        X3_ = WS_XLD(rs_, rb_, ob_, pix3); X4_ = WS_XLD(rs_, rb_, ob_, pix4); X5_ = WS_XLD(rs_, rb_, ob_, pix5); \
+        W0_ = WS_WLD(0, CH); W1_ = WS_WLD(1, CH); W2_ = WS_WLD(2, CH); W3_ = WS_WLD(3, CH); W4_ = WS_WLD(4, CH); \
+        W5_ = WS_WLD(5, CH); W6_ = WS_WLD(6, CH); W7_ = WS_WLD(7, CH); W8_ = WS_WLD(8, CH);                  \
+        asm volatile("" ::: "memory");                                                                       \
+    }
+#define WS_ISSUE_A(CH) WS_ISSUE(xa0, xa1, xa2, xa3, xa4, xa5, wa0, wa1, wa2, wa3, wa4, wa5, wa6, wa7, wa8, CH)
+#define WS_ISSUE_B(CH) WS_ISSUE(xb_0, xb_1, xb_2, xb_3, xb_4, xb_5, wb0, wb1, wb2, wb3, wb4, wb5, wb6, wb7, wb8, CH)
+#define WS_STORE(XT, WT_, V0, V1, V2, V3, V4, V5, U0, U1, U2, U3, U4, U5, U6, U7, U8)                        \
+    *reinterpret_cast<u32x4*>((XT) + lds_slot) = V0;                                                         \
+    *reinterpret_cast<u32x4*>((XT) + lds_slot + 64 * PIXB) = V1;                                             \
+    *reinterpret_cast<u32x4*>((XT) + lds_slot + 128 * PIXB) = V2;                                            \
+    *reinterpret_cast<u32x4*>((XT) + lds_slot + 192 * PIXB) = V3;                                            \
+    *reinterpret_cast<u32x4*>((XT) + lds_slot + 256 * PIXB) = V4;                                            \
+    if (lt < 16) *reinterpret_cast<u32x4*>((XT) + lds_slot + 320 * PIXB) = V5;                               \
+    *reinterpret_cast<u32x4*>((WT_) + lt * 16) = U0;             *reinterpret_cast<u32x4*>((WT_) + (lt + 256) * 16) = U1;  \
+    *reinterpret_cast<u32x4*>((WT_) + (lt + 512) * 16) = U2;     *reinterpret_cast<u32x4*>((WT_) + (lt + 768) * 16) = U3;  \
+    *reinterpret_cast<u32x4*>((WT_) + (lt + 1024) * 16) = U4;    *reinterpret_cast<u32x4*>((WT_) + (lt + 1280) * 16) = U5; \
+    *reinterpret_cast<u32x4*>((WT_) + (lt + 1536) * 16) = U6;    *reinterpret_cast<u32x4*>((WT_) + (lt + 1792) * 16) = U7; \
+    *reinterpret_cast<u32x4*>((WT_) + (lt + 2048) * 16) = U8;
+#define WS_STORE_A WS_STORE(xb0, wt0, xa0, xa1, xa2, xa3, xa4, xa5, wa0, wa1, wa2, wa3, wa4, wa5, wa6, wa7, wa8)
+#define WS_STORE_B WS_STORE(xb1, wt1, xb_0, xb_1, xb_2, xb_3, xb_4, xb_5, wb0, wb1, wb2, wb3, wb4, wb5, wb6, wb7, wb8)
+        // Stage s = (local item s / nch, chunk s % nch); even stages use set A / buffers 0, odd ones set B / buffers 1.
+        // Load order: A(0) B(1) A(2) | B(3) A(4) | B(5) A(6) | ...   (kq, cq): cursor of the next even stage to issue.
+        int kq = 0, cq = 0;
+        WS_PIXELS(kq)
+        WS_ISSUE_A(cq)
+        WS_ISSUE_B(cq + 1)
+        WS_STORE_A
+        cq += 2; if (cq == nch) { cq = 0; ++kq; }
+        WS_PIXELS(kq)                                  // pix* describe the item of stages (kq, cq), (kq, cq + 1)
+        WS_ISSUE_A(cq)
+        for (int sidx = 0; sidx < nloc * nch; sidx += 2) {
+            lds_barrier();                             // even stage ready in buffers 0; buffers 1 are free
+            WS_STORE_B
+            WS_ISSUE_B(cq + 1)
+            lds_barrier();                             // odd stage ready in buffers 1; buffers 0 are free
+            WS_STORE_A
+            cq += 2; if (cq == nch) { cq = 0; ++kq; }
+            WS_PIXELS(kq)
+            WS_ISSUE_A(cq)
+        }
+#undef WS_PIX
+#undef WS_PIXELS
+#undef WS_XLD
+#undef WS_WLD
+#undef WS_ISSUE
+#undef WS_ISSUE_A
+#undef WS_ISSUE_B
+#undef WS_STORE
+#undef WS_STORE_A
+#undef WS_STORE_B
+    } else {
+        // ------------------------------------------------------------ MFMA waves
+        float4 bv[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            bv[nt] = a.bias ? *reinterpret_cast<const float4*>(a.bias + nb * BN + nt * 16 + (lane >> 4) * 4)
+                            : make_float4(0.f, 0.f, 0.f, 0.f);
+            asm volatile("" : "+v"(bv[nt].x), "+v"(bv[nt].y), "+v"(bv[nt].z), "+v"(bv[nt].w));
+        }
+        char* yp; int cy, coff;
+        if (nb * BN < a.cy1) { yp = a.y1; cy = a.cy1; coff = nb * BN; }
+        else { yp = a.y2; cy = a.cout - a.cy1; coff = nb * BN - a.cy1; }
+        const auto rsy = wave_uniform_rsrc(yp, npix * cy * TSZ);
+        const int abase0 = ((wave * 4 + 1) * 18 + (lane & 15) + 1) * PIXB + P::a_lane_off(lane);
+        int soff[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+            soff[mt] = (((wave * 4 + mt) * a.w + (lane & 15)) * cy + coff + ((lane >> 4) & 1) * 16 + (lane >> 5) * 8) * TSZ;
+        u32x4 pend[8];
+        unsigned pvo[4] = {WR_OOB, WR_OOB, WR_OOB, WR_OOB};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) pend[i] = u32x4{0u, 0u, 0u, 0u};
+#define WS_PEND_STORE(IDX)                                                                                    \
+    do {                                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        __builtin_amdgcn_raw_buffer_store_b128(pend[IDX], rsy, pvo[(IDX) >> 1], ((IDX) & 1) * 32 * TSZ, 0);     \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+    } while (0)
+        for (int k = 0; k < nloc; ++k) {
+            const int tile = ((int)blockIdx.x + k * (int)gridDim.x) / nblk;
+            const int r = tile / g.tiles_x;
+            const int x0 = (tile - r * g.tiles_x) << 4;
+            const int nn = r / g.tiles_y;
+            const int y0 = (r - nn * g.tiles_y) << 4;
+            f32x4 acc[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{bv[j].x, bv[j].y, bv[j].z, bv[j].w};
+            // first chunk pair: the previous item's results leave during its MFMA phases
+            lds_barrier();
+            P::mma_chunk_rows(acc, xb0, abase0, HWB, wt0, lane, [&](int st) {
+                if (st == 1) WS_PEND_STORE(0); else if (st == 3) WS_PEND_STORE(1);
+                else if (st == 5) WS_PEND_STORE(2); else if (st == 7) WS_PEND_STORE(3);
+            });
+            lds_barrier();
+            P::mma_chunk_rows(acc, xb1, abase0, HWB, wt1, lane, [&](int st) {
+                if (st == 1) WS_PEND_STORE(4); else if (st == 3) WS_PEND_STORE(5);
+                else if (st == 5) WS_PEND_STORE(6); else if (st == 7) WS_PEND_STORE(7);
+            });
+            for (int cp = 2; cp < nch; cp += 2) {
+                lds_barrier();
+                P::mma_chunk_rows(acc, xb0, abase0, HWB, wt0, lane, [](int) {});
+                lds_barrier();
+                P::mma_chunk_rows(acc, xb1, abase0, HWB, wt1, lane, [](int) {});
+            }
+            const int tbase = ((nn * a.h + y0) * a.w + x0) * cy * TSZ;
+            const bool xok = (lane & 15) < a.w - x0;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const bool ok = xok && wave * 4 + mt < a.h - y0;
+                pvo[mt] = ok ? (unsigned)(tbase + soff[mt]) : WR_OOB;
+#pragma unroll
+                for (int np = 0; np < 2; ++np) {
+                    union { bf16x4 h; u32x2 u; } pa, pb;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float va = acc[mt][2 * np][q], vb = acc[mt][2 * np + 1][q];
+                        if (RELU) {
+                            va = __builtin_amdgcn_fmed3f(va, 0.f, __builtin_inff());
+                            vb = __builtin_amdgcn_fmed3f(vb, 0.f, __builtin_inff());
+                        }
+                        pa.h[q] = (bf16_t)va;
+                        pb.h[q] = (bf16_t)vb;
+                    }
+                    const u32x2 s0 = __builtin_amdgcn_permlane16_swap(pa.u[0], pb.u[0], false, false);
+                    const u32x2 s1 = __builtin_amdgcn_permlane16_swap(pa.u[1], pb.u[1], false, false);
+                    pend[mt * 2 + np] = u32x4{s0[0], s1[0], s0[1], s1[1]};
+                }
+            }
+        }
+        WS_PEND_STORE(0); WS_PEND_STORE(1); WS_PEND_STORE(2); WS_PEND_STORE(3);
+        WS_PEND_STORE(4); WS_PEND_STORE(5); WS_PEND_STORE(6); WS_PEND_STORE(7);
+#undef WS_PEND_STORE
+    }
+}
+
 // ------------------------------------------------------------------ wgrad
 struct WgradArgs {
     const char* x1; const char* x2; int c1, c2;
@@ -1324,6 +1540,8 @@ int launch_fwd(ConvArgs a, void* ws, size_t ws_bytes, hipStream_t s) {
         if constexpr (sizeof(typename P::T) == 2) {
             allow_big_lds(conv3x3_fwd_wres_kernel<P, false>);
             allow_big_lds(conv3x3_fwd_wres_kernel<P, true>);
+            allow_big_lds(conv3x3_fwd_ws_kernel<P, false>);
+            allow_big_lds(conv3x3_fwd_ws_kernel<P, true>);
         }
         attr_set = true;
     }
@@ -1338,6 +1556,14 @@ int launch_fwd(ConvArgs a, void* ws, size_t ws_bytes, hipStream_t s) {
             if (a.epilogue == AD_EPI_RELU) conv3x3_fwd_wres_kernel<P, true><<<NUM_CU, WR_T, WR_LDS, s>>>(a);
             else conv3x3_fwd_wres_kernel<P, false><<<NUM_CU, WR_T, WR_LDS, s>>>(a);
             AD_LAUNCH_CHECK("conv3x3_fwd_wres");
+            return AD_OK;
+        }
+        // streamed-weights variant: any even number of chunks, at least one item per CU
+        if (halo && geo16 && nch >= 2 && nch % 2 == 0 && NUM_CU % nblk == 0 && nitems >= NUM_CU && fits &&
+            9LL * (a.c1 + a.c2) * a.cout * 2 <= WR_MAX_BYTES) {
+            if (a.epilogue == AD_EPI_RELU) conv3x3_fwd_ws_kernel<P, true><<<NUM_CU, WR_T, WR_LDS, s>>>(a);
+            else conv3x3_fwd_ws_kernel<P, false><<<NUM_CU, WR_T, WR_LDS, s>>>(a);
+            AD_LAUNCH_CHECK("conv3x3_fwd_ws");
             return AD_OK;
         }
     }

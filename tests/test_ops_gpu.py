@@ -132,7 +132,8 @@ def _window_check(y_dev, x_full, wk, b, relu, tol):
         assert err < tol, (img, y0, x0, err)
 
 
-@pytest.mark.parametrize("case", [(64, 0, 64, False), (64, 0, 64, True), (32, 32, 64, False), (64, 0, 128, False)])
+@pytest.mark.parametrize("case", [(64, 0, 64, False), (64, 0, 64, True), (32, 32, 64, False), (64, 0, 128, False),
+                                  (64, 64, 64, True), (128, 0, 128, False), (96, 160, 64, False)])   # streamed weights
 def test_conv3x3_fwd_large_launch(device, case):
     from adunet_amd import ops
     c1, c2, cout, relu = case
