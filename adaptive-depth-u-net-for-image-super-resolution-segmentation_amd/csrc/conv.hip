@@ -268,6 +268,9 @@ __device__ __forceinline__ uint4 load_w_slot(const char* wp, int kc_total, int c
     return *reinterpret_cast<const uint4*>(wp + ((size_t)(tap * kc_total + ch * 4 + kc) * cout + nb * BN + co) * 16);
 }
 
+#define AD_EPI_LN_RELU 2        // internal: ad_conv3x3_ln_relu_fwd
+#define AD_ERR_UNFUSED 1000     // internal: no fused kernel for this shape, run the two launches
+
 struct ConvArgs {
     const char* x1; const char* x2; int c1, c2;
     const char* wp; const float* bias;
@@ -277,6 +280,9 @@ struct ConvArgs {
     int ksplit;                // > 1: the channel chunks of an item are split over ksplit workgroups (tiny maps)
     float* slab;               // split-K partial sums [ksplit][n*h*w][cout] fp32
     unsigned long long* dbg;   // diagnostic builds only (-DAD_STAMP): per-workgroup phase cycle sums
+    // fused LayerNorm + ReLU epilogue (epilogue == AD_EPI_LN_RELU, cout == 64): y1 receives z, a_out the activation
+    const float* ln_gamma; const float* ln_beta; float ln_eps;
+    char* a_out; float* ln_mean; float* ln_rstd;
     Geo g;
 };
 
@@ -563,7 +569,7 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 constexpr int WR_T = 512;                      // threads: 4 MFMA waves + 4 loader waves
 constexpr int WR_XS = 6;                       // halo slots per loader thread (324 pixels x 4 parts / 256)
 constexpr int WR_XB = (324 * PIXB + 15) & ~15; // one halo buffer (31,104 B)
-constexpr size_t WR_LDS = 2 * WR_XB + 2 * WT_BYTES;
+constexpr size_t WR_LDS = 2 * WR_XB + 2 * WT_BYTES + 3 * BN * 4;   // + [gamma][beta][bias] of the fused LayerNorm epilogue
 constexpr unsigned WR_OOB = 0x80000000u;
 constexpr long long WR_MAX_BYTES = 0x7fffffffLL;
 
@@ -577,7 +583,172 @@ __device__ __forceinline__ auto wave_uniform_rsrc(const void* p, int bytes) {
                                              __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
 }
 
-template <typename P, bool RELU>
+// Sum of v over the four 16-lane groups of a wave, returned in every lane.  v_permlane16_swap(a, b) leaves rows
+// (a0,b0,a2,b2) / (a1,b1,a3,b3), v_permlane32_swap the lower / upper halves side by side, so with a = b = v two swaps
+// and two adds do the butterfly.  Written as inline asm with two distinct registers: extracting BOTH results of the
+// __builtin_amdgcn_permlane*_swap builtins as scalars is miscompiled by this hipcc (the second result aliases the first).
+__device__ __forceinline__ float sum_lane_groups(float v) {
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    float s = a + b, c = s;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(s), "+v"(c));
+    return s + c;
+}
+
+// ---- the MFMA-wave role shared by the two wave-specialised forward kernels ------------------------------------
+// EPI: 0 = bias, 1 = bias + ReLU, 2 = bias + LayerNorm(eps) + ReLU fused (Cout == 64: a pixel's 64 channels sit in
+// 16 registers x the 4 lane groups of one wave, so the statistics are 2 lane-swap steps).  EPI 2 writes the conv
+// output z, the activation a = relu(gamma * (z - mean) * rstd + beta) and mean / rstd per pixel; bias, gamma and
+// beta are read from LDS (gb: [gamma 64][beta 64][bias 64] floats) to keep the wave under 256 registers.
+// Results leave the registers during the MFMA phases of the NEXT item: packed to bf16 they wait in pend[] and one
+// 16-byte store is pinned between two tap steps, so the store queue never backs up into the MFMA issue.
+template <typename P, int EPI>
+__device__ __forceinline__ void ws_mma_role(const ConvArgs& a, const char* xb0, const char* xb1, const char* wt0,
+                                            const char* wt1, const float* gb, int wave, int lane, int nb, int nloc,
+                                            int nch) {
+    constexpr int TSZ = 2;
+    constexpr int HWB = 18 * PIXB;
+    const Geo& g = a.g;
+    const int nblk = a.cout / BN;
+    const int npix = a.n * a.h * a.w;
+    const int grp = lane >> 4;
+    float4 bv[4];
+    if (EPI != 2) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            bv[nt] = a.bias ? *reinterpret_cast<const float4*>(a.bias + nb * BN + nt * 16 + grp * 4)
+                            : make_float4(0.f, 0.f, 0.f, 0.f);
+            // consumed here, so that the wait for it is placed before the loop and not (as vmcnt(0)) inside it
+            asm volatile("" : "+v"(bv[nt].x), "+v"(bv[nt].y), "+v"(bv[nt].z), "+v"(bv[nt].w));
+        }
+    }
+    char* yp; int cy, coff;
+    if (nb * BN < a.cy1) { yp = a.y1; cy = a.cy1; coff = nb * BN; }
+    else { yp = a.y2; cy = a.cout - a.cy1; coff = nb * BN - a.cy1; }
+    const auto rsy = wave_uniform_rsrc(yp, npix * cy * TSZ);
+    const auto rsa = wave_uniform_rsrc(EPI == 2 ? a.a_out : yp, npix * cy * TSZ);
+    const auto rsm = wave_uniform_rsrc(EPI == 2 ? (const void*)a.ln_mean : (const void*)yp, npix * 4);
+    const auto rsr = wave_uniform_rsrc(EPI == 2 ? (const void*)a.ln_rstd : (const void*)yp, npix * 4);
+    const int abase0 = ((wave * 4 + 1) * 18 + (lane & 15) + 1) * PIXB + P::a_lane_off(lane);
+    int soff[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)   // after the row swap, lane group g holds channels (g&1)*16 + (g>>1)*8 .. +7 of an n-tile pair
+        soff[mt] = (((wave * 4 + mt) * a.w + (lane & 15)) * cy + coff + (grp & 1) * 16 + (grp >> 1) * 8) * TSZ;
+    constexpr int NPEND = EPI == 2 ? 16 : 8;
+    u32x4 pend[NPEND];
+    unsigned pvo[4] = {WR_OOB, WR_OOB, WR_OOB, WR_OOB};   // before the first item: out of range, stores dropped
+#pragma unroll
+    for (int i = 0; i < NPEND; ++i) pend[i] = u32x4{0u, 0u, 0u, 0u};
+#define WS_PEND_STORE(IDX, RS)                                                                                \
+    do {                                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);   /* pin the store between two tap steps (hipcc would bunch them) */ \
+        __builtin_amdgcn_raw_buffer_store_b128(pend[IDX], RS, pvo[((IDX) & 7) >> 1], ((IDX) & 1) * 32 * TSZ, 0); \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+    } while (0)
+    auto hook0 = [&](int st) {
+        if (EPI == 2) { if (st < 8) WS_PEND_STORE(st, rsy); }
+        else if ((st & 1) && st < 8) WS_PEND_STORE(st >> 1, rsy);
+    };
+    auto hook1 = [&](int st) {
+        if (EPI == 2) { if (st < 8) WS_PEND_STORE(8 + st, rsa); }
+        else if ((st & 1) && st < 8) WS_PEND_STORE(4 + (st >> 1), rsy);
+    };
+    for (int k = 0; k < nloc; ++k) {
+        const int tile = ((int)blockIdx.x + k * (int)gridDim.x) / nblk;
+        const int r = tile / g.tiles_x;
+        const int x0 = (tile - r * g.tiles_x) << 4;
+        const int nn = r / g.tiles_y;
+        const int y0 = (r - nn * g.tiles_y) << 4;
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float4 b4 = EPI == 2 ? *reinterpret_cast<const float4*>(gb + 128 + j * 16 + grp * 4) : bv[j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][j] = f32x4{b4.x, b4.y, b4.z, b4.w};
+        }
+        lds_barrier();                                  // even stage (chunk 0) ready
+        P::mma_chunk_rows(acc, xb0, abase0, HWB, wt0, lane, hook0);
+        lds_barrier();                                  // odd stage (chunk 1) ready
+        P::mma_chunk_rows(acc, xb1, abase0, HWB, wt1, lane, hook1);
+        for (int cp = 2; cp < nch; cp += 2) {
+            lds_barrier();
+            P::mma_chunk_rows(acc, xb0, abase0, HWB, wt0, lane, [](int) {});
+            lds_barrier();
+            P::mma_chunk_rows(acc, xb1, abase0, HWB, wt1, lane, [](int) {});
+        }
+        // Pack for the deferred stores.  A lane owns 4 consecutive channels (8 B) of pixel (mt, lane & 15) per n-tile;
+        // v_permlane16_swap trades the odd 16-lane rows of one n-tile with the even rows of the next, after which
+        // every lane holds 8 consecutive channels: 16-byte stores, two instructions per 128-byte NHWC row.
+        const int pixbase = (nn * a.h + y0) * a.w + x0;
+        const int tbase = pixbase * cy * TSZ;
+        const bool xok = (lane & 15) < a.w - x0;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const bool ok = xok && wave * 4 + mt < a.h - y0;
+            pvo[mt] = ok ? (unsigned)(tbase + soff[mt]) : WR_OOB;
+            float mean = 0.f, rstd = 0.f;
+            if (EPI == 2) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { const float v = acc[mt][nt][q]; s1 += v; s2 += v * v; }
+                s1 = sum_lane_groups(s1);
+                s2 = sum_lane_groups(s2);
+                mean = s1 * (1.f / 64.f);
+                rstd = rsqrtf(fmaxf(s2 * (1.f / 64.f) - mean * mean, 0.f) + a.ln_eps);
+                const unsigned so = ok && grp == 0 ? (unsigned)((pixbase + (wave * 4 + mt) * a.w + (lane & 15)) * 4) : WR_OOB;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, mean), rsm, so, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, rstd), rsr, so, 0, 0);
+            }
+#pragma unroll
+            for (int np = 0; np < 2; ++np) {
+                union { bf16x4 h; u32x2 u; } pa, pb, qa, qb;
+                float4 ga, gb4, ba, bb;
+                if (EPI == 2) {
+                    ga = *reinterpret_cast<const float4*>(gb + (2 * np) * 16 + grp * 4);
+                    gb4 = *reinterpret_cast<const float4*>(gb + (2 * np + 1) * 16 + grp * 4);
+                    ba = *reinterpret_cast<const float4*>(gb + 64 + (2 * np) * 16 + grp * 4);
+                    bb = *reinterpret_cast<const float4*>(gb + 64 + (2 * np + 1) * 16 + grp * 4);
+                }
+                const float gaa[4] = {ga.x, ga.y, ga.z, ga.w}, gba[4] = {gb4.x, gb4.y, gb4.z, gb4.w};
+                const float baa[4] = {ba.x, ba.y, ba.z, ba.w}, bba[4] = {bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float va = acc[mt][2 * np][q], vb = acc[mt][2 * np + 1][q];
+                    if (EPI == 1) {
+                        va = __builtin_amdgcn_fmed3f(va, 0.f, __builtin_inff());
+                        vb = __builtin_amdgcn_fmed3f(vb, 0.f, __builtin_inff());
+                    }
+                    pa.h[q] = (bf16_t)va;
+                    pb.h[q] = (bf16_t)vb;
+                    if (EPI == 2) {
+                        const float ya = (va - mean) * rstd * gaa[q] + baa[q], yb = (vb - mean) * rstd * gba[q] + bba[q];
+                        qa.h[q] = (bf16_t)__builtin_amdgcn_fmed3f(ya, 0.f, __builtin_inff());
+                        qb.h[q] = (bf16_t)__builtin_amdgcn_fmed3f(yb, 0.f, __builtin_inff());
+                    }
+                }
+                const u32x2 s0 = __builtin_amdgcn_permlane16_swap(pa.u[0], pb.u[0], false, false);
+                const u32x2 s1 = __builtin_amdgcn_permlane16_swap(pa.u[1], pb.u[1], false, false);
+                pend[mt * 2 + np] = u32x4{s0[0], s1[0], s0[1], s1[1]};
+                if (EPI == 2) {
+                    const u32x2 r0 = __builtin_amdgcn_permlane16_swap(qa.u[0], qb.u[0], false, false);
+                    const u32x2 r1 = __builtin_amdgcn_permlane16_swap(qa.u[1], qb.u[1], false, false);
+                    pend[(NPEND - 8) + mt * 2 + np] = u32x4{r0[0], r1[0], r0[1], r1[1]};
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) WS_PEND_STORE(i, rsy);
+    if (EPI == 2) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) WS_PEND_STORE(8 + i, rsa);
+    }
+#undef WS_PEND_STORE
+}
+
+template <typename P, int EPI>
 __global__ __launch_bounds__(WR_T, 1) void conv3x3_fwd_wres_kernel(ConvArgs a) {
     typedef typename P::T T;
     static_assert(sizeof(T) == 2, "the weights-resident kernel is the bf16 throughput path");
@@ -589,7 +760,6 @@ __global__ __launch_bounds__(WR_T, 1) void conv3x3_fwd_wres_kernel(ConvArgs a) {
     char* xb1 = xb0 + WR_XB;
     char* wt = xb1 + WR_XB;
     constexpr int TSZ = 2;
-    constexpr int HWB = 18 * PIXB;
 
     const int nblk = a.cout / BN;
     const int nitems = a.ntiles * nblk;
@@ -605,11 +775,13 @@ __global__ __launch_bounds__(WR_T, 1) void conv3x3_fwd_wres_kernel(ConvArgs a) {
         *reinterpret_cast<uint4*>(wt + s * 16) = load_w_slot(a.wp, kc_total, ch, a.cout, nb, s - ch * 9 * 4 * BN);
     }
 
-#ifdef AD_STAMP
-    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long t_last = clock64();
-    const unsigned long long t_begin = t_last;
-#endif
+    float* gb = reinterpret_cast<float*>(wt + 2 * WT_BYTES);
+    if (EPI == 2) {       // [gamma][beta][bias] of the 64 output channels; visible to the MFMA waves after this barrier
+        if (tid < 64) {
+            gb[tid] = a.ln_gamma[tid]; gb[64 + tid] = a.ln_beta[tid]; gb[128 + tid] = a.bias ? a.bias[tid] : 0.f;
+        }
+        lds_barrier();
+    }
     if (wave >= 4) {
         // ------------------------------------------------------------ loader waves
         const int lt = tid - 256;
@@ -689,106 +861,9 @@ __global__ __launch_bounds__(WR_T, 1) void conv3x3_fwd_wres_kernel(ConvArgs a) {
 #undef WR_ISSUE_B
 #undef WR_STORE
     } else {
-        // ------------------------------------------------------------ MFMA waves
-        float4 bv[4];
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            bv[nt] = a.bias ? *reinterpret_cast<const float4*>(a.bias + nb * BN + nt * 16 + (lane >> 4) * 4)
-                            : make_float4(0.f, 0.f, 0.f, 0.f);
-            // consumed here, so that the wait for it is placed before the loop and not (as vmcnt(0)) inside it
-            asm volatile("" : "+v"(bv[nt].x), "+v"(bv[nt].y), "+v"(bv[nt].z), "+v"(bv[nt].w));
-        }
-        char* yp; int cy, coff;
-        if (nb * BN < a.cy1) { yp = a.y1; cy = a.cy1; coff = nb * BN; }
-        else { yp = a.y2; cy = a.cout - a.cy1; coff = nb * BN - a.cy1; }
-        const auto rsy = wave_uniform_rsrc(yp, npix * cy * TSZ);
-        int abase[4], soff[4];
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const int ty = wave * 4 + mt, tx = lane & 15;          // tile pixel m = wave*64 + mt*16 + (lane&15)
-            abase[mt] = ((ty + 1) * 18 + tx + 1) * PIXB + P::a_lane_off(lane);
-            // after the row swap, lane group g = lane>>4 holds channels (g&1)*16 + (g>>1)*8 .. +7 of the n-tile pair
-            soff[mt] = ((ty * a.w + tx) * cy + coff + ((lane >> 4) & 1) * 16 + (lane >> 5) * 8) * TSZ;
-        }
-        // The results of item i leave the registers during the MFMA phases of item i+1: packed to bf16 they wait in
-        // pend[] and one 16-byte store is issued every other tap step, so the store queue never backs up into the
-        // MFMA issue.  Before the first item the offsets are out of range (stores dropped).
-        u32x4 pend[8];
-        unsigned pvo[4] = {WR_OOB, WR_OOB, WR_OOB, WR_OOB};
-#pragma unroll
-        for (int i = 0; i < 8; ++i) pend[i] = u32x4{0u, 0u, 0u, 0u};
-#define WR_PEND_STORE(IDX)                                                                                    \
-    do {                                                                                                      \
-        __builtin_amdgcn_sched_barrier(0);   /* pin the store between two tap steps (hipcc would bunch them) */ \
-        __builtin_amdgcn_raw_buffer_store_b128(pend[IDX], rsy, pvo[(IDX) >> 1], ((IDX) & 1) * 32 * TSZ, 0);     \
-        __builtin_amdgcn_sched_barrier(0);                                                                    \
-    } while (0)
-        for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
-            const int tile = item / nblk;
-            const int r = tile / g.tiles_x;
-            const int x0 = (tile - r * g.tiles_x) << 4;
-            const int nn = r / g.tiles_y;
-            const int y0 = (r - nn * g.tiles_y) << 4;
-            f32x4 acc[4][4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{bv[j].x, bv[j].y, bv[j].z, bv[j].w};
-            STAMP(1);
-            lds_barrier();                           // B0
-            STAMP(3);
-            P::mma_chunk_rows(acc, xb0, abase[0], HWB, wt, lane, [&](int st) {
-                if (st == 1) WR_PEND_STORE(0); else if (st == 3) WR_PEND_STORE(1);
-                else if (st == 5) WR_PEND_STORE(2); else if (st == 7) WR_PEND_STORE(3);
-            });
-            STAMP(5);
-            lds_barrier();                           // B1
-            STAMP(4);
-            P::mma_chunk_rows(acc, xb1, abase[0], HWB, wt + WT_BYTES, lane, [&](int st) {
-                if (st == 1) WR_PEND_STORE(4); else if (st == 3) WR_PEND_STORE(5);
-                else if (st == 5) WR_PEND_STORE(6); else if (st == 7) WR_PEND_STORE(7);
-            });
-            STAMP(5);
-            // Pack the accumulators for the deferred stores.  A lane owns 4 consecutive channels (8 B) of pixel
-            // (mt, lane & 15) per n-tile; v_permlane16_swap trades the odd 16-lane rows of one n-tile with the even
-            // rows of the next, after which every lane holds 8 consecutive channels: 16-byte stores, two
-            // instructions per 128-byte NHWC row instead of four.
-            const int tbase = ((nn * a.h + y0) * a.w + x0) * cy * TSZ;
-            const bool xok = (lane & 15) < a.w - x0;
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const bool ok = xok && wave * 4 + mt < a.h - y0;
-                pvo[mt] = ok ? (unsigned)(tbase + soff[mt]) : WR_OOB;
-#pragma unroll
-                for (int np = 0; np < 2; ++np) {
-                    union { bf16x4 h; u32x2 u; } pa, pb;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        float va = acc[mt][2 * np][q], vb = acc[mt][2 * np + 1][q];
-                        if (RELU) {
-                            va = __builtin_amdgcn_fmed3f(va, 0.f, __builtin_inff());
-                            vb = __builtin_amdgcn_fmed3f(vb, 0.f, __builtin_inff());
-                        }
-                        pa.h[q] = (bf16_t)va;
-                        pb.h[q] = (bf16_t)vb;
-                    }
-                    const u32x2 s0 = __builtin_amdgcn_permlane16_swap(pa.u[0], pb.u[0], false, false);
-                    const u32x2 s1 = __builtin_amdgcn_permlane16_swap(pa.u[1], pb.u[1], false, false);
-                    pend[mt * 2 + np] = u32x4{s0[0], s1[0], s0[1], s1[1]};
-                }
-            }
-            STAMP(7);
-        }
-        WR_PEND_STORE(0); WR_PEND_STORE(1); WR_PEND_STORE(2); WR_PEND_STORE(3);
-        WR_PEND_STORE(4); WR_PEND_STORE(5); WR_PEND_STORE(6); WR_PEND_STORE(7);
-#undef WR_PEND_STORE
+        ws_mma_role<P, EPI>(a, xb0, xb1, wt, wt + WT_BYTES, gb, wave, lane, nb,
+                            (nitems - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x, 2);
     }
-#ifdef AD_STAMP
-    if (tid == 0 && a.dbg) {
-        for (int i = 0; i < 8; ++i) a.dbg[blockIdx.x * 9 + i] = st[i];
-        a.dbg[blockIdx.x * 9 + 8] = clock64() - t_begin;
-    }
-#endif
 }
 
 // ------------------------------------------------------------------ forward / dgrad, wave specialised, streamed weights
@@ -797,7 +872,7 @@ __global__ __launch_bounds__(WR_T, 1) void conv3x3_fwd_wres_kernel(ConvArgs a) {
 // stage = one channel chunk, stages alternate between two [X][W] buffer pairs, one barrier per stage, loads issued
 // two stages ahead of their LDS store.  The pending output stores of an item drain during the first two stages of
 // the next one.  LDS: as above, 135.9 KB.
-template <typename P, bool RELU>
+template <typename P, int EPI>
 __global__ __launch_bounds__(WR_T, 1) void conv3x3_fwd_ws_kernel(ConvArgs a) {
     typedef typename P::T T;
     static_assert(sizeof(T) == 2, "bf16 throughput path");
@@ -810,7 +885,6 @@ __global__ __launch_bounds__(WR_T, 1) void conv3x3_fwd_ws_kernel(ConvArgs a) {
     char* wt0 = xb1 + WR_XB;
     char* wt1 = wt0 + WT_BYTES;
     constexpr int TSZ = 2;
-    constexpr int HWB = 18 * PIXB;
 
     const int nblk = a.cout / BN;
     const int nitems = a.ntiles * nblk;
@@ -820,6 +894,13 @@ __global__ __launch_bounds__(WR_T, 1) void conv3x3_fwd_ws_kernel(ConvArgs a) {
     const int nch = cin / P::CK;                    // even
     const int npix = a.n * a.h * a.w;
     const int nloc = (nitems - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // items of this workgroup (>= 1)
+    float* gb = reinterpret_cast<float*>(wt1 + WT_BYTES);
+    if (EPI == 2) {       // [gamma][beta][bias] of the 64 output channels; visible to the MFMA waves after this barrier
+        if (tid < 64) {
+            gb[tid] = a.ln_gamma[tid]; gb[64 + tid] = a.ln_beta[tid]; gb[128 + tid] = a.bias ? a.bias[tid] : 0.f;
+        }
+        lds_barrier();
+    }
 
     if (wave >= 4) {
         // ------------------------------------------------------------ loader waves
@@ -921,89 +1002,7 @@ __global__ __launch_bounds__(WR_T, 1) void conv3x3_fwd_ws_kernel(ConvArgs a) {
 #undef WS_STORE_A
 #undef WS_STORE_B
     } else {
-        // ------------------------------------------------------------ MFMA waves
-        float4 bv[4];
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            bv[nt] = a.bias ? *reinterpret_cast<const float4*>(a.bias + nb * BN + nt * 16 + (lane >> 4) * 4)
-                            : make_float4(0.f, 0.f, 0.f, 0.f);
-            asm volatile("" : "+v"(bv[nt].x), "+v"(bv[nt].y), "+v"(bv[nt].z), "+v"(bv[nt].w));
-        }
-        char* yp; int cy, coff;
-        if (nb * BN < a.cy1) { yp = a.y1; cy = a.cy1; coff = nb * BN; }
-        else { yp = a.y2; cy = a.cout - a.cy1; coff = nb * BN - a.cy1; }
-        const auto rsy = wave_uniform_rsrc(yp, npix * cy * TSZ);
-        const int abase0 = ((wave * 4 + 1) * 18 + (lane & 15) + 1) * PIXB + P::a_lane_off(lane);
-        int soff[4];
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-            soff[mt] = (((wave * 4 + mt) * a.w + (lane & 15)) * cy + coff + ((lane >> 4) & 1) * 16 + (lane >> 5) * 8) * TSZ;
-        u32x4 pend[8];
-        unsigned pvo[4] = {WR_OOB, WR_OOB, WR_OOB, WR_OOB};
-#pragma unroll
-        for (int i = 0; i < 8; ++i) pend[i] = u32x4{0u, 0u, 0u, 0u};
-#define WS_PEND_STORE(IDX)                                                                                    \
-    do {                                                                                                      \
-        __builtin_amdgcn_sched_barrier(0);                                                                    \
-        __builtin_amdgcn_raw_buffer_store_b128(pend[IDX], rsy, pvo[(IDX) >> 1], ((IDX) & 1) * 32 * TSZ, 0);     \
-        __builtin_amdgcn_sched_barrier(0);                                                                    \
-    } while (0)
-        for (int k = 0; k < nloc; ++k) {
-            const int tile = ((int)blockIdx.x + k * (int)gridDim.x) / nblk;
-            const int r = tile / g.tiles_x;
-            const int x0 = (tile - r * g.tiles_x) << 4;
-            const int nn = r / g.tiles_y;
-            const int y0 = (r - nn * g.tiles_y) << 4;
-            f32x4 acc[4][4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{bv[j].x, bv[j].y, bv[j].z, bv[j].w};
-            // first chunk pair: the previous item's results leave during its MFMA phases
-            lds_barrier();
-            P::mma_chunk_rows(acc, xb0, abase0, HWB, wt0, lane, [&](int st) {
-                if (st == 1) WS_PEND_STORE(0); else if (st == 3) WS_PEND_STORE(1);
-                else if (st == 5) WS_PEND_STORE(2); else if (st == 7) WS_PEND_STORE(3);
-            });
-            lds_barrier();
-            P::mma_chunk_rows(acc, xb1, abase0, HWB, wt1, lane, [&](int st) {
-                if (st == 1) WS_PEND_STORE(4); else if (st == 3) WS_PEND_STORE(5);
-                else if (st == 5) WS_PEND_STORE(6); else if (st == 7) WS_PEND_STORE(7);
-            });
-            for (int cp = 2; cp < nch; cp += 2) {
-                lds_barrier();
-                P::mma_chunk_rows(acc, xb0, abase0, HWB, wt0, lane, [](int) {});
-                lds_barrier();
-                P::mma_chunk_rows(acc, xb1, abase0, HWB, wt1, lane, [](int) {});
-            }
-            const int tbase = ((nn * a.h + y0) * a.w + x0) * cy * TSZ;
-            const bool xok = (lane & 15) < a.w - x0;
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const bool ok = xok && wave * 4 + mt < a.h - y0;
-                pvo[mt] = ok ? (unsigned)(tbase + soff[mt]) : WR_OOB;
-#pragma unroll
-                for (int np = 0; np < 2; ++np) {
-                    union { bf16x4 h; u32x2 u; } pa, pb;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        float va = acc[mt][2 * np][q], vb = acc[mt][2 * np + 1][q];
-                        if (RELU) {
-                            va = __builtin_amdgcn_fmed3f(va, 0.f, __builtin_inff());
-                            vb = __builtin_amdgcn_fmed3f(vb, 0.f, __builtin_inff());
-                        }
-                        pa.h[q] = (bf16_t)va;
-                        pb.h[q] = (bf16_t)vb;
-                    }
-                    const u32x2 s0 = __builtin_amdgcn_permlane16_swap(pa.u[0], pb.u[0], false, false);
-                    const u32x2 s1 = __builtin_amdgcn_permlane16_swap(pa.u[1], pb.u[1], false, false);
-                    pend[mt * 2 + np] = u32x4{s0[0], s1[0], s0[1], s1[1]};
-                }
-            }
-        }
-        WS_PEND_STORE(0); WS_PEND_STORE(1); WS_PEND_STORE(2); WS_PEND_STORE(3);
-        WS_PEND_STORE(4); WS_PEND_STORE(5); WS_PEND_STORE(6); WS_PEND_STORE(7);
-#undef WS_PEND_STORE
+        ws_mma_role<P, EPI>(a, xb0, xb1, wt0, wt1, gb, wave, lane, nb, nloc, nch);
     }
 }
 
@@ -1538,10 +1537,12 @@ int launch_fwd(ConvArgs a, void* ws, size_t ws_bytes, hipStream_t s) {
         allow_big_lds(conv3x3_fwd_kernel<P, 16, true>);
         allow_big_lds(conv3x3_fwd_kernel<P, 6, false>);
         if constexpr (sizeof(typename P::T) == 2) {
-            allow_big_lds(conv3x3_fwd_wres_kernel<P, false>);
-            allow_big_lds(conv3x3_fwd_wres_kernel<P, true>);
-            allow_big_lds(conv3x3_fwd_ws_kernel<P, false>);
-            allow_big_lds(conv3x3_fwd_ws_kernel<P, true>);
+            allow_big_lds(conv3x3_fwd_wres_kernel<P, 0>);
+            allow_big_lds(conv3x3_fwd_wres_kernel<P, 1>);
+            allow_big_lds(conv3x3_fwd_wres_kernel<P, 2>);
+            allow_big_lds(conv3x3_fwd_ws_kernel<P, 0>);
+            allow_big_lds(conv3x3_fwd_ws_kernel<P, 1>);
+            allow_big_lds(conv3x3_fwd_ws_kernel<P, 2>);
         }
         attr_set = true;
     }
@@ -1552,21 +1553,24 @@ int launch_fwd(ConvArgs a, void* ws, size_t ws_bytes, hipStream_t s) {
         const long long npix_ = (long long)a.n * a.h * a.w;
         const long long widest = a.c1 > a.c2 ? (a.c1 > a.cout ? a.c1 : a.cout) : (a.c2 > a.cout ? a.c2 : a.cout);
         const bool fits = npix_ * widest * 2 <= WR_MAX_BYTES;      // 32-bit buffer offsets
-        if (halo && geo16 && nch == 2 && NUM_CU % nblk == 0 && nitems >= 4 * NUM_CU && fits) {
-            if (a.epilogue == AD_EPI_RELU) conv3x3_fwd_wres_kernel<P, true><<<NUM_CU, WR_T, WR_LDS, s>>>(a);
-            else conv3x3_fwd_wres_kernel<P, false><<<NUM_CU, WR_T, WR_LDS, s>>>(a);
-            AD_LAUNCH_CHECK("conv3x3_fwd_wres");
-            return AD_OK;
-        }
-        // streamed-weights variant: any even number of chunks, at least one item per CU
-        if (halo && geo16 && nch >= 2 && nch % 2 == 0 && NUM_CU % nblk == 0 && nitems >= NUM_CU && fits &&
-            9LL * (a.c1 + a.c2) * a.cout * 2 <= WR_MAX_BYTES) {
-            if (a.epilogue == AD_EPI_RELU) conv3x3_fwd_ws_kernel<P, true><<<NUM_CU, WR_T, WR_LDS, s>>>(a);
-            else conv3x3_fwd_ws_kernel<P, false><<<NUM_CU, WR_T, WR_LDS, s>>>(a);
-            AD_LAUNCH_CHECK("conv3x3_fwd_ws");
-            return AD_OK;
-        }
+#define AD_WS_LAUNCH(KERN, NAME)                                                                     \
+    {                                                                                                \
+        if (a.epilogue == AD_EPI_LN_RELU) KERN<P, 2><<<NUM_CU, WR_T, WR_LDS, s>>>(a);                \
+        else if (a.epilogue == AD_EPI_RELU) KERN<P, 1><<<NUM_CU, WR_T, WR_LDS, s>>>(a);              \
+        else KERN<P, 0><<<NUM_CU, WR_T, WR_LDS, s>>>(a);                                             \
+        AD_LAUNCH_CHECK(NAME);                                                                       \
+        return AD_OK;                                                                                \
     }
+        const bool ln_ok = a.epilogue != AD_EPI_LN_RELU || nblk == 1;     // the fused LayerNorm needs all channels in a wave
+        if (halo && geo16 && nch == 2 && NUM_CU % nblk == 0 && nitems >= 4 * NUM_CU && fits && ln_ok)
+            AD_WS_LAUNCH(conv3x3_fwd_wres_kernel, "conv3x3_fwd_wres")
+        // streamed-weights variant: any even number of chunks, at least one item per CU
+        if (halo && geo16 && nch >= 2 && nch % 2 == 0 && NUM_CU % nblk == 0 && nitems >= NUM_CU && fits && ln_ok &&
+            9LL * (a.c1 + a.c2) * a.cout * 2 <= WR_MAX_BYTES)
+            AD_WS_LAUNCH(conv3x3_fwd_ws_kernel, "conv3x3_fwd_ws")
+#undef AD_WS_LAUNCH
+    }
+    if (a.epilogue == AD_EPI_LN_RELU) return AD_ERR_UNFUSED;     // the caller runs conv + LayerNorm as two launches
     size_t lds = 2 * (size_t)g.NPHP * 4 + 2 * BN * 4 + (((size_t)g.NPH * PIXB + 15) & ~15) + (size_t)FWS * FT * 16;
     if (lds > 160 * 1024) return ad_set_error(AD_ERR_ARG, "conv3x3_fwd: LDS %zu too large", lds);
     const int per_cu = lds <= 80 * 1024 ? 2 : 1;
@@ -1704,10 +1708,45 @@ extern "C" int ad_conv3x3_fwd(const void* x1, int c1, const void* x2, int c2, co
     a.n = n; a.h = h; a.w = w; a.cout = cout; a.epilogue = epilogue;
     a.dbg = g_dbg;
     a.ksplit = 1; a.slab = nullptr;
+    a.ln_gamma = a.ln_beta = nullptr; a.ln_eps = 0.f; a.a_out = nullptr; a.ln_mean = a.ln_rstd = nullptr;
     pick_geo(n, h, w, &a.g);
     a.ntiles = a.g.tiles_x * a.g.tiles_y * a.g.tiles_i;
     hipStream_t s = (hipStream_t)stream;
     return dtype == AD_BF16 ? launch_fwd<PolBF16>(a, ws, ws_bytes, s) : launch_fwd<PolF32>(a, ws, ws_bytes, s);
+}
+
+extern "C" int ad_layernorm_relu_fwd(const void* z, const float* gamma, const float* beta, void* y, float* mean,
+                                     float* rstd, int64_t npix, int c, float eps, int relu, int dtype, void* stream);
+
+extern "C" int ad_conv3x3_ln_relu_fwd(const void* x1, int c1, const void* x2, int c2, const void* w_packed,
+                                      const float* bias, const float* gamma, const float* beta, float eps, void* z,
+                                      void* act, float* mean, float* rstd, int n, int h, int w, int cout, void* ws,
+                                      size_t ws_bytes, int dtype, void* stream) {
+    AD_REQUIRE(dtype == AD_BF16 || dtype == AD_F32, "ad_conv3x3_ln_relu_fwd: bad dtype %d", dtype);
+    AD_REQUIRE(gamma && beta && z && act && mean && rstd, "ad_conv3x3_ln_relu_fwd: NULL LayerNorm operand");
+    const int gran = ad_cin_granule(dtype);
+    AD_REQUIRE(n > 0 && h > 0 && w > 0 && (long)n * h * w < (1L << 31), "ad_conv3x3_ln_relu_fwd: bad shape n=%d h=%d w=%d", n, h, w);
+    AD_REQUIRE(x1 && c1 > 0 && c1 % gran == 0 && (x2 == nullptr) == (c2 == 0) && c2 % gran == 0,
+               "ad_conv3x3_ln_relu_fwd: bad input channels c1=%d c2=%d", c1, c2);
+    AD_REQUIRE(cout > 0 && cout % BN == 0, "ad_conv3x3_ln_relu_fwd: cout=%d must be a multiple of %d", cout, BN);
+    ConvArgs a;
+    a.x1 = (const char*)x1; a.x2 = (const char*)x2; a.c1 = c1; a.c2 = c2;
+    a.wp = (const char*)w_packed; a.bias = bias;
+    a.y1 = (char*)z; a.y2 = nullptr; a.cy1 = cout;
+    a.n = n; a.h = h; a.w = w; a.cout = cout; a.epilogue = AD_EPI_LN_RELU;
+    a.dbg = g_dbg;
+    a.ksplit = 1; a.slab = nullptr;
+    a.ln_gamma = gamma; a.ln_beta = beta; a.ln_eps = eps;
+    a.a_out = (char*)act; a.ln_mean = mean; a.ln_rstd = rstd;
+    pick_geo(n, h, w, &a.g);
+    a.ntiles = a.g.tiles_x * a.g.tiles_y * a.g.tiles_i;
+    hipStream_t s = (hipStream_t)stream;
+    int rc = dtype == AD_BF16 ? launch_fwd<PolBF16>(a, ws, ws_bytes, s) : launch_fwd<PolF32>(a, ws, ws_bytes, s);
+    if (rc != AD_ERR_UNFUSED) return rc;
+    a.epilogue = AD_EPI_NONE;
+    rc = dtype == AD_BF16 ? launch_fwd<PolBF16>(a, ws, ws_bytes, s) : launch_fwd<PolF32>(a, ws, ws_bytes, s);
+    if (rc) return rc;
+    return ad_layernorm_relu_fwd(z, gamma, beta, act, mean, rstd, (int64_t)n * h * w, cout, eps, 1, dtype, stream);
 }
 
 extern "C" size_t ad_conv3x3_fwd_ws_bytes(int n, int h, int w, int cin, int cout, int dtype) {

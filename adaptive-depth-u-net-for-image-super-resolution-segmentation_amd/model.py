@@ -366,8 +366,8 @@ class Model:
             kind = step[0]
             if kind == "block":
                 for cs in step[1]:
-                    z = ops.conv3x3_fwd(cur1, cur2, self._packs[cs.name][0], self.param(cs.name + "/bias"), cs.cout)
-                    a, mean, rstd = ops.layernorm_relu_fwd(z, self.param(cs.ln + "/gamma"), self.param(cs.ln + "/beta"))
+                    z, a, mean, rstd = ops.conv3x3_ln_relu_fwd(cur1, cur2, self._packs[cs.name][0], self.param(cs.name + "/bias"),
+                                                               self.param(cs.ln + "/gamma"), self.param(cs.ln + "/beta"), cs.cout)
                     if keep:
                         tape.append(("cla", cs, cur1, cur2, z, mean, rstd, step[2]))
                     cur1, cur2 = a, None

@@ -5,6 +5,8 @@ csrc/.  All activations are NHWC, dtype torch.bfloat16 (throughput) or torch.flo
 """
 from __future__ import annotations
 
+import os
+
 from typing import Optional, Tuple
 
 import numpy as np
@@ -155,6 +157,31 @@ def conv3x3_fwd(x1: torch.Tensor, x2: Optional[torch.Tensor], w_packed: torch.Te
                                  ws.nbytes if ws else 0, dt(x1.dtype), _stream()),
               "ad_conv3x3_fwd")
     return (y1, y2) if split is not None else y1
+
+
+def conv3x3_ln_relu_fwd(x1: torch.Tensor, x2: Optional[torch.Tensor], w_packed: torch.Tensor, bias: Optional[torch.Tensor],
+                        gamma: torch.Tensor, beta: torch.Tensor, cout: int, eps: float = LN_EPS):
+    """conv_block's Conv2D -> LayerNormalization -> ReLU.  Returns (z, act, mean, rstd): z is the conv output kept for
+    the backward pass.  One launch where the library has the fused epilogue (cout == 64, large bf16 launches), else
+    the library runs the convolution and the LayerNorm kernel back to back."""
+    if os.environ.get("ADUNET_LN_TWO_LAUNCHES"):      # A/B switch for measurements
+        z = conv3x3_fwd(x1, x2, w_packed, bias, cout)
+        return (z,) + layernorm_relu_fwd(z, gamma, beta, eps=eps)
+    n, h, w, c1 = x1.shape
+    c2 = x2.shape[-1] if x2 is not None else 0
+    z = torch.empty((n, h, w, cout), dtype=x1.dtype, device=x1.device)
+    act = torch.empty_like(z)
+    mean = torch.empty(n * h * w, dtype=torch.float32, device=x1.device)
+    rstd = torch.empty(n * h * w, dtype=torch.float32, device=x1.device)
+    lib = _lib.load()
+    need = lib.ad_conv3x3_fwd_ws_bytes(n, h, w, c1 + c2, cout, dt(x1.dtype))
+    ws = _conv_workspace(x1.device, need) if need else None
+    with _timed("conv3x3_fwd"):       # the LayerNorm work (fused or not) is booked on the convolution
+        check(lib.ad_conv3x3_ln_relu_fwd(_p(x1), c1, _p(x2), c2, _p(w_packed), _p(bias), _p(gamma), _p(beta), eps,
+                                         _p(z), _p(act), _p(mean), _p(rstd), n, h, w, cout,
+                                         ws.ptr if ws else None, ws.nbytes if ws else 0, dt(x1.dtype), _stream()),
+              "ad_conv3x3_ln_relu_fwd")
+    return z, act, mean, rstd
 
 
 def conv3x3_wgrad(x1: torch.Tensor, x2: Optional[torch.Tensor], dz: torch.Tensor, dw_out: torch.Tensor, cin_real: int,

@@ -249,9 +249,9 @@ class SegModel(Model):
 
     def _block_fwd(self, blk, x1, x2, training, tape, keep):
         for cs, nn in blk:
-            z = ops.conv3x3_fwd(x1, x2, self._packs[cs.name][0], self.param(cs.name + "/bias"), cs.cout)
             g, b = self.param(nn + "/gamma"), self.param(nn + "/beta")
             if self.norm == "bn":
+                z = ops.conv3x3_fwd(x1, x2, self._packs[cs.name][0], self.param(cs.name + "/bias"), cs.cout)
                 if training:
                     a, mean, rstd = ops.batchnorm_relu_fwd_train(z, g, b, self._state(nn + "/moving_mean"),
                                                                  self._state(nn + "/moving_variance"), self._ws)
@@ -259,7 +259,8 @@ class SegModel(Model):
                     a = ops.batchnorm_relu_fwd_infer(z, g, b, self._state(nn + "/moving_mean"), self._state(nn + "/moving_variance"))
                     mean = rstd = None
             else:
-                a, mean, rstd = ops.layernorm_relu_fwd(z, g, b)
+                z, a, mean, rstd = ops.conv3x3_ln_relu_fwd(x1, x2, self._packs[cs.name][0], self.param(cs.name + "/bias"),
+                                                           g, b, cs.cout)
             if keep:
                 tape.append(("cna", cs, nn, x1, x2, z, mean, rstd))
             x1, x2 = a, None

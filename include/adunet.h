@@ -93,6 +93,18 @@ int ad_conv3x3_wgrad(const void* x1, int c1, const void* x2, int c2, const void*
                      int n, int h, int w, int cout,
                      void* ws, size_t ws_bytes, int dtype, void* stream);
 
+/* conv_block's Conv2D -> LayerNormalization -> ReLU (train_adaptive_unet.py:202-204, 207-209) in one call:
+ * z = conv(x) + bias (saved for the backward pass), act = relu(gamma * (z - mean) * rstd + beta), mean / rstd [npix]
+ * as ad_layernorm_relu_fwd writes them.  For cout == 64 on bf16 launches large enough for the wave-specialised
+ * kernels the LayerNorm runs in the convolution's epilogue, on the fp32 accumulators (one launch, z is never
+ * re-read); every other shape runs ad_conv3x3_fwd followed by ad_layernorm_relu_fwd.  Workspace as ad_conv3x3_fwd. */
+int ad_conv3x3_ln_relu_fwd(const void* x1, int c1, const void* x2, int c2,
+                           const void* w_packed, const float* bias,
+                           const float* gamma, const float* beta, float eps,
+                           void* z, void* act, float* mean, float* rstd,
+                           int n, int h, int w, int cout,
+                           void* ws, size_t ws_bytes, int dtype, void* stream);
+
 /* ---------------------------------------------------- LayerNorm (+ ReLU) -- */
 
 /* L.LayerNormalization(axis=-1) (eps 1e-3) followed by L.Activation("relu"):

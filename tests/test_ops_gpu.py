@@ -207,6 +207,49 @@ def test_conv3x3_wgrad_large_launch(device, ws, case):
     assert torch.equal(dw, dw2), "wgrad must be bitwise deterministic"
 
 
+@pytest.mark.parametrize("case", [(F32, 2, 20, 20, 32, 0, 64), (BF16, 2, 20, 20, 64, 64, 64), (BF16, 3, 8, 8, 64, 0, 128),
+                                  (BF16, 5, 250, 246, 64, 0, 64), (BF16, 5, 250, 246, 64, 64, 64)])
+def test_conv3x3_ln_relu_fwd(device, case):
+    """Conv2D -> LayerNormalization -> ReLU in one call: the two-launch route for small / wide shapes, the fused
+    epilogue of the wave-specialised kernels for the last two (cout 64, 1280 tiles): oracle on windows."""
+    from adunet_amd import ops
+    dtype, n, h, w, c1, c2, cout = case
+    rng = np.random.default_rng(21)
+    cin = c1 + c2
+    x = rnd(rng.standard_normal((n, h, w, cin)), dtype)
+    wk = rnd(rng.standard_normal((3, 3, cin, cout)) * 0.1, dtype)
+    b = rng.standard_normal(cout).astype(np.float32).astype(np.float64)
+    gam = rng.uniform(0.5, 1.5, cout).astype(np.float32).astype(np.float64)
+    bet = (0.3 * rng.standard_normal(cout)).astype(np.float32).astype(np.float64)
+    x1 = to_dev(x[..., :c1], dtype, device)
+    x2 = to_dev(x[..., c1:], dtype, device) if c2 else None
+    wf, _ = ops.conv3x3_pack(torch.tensor(wk, dtype=F32, device=device), cin, dtype, want_dgrad=False)
+    f = lambda v: torch.tensor(v, dtype=F32, device=device)
+    z, act, mean, rstd = ops.conv3x3_ln_relu_fwd(x1, x2, wf, f(b), f(gam), f(bet), cout)
+    tol = TOL[dtype]
+    big = h > 64
+    wins = [(i, y0, x0, min(y0 + WIN, h), min(x0 + WIN, w)) for i, y0, x0 in (WINDOWS if big else [])] or \
+           [(i, 0, 0, h, w) for i in range(n)]
+    for img, y0, x0, y1, x1e in wins:
+        zw = ref.conv2d_same_fwd(x[img:img + 1, y0:y1, x0:x1e], wk, b)[0]
+        aw, cache = ref.layernorm_fwd(zw, gam, bet)
+        aw = np.maximum(aw, 0)
+        ys = slice(0 if y0 == 0 else 1, (y1 - y0) if y1 == h else (y1 - y0 - 1))
+        xs = slice(0 if x0 == 0 else 1, (x1e - x0) if x1e == w else (x1e - x0 - 1))
+        gz = z[img, y0:y1, x0:x1e].to(torch.float64).cpu().numpy()[ys, xs]
+        ga = act[img, y0:y1, x0:x1e].to(torch.float64).cpu().numpy()[ys, xs]
+        assert np.abs(gz - zw[ys, xs]).max() / np.abs(zw).max() < tol
+        assert np.abs(ga - aw[ys, xs]).max() / np.abs(aw).max() < 2 * tol
+        mu = zw.mean(-1)
+        rs = 1.0 / np.sqrt(zw.var(-1) + 1e-3)
+        gm = mean.view(n, h, w)[img, y0:y1, x0:x1e].to(torch.float64).cpu().numpy()[ys, xs]
+        gr = rstd.view(n, h, w)[img, y0:y1, x0:x1e].to(torch.float64).cpu().numpy()[ys, xs]
+        assert np.abs(gm - mu[ys, xs]).max() < tol * np.abs(zw).max()
+        assert np.abs(gr / rs[ys, xs] - 1).max() < (1e-4 if dtype == F32 else 2e-2)
+    z2, act2, mean2, rstd2 = ops.conv3x3_ln_relu_fwd(x1, x2, wf, f(b), f(gam), f(bet), cout)
+    assert torch.equal(z, z2) and torch.equal(act, act2) and torch.equal(mean, mean2) and torch.equal(rstd, rstd2)
+
+
 @pytest.mark.parametrize("dtype", [F32, BF16])
 def test_first_layer_padded_channels(device, ws, dtype):
     """3-channel network input zero-padded to the conv granule; wgrad writes only the 3 real rows."""
