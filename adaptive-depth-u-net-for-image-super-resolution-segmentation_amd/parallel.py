@@ -54,6 +54,7 @@ class DataParallel:
             model._repack()
         model.grad_ready = self._ready
         model.grad_sync = self._sync
+        model._dp = self
 
     def _launch(self, lo: int, hi: int):
         g = self.model.G[lo:hi]
@@ -76,8 +77,11 @@ class DataParallel:
         while self._next < len(self.buckets):
             self._launch(*self.buckets[self._next])
             self._next += 1
+        self.wait_all()
+        self._next = 0
+        return 1.0 / self.world
+
+    def wait_all(self):
         for w in self._works:
             w.wait()           # the compute stream waits for the collective; the host does not block
         self._works.clear()
-        self._next = 0
-        return 1.0 / self.world

@@ -150,10 +150,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # One process: the ~190 launches of a step are captured once in a hipGraph and replayed (no tracing compiler:
-    # the same hand-written kernels, minus the Python launch loop).  Data parallel: eager, so that the RCCL
-    # bucket all-reduces overlap backward on their own stream.
-    graphed = not use_dist and not args.eager
+    # The ~190 launches of a step are captured once in hipGraphs and replayed (no tracing compiler: the same
+    # hand-written kernels, minus the Python launch loop).  Data parallel: the capture is cut where a gradient bucket
+    # becomes final and the RCCL all-reduces are launched eagerly between the segments on their own stream.
+    graphed = not args.eager
     step_fn = model.make_graphed_train_step(lr_img, hr_img) if graphed else model.train_on_batch
     for _ in range(args.warmup):
         step_fn(lr_img, hr_img)
@@ -221,6 +221,9 @@ def main():
             line["cpu_baseline"] = cpu_baseline(scale, depth, patch)
         print(json.dumps(line), flush=True)
     if use_dist:
+        del step_fn, model            # graphs and side streams go before the communicator they reference
+        torch.cuda.synchronize()
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -172,3 +172,48 @@ def test_graph_replayed_step_equals_eager_step(device):
     assert results[0][2] == results[1][2] == 5
     assert results[0][0] == results[1][0]
     assert torch.equal(results[0][1], results[1][1])
+
+
+def test_segmented_graph_step_under_data_parallel(device):
+    """DataParallel (world size 1 on RCCL): the step is captured as several graph segments with the bucket all-reduces
+    launched eagerly in between; it must follow the eager data-parallel trajectory bit for bit."""
+    import os
+    import torch.distributed as dist
+    from adunet_amd.model import Adam, build_losses_and_metrics, build_super_resolution_unet
+    from adunet_amd.parallel import DataParallel
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29741")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+    try:
+        rng = np.random.default_rng(22)
+        batches = [synth(rng, 3, 32) for _ in range(4)]
+        results = []
+        for graphed in (False, True):
+            model, _ = build_super_resolution_unet(0.5, depth_override=2, input_size=32, dtype=torch.bfloat16, device=device)
+            loss, metrics = build_losses_and_metrics("charbonnier")
+            model.compile(optimizer=Adam(1e-3), loss=loss, metrics=metrics)
+            model._require_device()
+            model.set_weights(model.initial_weights(np.random.default_rng(1), head_uniform=0.05))
+            dp = DataParallel(model, bucket_bytes=1 << 20)          # several buckets -> several graph segments
+            assert len(dp.buckets) >= 3
+            if graphed:
+                step = model.make_graphed_train_step(*batches[0])
+                assert len(step.segments) >= 3
+                assert sum(len(b) for _, b, _ in step.segments) == len(dp.buckets)
+            else:
+                step = model.train_on_batch
+                step(*batches[0]); step(*batches[0])
+            losses = [float(step(*b)[0]) for b in batches[1:]]
+            results.append((losses, model.P.clone(), model.optimizer.iterations))
+        assert results[0][2] == results[1][2] == 5
+        assert results[0][0] == results[1][0]
+        assert torch.equal(results[0][1], results[1][1])
+    finally:
+        # released before the process group goes away: graphs and side streams reference the communicator's work
+        del results
+        if created:
+            torch.cuda.synchronize()
+            dist.barrier()
