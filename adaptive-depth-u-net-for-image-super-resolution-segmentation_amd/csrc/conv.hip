@@ -1011,6 +1011,7 @@ struct WgradArgs {
     const char* x1; const char* x2; int c1, c2;
     const char* dz;
     float* ws;
+    float* dw; int cin_real;   // nsplit == 1: the kernel writes dw_hwio itself, there is nothing to reduce
     int n, h, w, cout;
     int ntiles, tiles_per_split, ncib, ncob;
     Geo g;
@@ -1227,6 +1228,7 @@ __global__ __launch_bounds__(256, XS <= 6 ? 2 : 1) void conv3x3_wgrad_kernel(Wgr
 
 #undef WG_ISSUE
     float* slab = a.ws + ((size_t)(split * a.ncib + cib) * a.ncob + cob) * (9 * P::CK * BN);
+    const bool direct = gridDim.x == 1 && a.dw != nullptr;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
@@ -1235,7 +1237,12 @@ __global__ __launch_bounds__(256, XS <= 6 ? 2 : 1) void conv3x3_wgrad_kernel(Wgr
             for (int r = 0; r < 4; ++r) {
                 int ci, co;
                 WP::coords(wave, lane, j, r, &ci, &co);
-                slab[(tap * P::CK + ci) * BN + co] = acc[tap][j][r];
+                if (direct) {
+                    if (cib * P::CK + ci < a.cin_real)
+                        a.dw[((size_t)tap * a.cin_real + cib * P::CK + ci) * a.cout + cob * BN + co] = acc[tap][j][r];
+                } else {
+                    slab[(tap * P::CK + ci) * BN + co] = acc[tap][j][r];
+                }
             }
 }
 
@@ -1618,6 +1625,9 @@ static void plan_wgrad(int n, int h, int w, int c1, int c2, int cout, int dtype,
     int want = ((p->specialised ? 1 : 2) * NUM_CU) / (p->ncib * p->ncob);   // workgroups per CU in total
     if (want < 1) want = 1;
     if (want > p->ntiles) want = p->ntiles;
+    // tiny maps (<= 4 tiles): the channel blocks alone fill the chip when there are >= 128 of them; one split lets the
+    // kernel write dw itself instead of round-tripping 4 x |dw| through the slab reduce
+    if (!p->specialised && p->ntiles <= 4 && p->ncib * p->ncob >= NUM_CU / 2) want = 1;
     p->tiles_per_split = (p->ntiles + want - 1) / want;
     p->nsplit = (p->ntiles + p->tiles_per_split - 1) / p->tiles_per_split;
     p->ws_bytes = (size_t)p->nsplit * p->ncib * p->ncob * 9 * p->ck * BN * sizeof(float);
@@ -1787,9 +1797,11 @@ extern "C" int ad_conv3x3_wgrad(const void* x1, int c1, const void* x2, int c2, 
     a.n = n; a.h = h; a.w = w; a.cout = cout;
     a.ntiles = p.ntiles; a.tiles_per_split = p.tiles_per_split; a.ncib = p.ncib; a.ncob = p.ncob;
     a.g = p.g;
+    const bool direct = p.nsplit == 1 && !p.specialised;
+    a.dw = direct ? dw_hwio : nullptr; a.cin_real = cin_real;
     hipStream_t s = (hipStream_t)stream;
     int rc = dtype == AD_BF16 ? launch_wgrad<PolBF16>(a, p, s) : launch_wgrad<PolF32>(a, p, s);
-    if (rc) return rc;
+    if (rc || direct) return rc;
     int total = 9 * cin_real * cout;
     wgrad_reduce_kernel<<<(total + 63) / 64, 256, 0, s>>>((const float*)ws, dw_hwio, p.nsplit, p.ncib, p.ncob, p.ck,
                                                          cin_real, cout);
