@@ -1527,6 +1527,25 @@ static void allow_big_lds(K kern) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
+// Which wave-specialised bf16 forward kernel takes a launch: 0 = none (generic kernel), 1 = weights resident
+// (Cin = 64, >= 4 items per CU), 2 = streamed weights (even number of 32-channel chunks, >= 1 item per CU).
+// Both need 16x16 tiles, 256 % (cout / 64) == 0 and tensors below 2 GiB (32-bit buffer offsets); the fused
+// LayerNorm epilogue additionally needs cout == 64 (all channels of a pixel inside one wave).
+static int fwd_ws_kind(int n, int h, int w, int c1, int c2, int cout, bool ln) {
+    Geo g;
+    pick_geo(n, h, w, &g);
+    const bool geo16 = g.lti == 0 && g.lth == 4 && g.ltw == 4 && g.ph && g.pw;
+    const int nblk = cout / BN, nch = (c1 + c2) / PolBF16::CK;
+    const long long nitems = (long long)g.tiles_x * g.tiles_y * g.tiles_i * nblk;
+    const long long npix = (long long)n * h * w;
+    const long long widest = c1 > c2 ? (c1 > cout ? c1 : cout) : (c2 > cout ? c2 : cout);
+    const bool fits = npix * widest * 2 <= WR_MAX_BYTES && 9LL * (c1 + c2) * cout * 2 <= WR_MAX_BYTES;
+    if (!geo16 || nblk == 0 || NUM_CU % nblk != 0 || !fits || (ln && nblk != 1)) return 0;
+    if (nch == 2 && nitems >= 4 * NUM_CU) return 1;
+    if (nch >= 2 && nch % 2 == 0 && nitems >= NUM_CU) return 2;
+    return 0;
+}
+
 template <typename P>
 int launch_fwd(ConvArgs a, void* ws, size_t ws_bytes, hipStream_t s) {
     Geo& g = a.g;
@@ -1554,12 +1573,8 @@ int launch_fwd(ConvArgs a, void* ws, size_t ws_bytes, hipStream_t s) {
         attr_set = true;
     }
     if constexpr (sizeof(typename P::T) == 2) {
-        // weights-resident kernel: two channel chunks, 16x16 tiles, enough tiles to give every CU several items
-        const bool geo16 = g.lti == 0 && g.lth == 4 && g.ltw == 4;
         a.ksplit = 1; a.slab = nullptr;
-        const long long npix_ = (long long)a.n * a.h * a.w;
-        const long long widest = a.c1 > a.c2 ? (a.c1 > a.cout ? a.c1 : a.cout) : (a.c2 > a.cout ? a.c2 : a.cout);
-        const bool fits = npix_ * widest * 2 <= WR_MAX_BYTES;      // 32-bit buffer offsets
+        const int kind = fwd_ws_kind(a.n, a.h, a.w, a.c1, a.c2, a.cout, a.epilogue == AD_EPI_LN_RELU);
 #define AD_WS_LAUNCH(KERN, NAME)                                                                     \
     {                                                                                                \
         if (a.epilogue == AD_EPI_LN_RELU) KERN<P, 2><<<NUM_CU, WR_T, WR_LDS, s>>>(a);                \
@@ -1568,13 +1583,8 @@ int launch_fwd(ConvArgs a, void* ws, size_t ws_bytes, hipStream_t s) {
         AD_LAUNCH_CHECK(NAME);                                                                       \
         return AD_OK;                                                                                \
     }
-        const bool ln_ok = a.epilogue != AD_EPI_LN_RELU || nblk == 1;     // the fused LayerNorm needs all channels in a wave
-        if (halo && geo16 && nch == 2 && NUM_CU % nblk == 0 && nitems >= 4 * NUM_CU && fits && ln_ok)
-            AD_WS_LAUNCH(conv3x3_fwd_wres_kernel, "conv3x3_fwd_wres")
-        // streamed-weights variant: any even number of chunks, at least one item per CU
-        if (halo && geo16 && nch >= 2 && nch % 2 == 0 && NUM_CU % nblk == 0 && nitems >= NUM_CU && fits && ln_ok &&
-            9LL * (a.c1 + a.c2) * a.cout * 2 <= WR_MAX_BYTES)
-            AD_WS_LAUNCH(conv3x3_fwd_ws_kernel, "conv3x3_fwd_ws")
+        if (kind == 1) AD_WS_LAUNCH(conv3x3_fwd_wres_kernel, "conv3x3_fwd_wres")
+        if (kind == 2) AD_WS_LAUNCH(conv3x3_fwd_ws_kernel, "conv3x3_fwd_ws")
 #undef AD_WS_LAUNCH
     }
     if (a.epilogue == AD_EPI_LN_RELU) return AD_ERR_UNFUSED;     // the caller runs conv + LayerNorm as two launches
@@ -1727,6 +1737,11 @@ extern "C" int ad_conv3x3_fwd(const void* x1, int c1, const void* x2, int c2, co
 
 extern "C" int ad_layernorm_relu_fwd(const void* z, const float* gamma, const float* beta, void* y, float* mean,
                                      float* rstd, int64_t npix, int c, float eps, int relu, int dtype, void* stream);
+
+extern "C" int ad_conv3x3_ln_relu_is_fused(int n, int h, int w, int c1, int c2, int cout, int dtype) {
+    if (dtype != AD_BF16 || n <= 0 || h <= 0 || w <= 0 || c1 <= 0 || c2 < 0 || cout <= 0 || cout % BN) return 0;
+    return fwd_ws_kind(n, h, w, c1, c2, cout, true) != 0;
+}
 
 extern "C" int ad_conv3x3_ln_relu_fwd(const void* x1, int c1, const void* x2, int c2, const void* w_packed,
                                       const float* bias, const float* gamma, const float* beta, float eps, void* z,

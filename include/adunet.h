@@ -98,6 +98,7 @@ int ad_conv3x3_wgrad(const void* x1, int c1, const void* x2, int c2, const void*
  * as ad_layernorm_relu_fwd writes them.  For cout == 64 on bf16 launches large enough for the wave-specialised
  * kernels the LayerNorm runs in the convolution's epilogue, on the fp32 accumulators (one launch, z is never
  * re-read); every other shape runs ad_conv3x3_fwd followed by ad_layernorm_relu_fwd.  Workspace as ad_conv3x3_fwd. */
+int ad_conv3x3_ln_relu_is_fused(int n, int h, int w, int c1, int c2, int cout, int dtype);   /* 1: one launch */
 int ad_conv3x3_ln_relu_fwd(const void* x1, int c1, const void* x2, int c2,
                            const void* w_packed, const float* bias,
                            const float* gamma, const float* beta, float eps,

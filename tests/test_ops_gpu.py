@@ -226,6 +226,20 @@ def test_conv3x3_ln_relu_fwd(device, case):
     wf, _ = ops.conv3x3_pack(torch.tensor(wk, dtype=F32, device=device), cin, dtype, want_dgrad=False)
     f = lambda v: torch.tensor(v, dtype=F32, device=device)
     z, act, mean, rstd = ops.conv3x3_ln_relu_fwd(x1, x2, wf, f(b), f(gam), f(bet), cout)
+    from adunet_amd import _lib
+    lib = _lib.load()
+    assert bool(lib.ad_conv3x3_ln_relu_is_fused(n, h, w, c1, c2, cout, ops.dt(dtype))) == (h > 64)
+    if h <= 64:      # the library's own two-launch route behind the same entry point gives the same bits
+        zz, aa = torch.empty_like(z), torch.empty_like(z)
+        mm, rr = torch.empty_like(mean), torch.empty_like(rstd)
+        bb, gg, be = f(b), f(gam), f(bet)
+        need = lib.ad_conv3x3_fwd_ws_bytes(n, h, w, c1 + c2, cout, ops.dt(dtype))     # split-K scratch, as ops passes it
+        wsb = torch.empty(max(need, 1), dtype=torch.uint8, device=device)
+        _lib.check(lib.ad_conv3x3_ln_relu_fwd(x1.data_ptr(), c1, x2.data_ptr() if c2 else None, c2, wf.data_ptr(), bb.data_ptr(),
+                                              gg.data_ptr(), be.data_ptr(), 1e-3, zz.data_ptr(), aa.data_ptr(), mm.data_ptr(),
+                                              rr.data_ptr(), n, h, w, cout, wsb.data_ptr(), need, ops.dt(dtype),
+                                              torch.cuda.current_stream().cuda_stream), "ad_conv3x3_ln_relu_fwd")
+        assert torch.equal(zz, z) and torch.equal(aa, act) and torch.equal(mm, mean) and torch.equal(rr, rstd)
     tol = TOL[dtype]
     big = h > 64
     wins = [(i, y0, x0, min(y0 + WIN, h), min(x0 + WIN, w)) for i, y0, x0 in (WINDOWS if big else [])] or \
