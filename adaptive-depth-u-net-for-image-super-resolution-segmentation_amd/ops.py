@@ -47,12 +47,20 @@ class KernelTimer:
     def __init__(self):
         self.records = {}
 
-    def add(self, name, e0, e1):
-        self.records.setdefault(name, []).append((e0, e1))
+    def add(self, name, e0, e1, work=0.0, nbytes=0.0):
+        self.records.setdefault(name, []).append((e0, e1, work, nbytes))
 
     def summary(self):
         """name -> (launches, total_ms); call after torch.cuda.synchronize()."""
-        return {k: (len(v), sum(a.elapsed_time(b) for a, b in v)) for k, v in self.records.items()}
+        return {k: (len(v), sum(r[0].elapsed_time(r[1]) for r in v)) for k, v in self.records.items()}
+
+    def work(self, name) -> float:
+        """Sum of the work figures (FLOPs as launched, padded channels included) the wrappers attached to `name`."""
+        return sum(r[2] for r in self.records.get(name, []))
+
+    def nbytes(self, name) -> float:
+        """Sum of the algorithmic bytes (each operand tensor once) the wrappers attached to `name`."""
+        return sum(r[3] for r in self.records.get(name, []))
 
 
 _timer: Optional[KernelTimer] = None
@@ -64,8 +72,10 @@ def set_timer(t: Optional[KernelTimer]):
 
 
 class _timed:
-    def __init__(self, name):
+    def __init__(self, name, work=0.0, nbytes=0.0):
         self.name = name
+        self.work = work
+        self.nbytes = nbytes
 
     def __enter__(self):
         if _timer is not None:
@@ -76,7 +86,7 @@ class _timed:
         if _timer is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
-            _timer.add(self.name, self.e0, e1)
+            _timer.add(self.name, self.e0, e1, self.work, self.nbytes)
         return False
 
 
@@ -151,7 +161,7 @@ def conv3x3_fwd(x1: torch.Tensor, x2: Optional[torch.Tensor], w_packed: torch.Te
     lib = _lib.load()
     need = lib.ad_conv3x3_fwd_ws_bytes(n, h, w, c1 + c2, cout, dt(x1.dtype))
     ws = _conv_workspace(x1.device, need) if need else None
-    with _timed("conv3x3_fwd"):
+    with _timed("conv3x3_fwd", 2.0 * n * h * w * 9 * (c1 + c2) * cout, float(n * h * w * (c1 + c2 + cout) * x1.element_size())):
         check(lib.ad_conv3x3_fwd(_p(x1), c1, _p(x2), c2, _p(w_packed), _p(bias), _p(y1), cy1, _p(y2),
                                  n, h, w, cout, EPI_RELU if relu else EPI_NONE, ws.ptr if ws else None,
                                  ws.nbytes if ws else 0, dt(x1.dtype), _stream()),
@@ -179,7 +189,7 @@ def conv3x3_ln_relu_fwd(x1: torch.Tensor, x2: Optional[torch.Tensor], w_packed: 
     lib = _lib.load()
     need = lib.ad_conv3x3_fwd_ws_bytes(n, h, w, c1 + c2, cout, dt(x1.dtype))
     ws = _conv_workspace(x1.device, need) if need else None
-    with _timed("conv3x3_fwd"):       # the LayerNorm work (fused or not) is booked on the convolution
+    with _timed("conv3x3_ln_relu_fwd", 2.0 * n * h * w * 9 * (c1 + c2) * cout):   # fused launches, own family
         check(lib.ad_conv3x3_ln_relu_fwd(_p(x1), c1, _p(x2), c2, _p(w_packed), _p(bias), _p(gamma), _p(beta), eps,
                                          _p(z), _p(act), _p(mean), _p(rstd), n, h, w, cout,
                                          ws.ptr if ws else None, ws.nbytes if ws else 0, dt(x1.dtype), _stream()),

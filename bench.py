@@ -51,18 +51,6 @@ def synth_batch(rank, n, p, device):
     return torch.from_numpy(lr).to(device), torch.from_numpy(hr).to(device)
 
 
-def conv_bytes_per_image(model, elem=2):
-    """Algorithmic HBM bytes of the forward/dgrad conv launches per image: every 3x3 conv reads its input once and
-    writes its output once in each direction (weights are noise at these sizes); the first conv has no dgrad."""
-    total = 0.0
-    for i, cs in enumerate(model.convs.values()):
-        if cs.k != 3:
-            continue
-        b = float(cs.hw * cs.hw * (max(cs.cin, 16) + cs.cout) * elem)
-        total += b if i == 0 else 2.0 * b
-    return total
-
-
 def pmc_traffic(workload, dtype, batch):
     """HBM bytes per launch of the conv3x3_fwd family from the committed rocprofv3 PMC passes (profiles/README.md);
     None when the run is not the configuration those passes were taken on."""
@@ -184,10 +172,14 @@ def main():
         fwd, first = conv_flops_per_image(model)
         f_step = 3.0 * fwd - first
         summ = timer.summary()
-        # dominant kernel family: the forward convs and the dgrads (same kernels on the rotated weight pack)
+        # dominant kernel family: the forward convs and the dgrads (same kernels on the rotated weight pack) that run
+        # WITHOUT the fused LayerNorm epilogue; the five fused launches are their own timer family.  FLOPs are the
+        # algorithmic ones: what the wrappers launched minus the zero-padded channels of the first conv (3 -> 32).
         n_launch, ms = summ["conv3x3_fwd"]
-        flops_kernel = (2.0 * fwd - first) * batch * timed_steps         # algorithmic FLOPs through that kernel
+        padded_first = first * (model._cin_pad(next(iter(model.convs.values()))) / 3.0 - 1.0) * batch * timed_steps
+        flops_kernel = timer.work("conv3x3_fwd") - padded_first
         achieved = flops_kernel / (ms * 1e-3) / 1e12
+        fused = summ.get("conv3x3_ln_relu_fwd", (0, 0.0))
         total_ms = sum(v[1] for v in summ.values())
         if args.breakdown:
             print(f"{'op family':<22}{'launches/step':>14}{'ms/step':>10}{'share':>8}", file=sys.stderr)
@@ -206,13 +198,13 @@ def main():
                        "final_psnr": float(last_psnr)},
             "roofline": {"bound": "mfma",
                          "kernel": "forward-conv / dgrad family: conv3x3_fwd_wres_kernel, conv3x3_fwd_ws_kernel, "
-                                   "conv3x3_fwd_kernel (+ splitk_finalize_kernel); the LayerNorm fused into five of "
-                                   "the launches is timed with them but not counted as FLOPs",
+                                   "conv3x3_fwd_kernel (+ splitk_finalize_kernel), launches without the fused "
+                                   "LayerNorm epilogue",
+                         "fused_ln_launches_per_step": fused[0] / timed_steps, "fused_ln_ms_per_step": fused[1] / timed_steps,
                          "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_TFLOPS,
                          "traffic": pmc_traffic(args.workload, args.dtype, batch),
-                         "algorithmic_bytes_per_launch": conv_bytes_per_image(model, 2 if args.dtype == "bf16" else 4)
-                         * batch * timed_steps / n_launch,
+                         "algorithmic_bytes_per_launch": timer.nbytes("conv3x3_fwd") / n_launch,
                          "launches_per_step": n_launch / timed_steps, "avg_launch_ms": ms / n_launch,
                          "timing": ("HIP events around every launch of %d eager steps run right after the graph-replayed "
                                     "timed region" % timed_steps) if graphed else "HIP events inside the timed region",

@@ -15,13 +15,17 @@ import json
 import re
 import sys
 
-FAMILIES = {       # kernel-name prefix -> op family used by bench.py's roofline
-    "conv3x3_fwd_wres_kernel": "conv3x3_fwd", "conv3x3_fwd_kernel": "conv3x3_fwd", "splitk_finalize_kernel": "conv3x3_fwd",
-    "conv3x3_wgrad_kernel": "conv3x3_wgrad", "wgrad_reduce_kernel": "conv3x3_wgrad",
+FAMILIES = {       # kernel name -> op family used by bench.py's roofline ("_ln": launches with the fused LayerNorm epilogue)
+    "conv3x3_fwd_wres_kernel": "conv3x3_fwd", "conv3x3_fwd_ws_kernel": "conv3x3_fwd", "conv3x3_fwd_kernel": "conv3x3_fwd",
+    "splitk_finalize_kernel": "conv3x3_fwd",
+    "conv3x3_fwd_wres_kernel_ln": "conv3x3_ln_relu_fwd", "conv3x3_fwd_ws_kernel_ln": "conv3x3_ln_relu_fwd",
+    "conv3x3_wgrad_kernel": "conv3x3_wgrad", "conv3x3_wgrad_ws_kernel": "conv3x3_wgrad", "wgrad_reduce_kernel": "conv3x3_wgrad",
 }
 
 
 def short(name):
+    if re.search(r"conv3x3_fwd_w(res|s)_kernel", name) and ("Li2EEE" in name or re.search(r", 2>", name)):
+        return re.search(r"conv3x3_fwd_w(?:res|s)_kernel", name).group(0) + "_ln"
     name = re.sub(r"^void ", "", name).replace("(anonymous namespace)::", "")
     m = re.match(r"_ZN12_GLOBAL__N_1\d+([a-z0-9_]+?_kernel)", name)
     if m:
