@@ -14,9 +14,14 @@
 // of one pixel, so the epilogue writes 8/16-byte pieces of NHWC rows (and per-pixel reductions over
 // channels stay inside 4 registers x 4 lane groups).
 //
-// Both kernels are persistent (grid ~ 2 workgroups per CU, strided over work items) and software
-// pipelined through registers: the global loads of the next (tile, channel chunk) are issued before
-// the MFMA phase of the current one and written to LDS after it, so HBM/L2 latency hides under compute.
+// Kernel variants (all persistent, software pipelined through registers):
+//   conv3x3_fwd_wres_kernel   bf16, 16x16 tiles, Cin = 64: weights resident in LDS, 4 MFMA + 4 loader waves
+//   conv3x3_fwd_ws_kernel     bf16, 16x16 tiles, Cin = 64 k: weights streamed with the halo, same organisation
+//   conv3x3_fwd_kernel        every other shape (tiny maps, fp32): 256 threads, split-K when there are few tiles
+//   conv3x3_wgrad_ws_kernel   bf16, 16x16 tiles, Cin multiple of 64: 4 MFMA + 4 loader waves
+//   conv3x3_wgrad_kernel      every other shape
+// The wave-specialised variants use buffer loads / stores with out-of-range offsets for the zero padding and the
+// ragged tile edges, which keeps every s_waitcnt vmcnt exact (see the comments above them).
 //
 // Tile geometry is a runtime (TI images x TH x TW) split of 256 pixels so that tiny feature maps
 // (4x4, 2x2, 1x1 at the bottleneck) pack many images into one tile instead of wasting the MFMA.
