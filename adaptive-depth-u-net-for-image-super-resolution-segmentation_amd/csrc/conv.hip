@@ -600,6 +600,25 @@ __device__ __forceinline__ float sum_lane_groups(float v) {
     return s + c;
 }
 
+// XCD-aware work order of the wave-specialised forward kernels.  Workgroup b runs on XCD b % 8 (round-robin dispatch
+// over the 8 XCDs, each with its own L2).  In every round the 32 workgroups of one XCD take 32 / nblk CONSECUTIVE
+// tiles (for a 256-wide map and nblk = 1: two full tile rows) and, when cout has several 64-channel blocks, all the
+// blocks of a tile: the halo rows / columns that neighbouring tiles share and the input a tile's output blocks share
+// are then fetched into ONE L2 instead of up to eight.  tile(k) = slot0 + k * stride for the k-th item of a workgroup.
+struct WsOrder {
+    int nb, slot0, stride, nloc;
+};
+__device__ __forceinline__ WsOrder ws_order(int ntiles, int nblk) {
+    const int b = blockIdx.x, xcd = b & 7, r = b >> 3;
+    const int tpx = (NUM_CU / 8) / nblk;            // tiles per XCD and round (nblk divides 32: launcher)
+    WsOrder o;
+    o.nb = r % nblk;
+    o.slot0 = xcd * tpx + r / nblk;
+    o.stride = 8 * tpx;
+    o.nloc = o.slot0 < ntiles ? (ntiles - o.slot0 + o.stride - 1) / o.stride : 0;
+    return o;
+}
+
 // ---- the MFMA-wave role shared by the two wave-specialised forward kernels ------------------------------------
 // EPI: 0 = bias, 1 = bias + ReLU, 2 = bias + LayerNorm(eps) + ReLU fused (Cout == 64: a pixel's 64 channels sit in
 // 16 registers x the 4 lane groups of one wave, so the statistics are 2 lane-swap steps).  EPI 2 writes the conv
@@ -609,8 +628,9 @@ __device__ __forceinline__ float sum_lane_groups(float v) {
 // 16-byte store is pinned between two tap steps, so the store queue never backs up into the MFMA issue.
 template <typename P, int EPI>
 __device__ __forceinline__ void ws_mma_role(const ConvArgs& a, const char* xb0, const char* xb1, const char* wt0,
-                                            const char* wt1, const float* gb, int wave, int lane, int nb, int nloc,
+                                            const char* wt1, const float* gb, int wave, int lane, const WsOrder& o,
                                             int nch) {
+    const int nb = o.nb, nloc = o.nloc;
     constexpr int TSZ = 2;
     constexpr int HWB = 18 * PIXB;
     const Geo& g = a.g;
@@ -659,7 +679,7 @@ __device__ __forceinline__ void ws_mma_role(const ConvArgs& a, const char* xb0, 
         else if ((st & 1) && st < 8) WS_PEND_STORE(4 + (st >> 1), rsy);
     };
     for (int k = 0; k < nloc; ++k) {
-        const int tile = ((int)blockIdx.x + k * (int)gridDim.x) / nblk;
+        const int tile = o.slot0 + k * o.stride;
         const int r = tile / g.tiles_x;
         const int x0 = (tile - r * g.tiles_x) << 4;
         const int nn = r / g.tiles_y;
@@ -767,8 +787,8 @@ __global__ __launch_bounds__(WR_T, 1) void conv3x3_fwd_wres_kernel(ConvArgs a) {
     constexpr int TSZ = 2;
 
     const int nblk = a.cout / BN;
-    const int nitems = a.ntiles * nblk;
-    const int nb = blockIdx.x % nblk;               // gridDim.x is a multiple of nblk: fixed for this workgroup
+    const WsOrder o = ws_order(a.ntiles, nblk);
+    const int nb = o.nb;                            // one 64-channel output block per workgroup for the whole launch
     const int kc_total = (a.c1 + a.c2) / P::KV;
     const int npix = a.n * a.h * a.w;
 
@@ -813,9 +833,9 @@ __global__ __launch_bounds__(WR_T, 1) void conv3x3_fwd_wres_kernel(ConvArgs a) {
         const bool ok_ = (unsigned)y_ < (unsigned)a.h && (unsigned)x_ < (unsigned)a.w;           \
         pix##I = ok_ ? ((NN) * a.h + y_) * a.w + x_ : -1;                                        \
     }
-#define WR_PIXELS(ITEM)                                                                          \
+#define WR_PIXELS(K)                                                                             \
     {                                                                                            \
-        const int tile_ = min((ITEM), nitems - 1) / nblk;   /* past the end: re-fetch the last tile, loads stay unconditional */ \
+        const int tile_ = o.slot0 + min((K), o.nloc - 1) * o.stride;   /* past the end: re-fetch the last tile, loads stay unconditional */ \
         const int r_ = tile_ / g.tiles_x;                                                        \
         const int x0_ = (tile_ - r_ * g.tiles_x) << 4;                                           \
         const int nn_ = r_ / g.tiles_y;                                                          \
@@ -843,20 +863,20 @@ __global__ __launch_bounds__(WR_T, 1) void conv3x3_fwd_wres_kernel(ConvArgs a) {
     if (lt < 16) *reinterpret_cast<u32x4*>((XT) + lds_slot + 320 * PIXB) = V5;
 
         // load order (the vmcnt arithmetic depends on it): A(0) B(0) A(1) | B(1) A(2) | B(2) A(3) | ...
-        int item = blockIdx.x;
-        WR_PIXELS(item)
+        int k = 0;
+        WR_PIXELS(k)
         WR_ISSUE_A
         WR_ISSUE_B
         WR_STORE(xb0, xa0, xa1, xa2, xa3, xa4, xa5)
-        WR_PIXELS(item + (int)gridDim.x)            // pix* now describe item + 1 until B(item + 1) has been issued
+        WR_PIXELS(k + 1)                             // pix* now describe item k + 1 until B(k + 1) has been issued
         WR_ISSUE_A
-        for (; item < nitems; item += gridDim.x) {
+        for (; k < o.nloc; ++k) {
             lds_barrier();                           // B0: X0 = chunk 0 of this item is complete; X1 is free
             WR_STORE(xb1, xb_0, xb_1, xb_2, xb_3, xb_4, xb_5)
             WR_ISSUE_B                               // chunk 1 of the next item
             lds_barrier();                           // B1: X1 complete; X0 is free
             WR_STORE(xb0, xa0, xa1, xa2, xa3, xa4, xa5)
-            WR_PIXELS(item + 2 * (int)gridDim.x)
+            WR_PIXELS(k + 2)
             WR_ISSUE_A                               // chunk 0 of the item after next
         }
 #undef WR_PIX
@@ -866,8 +886,7 @@ __global__ __launch_bounds__(WR_T, 1) void conv3x3_fwd_wres_kernel(ConvArgs a) {
 #undef WR_ISSUE_B
 #undef WR_STORE
     } else {
-        ws_mma_role<P, EPI>(a, xb0, xb1, wt, wt + WT_BYTES, gb, wave, lane, nb,
-                            (nitems - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x, 2);
+        ws_mma_role<P, EPI>(a, xb0, xb1, wt, wt + WT_BYTES, gb, wave, lane, o, 2);
     }
 }
 
@@ -892,13 +911,13 @@ __global__ __launch_bounds__(WR_T, 1) void conv3x3_fwd_ws_kernel(ConvArgs a) {
     constexpr int TSZ = 2;
 
     const int nblk = a.cout / BN;
-    const int nitems = a.ntiles * nblk;
-    const int nb = blockIdx.x % nblk;               // gridDim.x is a multiple of nblk: fixed for this workgroup
+    const WsOrder o = ws_order(a.ntiles, nblk);
+    const int nb = o.nb;                            // one 64-channel output block per workgroup for the whole launch
     const int cin = a.c1 + a.c2;
     const int kc_total = cin / P::KV;
     const int nch = cin / P::CK;                    // even
     const int npix = a.n * a.h * a.w;
-    const int nloc = (nitems - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // items of this workgroup (>= 1)
+    const int nloc = o.nloc;                        // items of this workgroup (>= 1)
     float* gb = reinterpret_cast<float*>(wt1 + WT_BYTES);
     if (EPI == 2) {       // [gamma][beta][bias] of the 64 output channels; visible to the MFMA waves after this barrier
         if (tid < 64) {
@@ -935,7 +954,7 @@ __global__ __launch_bounds__(WR_T, 1) void conv3x3_fwd_ws_kernel(ConvArgs a) {
         // stage cursor of the next issue: local item k (clamped to the last one), chunk ch
 #define WS_PIXELS(K)                                                                             \
     {                                                                                            \
-        const int tile_ = ((int)blockIdx.x + min((K), nloc - 1) * (int)gridDim.x) / nblk;        \
+        const int tile_ = o.slot0 + min((K), nloc - 1) * o.stride;                               \
         const int r_ = tile_ / g.tiles_x;                                                        \
         const int x0_ = (tile_ - r_ * g.tiles_x) << 4;                                           \
         const int nn_ = r_ / g.tiles_y;                                                          \
@@ -1007,7 +1026,7 @@ __global__ __launch_bounds__(WR_T, 1) void conv3x3_fwd_ws_kernel(ConvArgs a) {
 #undef WS_STORE_A
 #undef WS_STORE_B
     } else {
-        ws_mma_role<P, EPI>(a, xb0, xb1, wt0, wt1, gb, wave, lane, nb, nloc, nch);
+        ws_mma_role<P, EPI>(a, xb0, xb1, wt0, wt1, gb, wave, lane, o, nch);
     }
 }
 
@@ -1545,7 +1564,7 @@ static int fwd_ws_kind(int n, int h, int w, int c1, int c2, int cout, bool ln) {
     const long long npix = (long long)n * h * w;
     const long long widest = c1 > c2 ? (c1 > cout ? c1 : cout) : (c2 > cout ? c2 : cout);
     const bool fits = npix * widest * 2 <= WR_MAX_BYTES && 9LL * (c1 + c2) * cout * 2 <= WR_MAX_BYTES;
-    if (!geo16 || nblk == 0 || NUM_CU % nblk != 0 || !fits || (ln && nblk != 1)) return 0;
+    if (!geo16 || nblk == 0 || (NUM_CU / 8) % nblk != 0 || !fits || (ln && nblk != 1)) return 0;
     if (nch == 2 && nitems >= 4 * NUM_CU) return 1;
     if (nch >= 2 && nch % 2 == 0 && nitems >= NUM_CU) return 2;
     return 0;
