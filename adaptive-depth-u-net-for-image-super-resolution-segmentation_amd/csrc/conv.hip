@@ -619,6 +619,80 @@ __device__ __forceinline__ WsOrder ws_order(int ntiles, int nblk) {
     return o;
 }
 
+// Packs one 256-pixel x 64-channel accumulator tile of an MFMA wave set for its stores (and, EPI 2, applies the fused
+// LayerNorm + ReLU).  A lane owns 4 consecutive channels (8 B) of pixel (mt, lane & 15) per n-tile; v_permlane16_swap
+// trades the odd 16-lane rows of one n-tile with the even rows of the next, after which every lane holds 8 consecutive
+// channels: 16-byte stores, two instructions per 128-byte NHWC row.  pend[0..7]: z (or relu(z), EPI 1) pieces
+// (mt, n-tile pair), pend[8..15]: activation pieces (EPI 2); pvo[mt]: byte offset of the piece, out of range past the
+// image edge.  mean / rstd are stored here (lane group 0).
+template <int EPI, typename RS>
+__device__ __forceinline__ void ws_pack_tile(const f32x4 (&acc)[4][4], const float* gb, float eps, int wave, int lane,
+                                             int img_h, int img_w, int nn, int y0, int x0, int cy, const int (&soff)[4],
+                                             RS rsm, RS rsr, u32x4 (&pend)[EPI == 2 ? 16 : 8], unsigned (&pvo)[4]) {
+    constexpr int TSZ = 2;
+    constexpr int NPEND = EPI == 2 ? 16 : 8;
+    const int grp = lane >> 4;
+    const int pixbase = (nn * img_h + y0) * img_w + x0;
+    const int tbase = pixbase * cy * TSZ;
+    const bool xok = (lane & 15) < img_w - x0;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const bool ok = xok && wave * 4 + mt < img_h - y0;
+        pvo[mt] = ok ? (unsigned)(tbase + soff[mt]) : WR_OOB;
+        float mean = 0.f, rstd = 0.f;
+        if (EPI == 2) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const float v = acc[mt][nt][q]; s1 += v; s2 += v * v; }
+            s1 = sum_lane_groups(s1);
+            s2 = sum_lane_groups(s2);
+            mean = s1 * (1.f / 64.f);
+            rstd = rsqrtf(fmaxf(s2 * (1.f / 64.f) - mean * mean, 0.f) + eps);
+            const unsigned so = ok && grp == 0 ? (unsigned)((pixbase + (wave * 4 + mt) * img_w + (lane & 15)) * 4) : WR_OOB;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, mean), rsm, so, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, rstd), rsr, so, 0, 0);
+        }
+#pragma unroll
+        for (int np = 0; np < 2; ++np) {
+            union { bf16x4 h; u32x2 u; } pa, pb, qa, qb;
+            float4 ga, gb4, ba, bb;
+            if (EPI == 2) {
+                ga = *reinterpret_cast<const float4*>(gb + (2 * np) * 16 + grp * 4);
+                gb4 = *reinterpret_cast<const float4*>(gb + (2 * np + 1) * 16 + grp * 4);
+                ba = *reinterpret_cast<const float4*>(gb + 64 + (2 * np) * 16 + grp * 4);
+                bb = *reinterpret_cast<const float4*>(gb + 64 + (2 * np + 1) * 16 + grp * 4);
+            }
+            const float gaa[4] = {ga.x, ga.y, ga.z, ga.w}, gba[4] = {gb4.x, gb4.y, gb4.z, gb4.w};
+            const float baa[4] = {ba.x, ba.y, ba.z, ba.w}, bba[4] = {bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float va = acc[mt][2 * np][q], vb = acc[mt][2 * np + 1][q];
+                if (EPI == 1) {
+                    va = __builtin_amdgcn_fmed3f(va, 0.f, __builtin_inff());
+                    vb = __builtin_amdgcn_fmed3f(vb, 0.f, __builtin_inff());
+                }
+                pa.h[q] = (bf16_t)va;
+                pb.h[q] = (bf16_t)vb;
+                if (EPI == 2) {
+                    const float ya = (va - mean) * rstd * gaa[q] + baa[q], yb = (vb - mean) * rstd * gba[q] + bba[q];
+                    qa.h[q] = (bf16_t)__builtin_amdgcn_fmed3f(ya, 0.f, __builtin_inff());
+                    qb.h[q] = (bf16_t)__builtin_amdgcn_fmed3f(yb, 0.f, __builtin_inff());
+                }
+            }
+            const u32x2 s0 = __builtin_amdgcn_permlane16_swap(pa.u[0], pb.u[0], false, false);
+            const u32x2 s1 = __builtin_amdgcn_permlane16_swap(pa.u[1], pb.u[1], false, false);
+            pend[mt * 2 + np] = u32x4{s0[0], s1[0], s0[1], s1[1]};
+            if (EPI == 2) {
+                const u32x2 r0 = __builtin_amdgcn_permlane16_swap(qa.u[0], qb.u[0], false, false);
+                const u32x2 r1 = __builtin_amdgcn_permlane16_swap(qa.u[1], qb.u[1], false, false);
+                pend[(NPEND - 8) + mt * 2 + np] = u32x4{r0[0], r1[0], r0[1], r1[1]};
+            }
+        }
+    }
+}
+
 // ---- the MFMA-wave role shared by the two wave-specialised forward kernels ------------------------------------
 // EPI: 0 = bias, 1 = bias + ReLU, 2 = bias + LayerNorm(eps) + ReLU fused (Cout == 64: a pixel's 64 channels sit in
 // 16 registers x the 4 lane groups of one wave, so the statistics are 2 lane-swap steps).  EPI 2 writes the conv
@@ -701,68 +775,7 @@ __device__ __forceinline__ void ws_mma_role(const ConvArgs& a, const char* xb0, 
             lds_barrier();
             P::mma_chunk_rows(acc, xb1, abase0, HWB, wt1, lane, [](int) {});
         }
-        // Pack for the deferred stores.  A lane owns 4 consecutive channels (8 B) of pixel (mt, lane & 15) per n-tile;
-        // v_permlane16_swap trades the odd 16-lane rows of one n-tile with the even rows of the next, after which
-        // every lane holds 8 consecutive channels: 16-byte stores, two instructions per 128-byte NHWC row.
-        const int pixbase = (nn * a.h + y0) * a.w + x0;
-        const int tbase = pixbase * cy * TSZ;
-        const bool xok = (lane & 15) < a.w - x0;
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const bool ok = xok && wave * 4 + mt < a.h - y0;
-            pvo[mt] = ok ? (unsigned)(tbase + soff[mt]) : WR_OOB;
-            float mean = 0.f, rstd = 0.f;
-            if (EPI == 2) {
-                float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) { const float v = acc[mt][nt][q]; s1 += v; s2 += v * v; }
-                s1 = sum_lane_groups(s1);
-                s2 = sum_lane_groups(s2);
-                mean = s1 * (1.f / 64.f);
-                rstd = rsqrtf(fmaxf(s2 * (1.f / 64.f) - mean * mean, 0.f) + a.ln_eps);
-                const unsigned so = ok && grp == 0 ? (unsigned)((pixbase + (wave * 4 + mt) * a.w + (lane & 15)) * 4) : WR_OOB;
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, mean), rsm, so, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, rstd), rsr, so, 0, 0);
-            }
-#pragma unroll
-            for (int np = 0; np < 2; ++np) {
-                union { bf16x4 h; u32x2 u; } pa, pb, qa, qb;
-                float4 ga, gb4, ba, bb;
-                if (EPI == 2) {
-                    ga = *reinterpret_cast<const float4*>(gb + (2 * np) * 16 + grp * 4);
-                    gb4 = *reinterpret_cast<const float4*>(gb + (2 * np + 1) * 16 + grp * 4);
-                    ba = *reinterpret_cast<const float4*>(gb + 64 + (2 * np) * 16 + grp * 4);
-                    bb = *reinterpret_cast<const float4*>(gb + 64 + (2 * np + 1) * 16 + grp * 4);
-                }
-                const float gaa[4] = {ga.x, ga.y, ga.z, ga.w}, gba[4] = {gb4.x, gb4.y, gb4.z, gb4.w};
-                const float baa[4] = {ba.x, ba.y, ba.z, ba.w}, bba[4] = {bb.x, bb.y, bb.z, bb.w};
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float va = acc[mt][2 * np][q], vb = acc[mt][2 * np + 1][q];
-                    if (EPI == 1) {
-                        va = __builtin_amdgcn_fmed3f(va, 0.f, __builtin_inff());
-                        vb = __builtin_amdgcn_fmed3f(vb, 0.f, __builtin_inff());
-                    }
-                    pa.h[q] = (bf16_t)va;
-                    pb.h[q] = (bf16_t)vb;
-                    if (EPI == 2) {
-                        const float ya = (va - mean) * rstd * gaa[q] + baa[q], yb = (vb - mean) * rstd * gba[q] + bba[q];
-                        qa.h[q] = (bf16_t)__builtin_amdgcn_fmed3f(ya, 0.f, __builtin_inff());
-                        qb.h[q] = (bf16_t)__builtin_amdgcn_fmed3f(yb, 0.f, __builtin_inff());
-                    }
-                }
-                const u32x2 s0 = __builtin_amdgcn_permlane16_swap(pa.u[0], pb.u[0], false, false);
-                const u32x2 s1 = __builtin_amdgcn_permlane16_swap(pa.u[1], pb.u[1], false, false);
-                pend[mt * 2 + np] = u32x4{s0[0], s1[0], s0[1], s1[1]};
-                if (EPI == 2) {
-                    const u32x2 r0 = __builtin_amdgcn_permlane16_swap(qa.u[0], qb.u[0], false, false);
-                    const u32x2 r1 = __builtin_amdgcn_permlane16_swap(qa.u[1], qb.u[1], false, false);
-                    pend[(NPEND - 8) + mt * 2 + np] = u32x4{r0[0], r1[0], r0[1], r1[1]};
-                }
-            }
-        }
+        ws_pack_tile<EPI>(acc, gb, a.ln_eps, wave, lane, a.h, a.w, nn, y0, x0, cy, soff, rsm, rsr, pend, pvo);
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) WS_PEND_STORE(i, rsy);
