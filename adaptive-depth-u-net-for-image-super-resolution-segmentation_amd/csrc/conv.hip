@@ -1501,6 +1501,229 @@ __global__ __launch_bounds__(W2_T, 1) void conv3x3_wgrad_ws_kernel(WgradArgs a) 
     }
 }
 
+// ------------------------------------------------------------------ first layer: 3 input channels (bf16)
+// The network's first conv has Cin = 3.  As an implicit GEMM over 9 taps x 32 zero-padded channels it wastes 90 % of
+// its MFMA work and needs a 32-channel padded copy of the input.  Here K is the 27 real (tap, channel) products
+// padded to ONE 32-deep MFMA step, k = tap * 3 + ch: the halo tile of the raw fp32 input (18 x 18 x 3) is staged in
+// LDS as bf16 and every lane gathers the 8 K-values of its pixel; the 64 x 32 weights live in registers (read from
+// the fp32 HWIO master weights, no pack).  Forward writes z and a = relu(LayerNorm(z)) (the fused epilogue of the
+// wave-specialised kernels); wgrad contracts the same patches against dz with the transposed LDS read.  Both are
+// pure streams: 12 B/pixel in, 128 B/pixel out (forward) or in (wgrad).
+struct C3Args {
+    const float* x;            // [N, H, W, 3] fp32
+    const float* w;            // [27, 64] fp32 (HWIO flattened), forward
+    const float* bias; const float* gamma; const float* beta; float eps;
+    char* z; char* act; float* mean; float* rstd;      // forward outputs
+    const char* dz; float* ws;                         // wgrad: dz [N, H, W, 64] bf16, slabs [grid][27][64] fp32
+    int n, h, w_img, tiles_x, tiles_y, ntiles;
+};
+constexpr int C3_T = 256;
+constexpr int C3_HALO = 18 * 18 * 3;          // elements of one halo tile
+constexpr int C3_HB = 1984;                   // bytes of one bf16 halo buffer (972 * 2, padded)
+
+// element e of the halo tile = (row e / 54, col (e % 54) / 3, channel e % 3); four per thread (972 of 1024 used)
+struct C3Halo {
+    int dy[4], dx[4], ch[4];
+};
+__device__ __forceinline__ C3Halo c3_halo_setup(int tid) {
+    C3Halo hsl;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = tid + C3_T * i;
+        const int r = e / 54, rem = e - r * 54;
+        hsl.dy[i] = e < C3_HALO ? r : 1 << 20;       // far outside every image: loads zeros, never stored
+        hsl.dx[i] = rem / 3;
+        hsl.ch[i] = rem - (rem / 3) * 3;
+    }
+    return hsl;
+}
+#define C3_LOAD_HALO(V, RSX, NN, Y0, X0)                                                                  \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                       \
+        const int y_ = (Y0) - 1 + hsl.dy[i], x_ = (X0) - 1 + hsl.dx[i];                                   \
+        const bool ok_ = (unsigned)y_ < (unsigned)a.h && (unsigned)x_ < (unsigned)a.w_img;                \
+        V[i] = __builtin_amdgcn_raw_buffer_load_b32(                                                      \
+            RSX, ok_ ? (unsigned)((((NN) * a.h + y_) * a.w_img + x_) * 12 + hsl.ch[i] * 4) : WR_OOB, 0, 0); \
+    }
+#define C3_STORE_HALO(V, BUF)                                                                             \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                         \
+        if (tid + C3_T * i < C3_HALO)                                                                     \
+            reinterpret_cast<bf16_t*>(BUF)[tid + C3_T * i] = (bf16_t)__builtin_bit_cast(float, V[i]);
+#define C3_TILE(T)                                                                                        \
+    const int t_ = (T) < a.ntiles ? (T) : a.ntiles - 1;      /* past the end: re-fetch, loads stay unconditional */ \
+    const int r_ = t_ / a.tiles_x;                                                                        \
+    const int x0 = (t_ - r_ * a.tiles_x) << 4;                                                            \
+    const int nn = r_ / a.tiles_y;                                                                        \
+    const int y0 = (r_ - nn * a.tiles_y) << 4;
+
+__global__ __launch_bounds__(C3_T, 2) void conv3x3_c3_fwd_kernel(C3Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* hb0 = smem;
+    char* hb1 = smem + C3_HB;
+    float* gb = reinterpret_cast<float*>(smem + 2 * C3_HB);      // [gamma][beta][bias]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = lane >> 4;
+    const int npix = a.n * a.h * a.w_img;
+    if (tid < 64) {
+        gb[tid] = a.gamma[tid]; gb[64 + tid] = a.beta[tid]; gb[128 + tid] = a.bias ? a.bias[tid] : 0.f;
+    }
+    // weight fragments (MFMA operand A): row = output channel nt*16 + (lane & 15), k = 8 grp .. 8 grp + 7
+    bf16x8 wf[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 8 * grp + j;
+            wf[nt][j] = (bf16_t)(k < 27 ? a.w[k * 64 + nt * 16 + (lane & 15)] : 0.f);
+        }
+    // patch gather: K index k of pixel (row, col) sits at halo element (row * 18 + col) * 3 + k + 45 * (k / 9)
+    int koff[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 8 * grp + j;
+        koff[j] = k < 27 ? (k + 45 * (k / 9)) * 2 : -1;
+    }
+    const C3Halo hsl = c3_halo_setup(tid);
+    const auto rsx = wave_uniform_rsrc(a.x, npix * 12);
+    const auto rsz = wave_uniform_rsrc(a.z, npix * 128);
+    const auto rsa = wave_uniform_rsrc(a.act, npix * 128);
+    const auto rsm = wave_uniform_rsrc(a.mean, npix * 4);
+    const auto rsr = wave_uniform_rsrc(a.rstd, npix * 4);
+    int soff[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+        soff[mt] = (((wave * 4 + mt) * a.w_img + (lane & 15)) * 64 + (grp & 1) * 16 + (grp >> 1) * 8) * 2;
+    unsigned hv[4];
+    {
+        C3_TILE((int)blockIdx.x)
+        C3_LOAD_HALO(hv, rsx, nn, y0, x0)
+    }
+    int buf = 0;
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        char* hb = buf ? hb1 : hb0;
+        C3_STORE_HALO(hv, hb)
+        lds_barrier();                              // also orders gb on the first pass
+        {
+            C3_TILE(tile + (int)gridDim.x)
+            C3_LOAD_HALO(hv, rsx, nn, y0, x0)        // next tile, lands during this tile's work
+        }
+        C3_TILE(tile)
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float4 b4 = *reinterpret_cast<const float4*>(gb + 128 + j * 16 + grp * 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][j] = f32x4{b4.x, b4.y, b4.z, b4.w};
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const char* pb = hb + (((wave * 4 + mt) * 18 + (lane & 15)) * 3) * 2;
+            bf16x8 xf;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                xf[j] = koff[j] >= 0 ? *reinterpret_cast<const bf16_t*>(pb + koff[j]) : (bf16_t)0.f;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf, acc[mt][nt], 0, 0, 0);
+        }
+        u32x4 pend[16];
+        unsigned pvo[4];
+        ws_pack_tile<2>(acc, gb, a.eps, wave, lane, a.h, a.w_img, nn, y0, x0, 64, soff, rsm, rsr, pend, pvo);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            __builtin_amdgcn_raw_buffer_store_b128(pend[i], rsz, pvo[i >> 1], (i & 1) * 64, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(pend[8 + i], rsa, pvo[i >> 1], (i & 1) * 64, 0);
+        }
+        buf ^= 1;
+    }
+}
+
+// wgrad of the same layer: slab[k][co] = sum over this workgroup's tiles of patch[pixel][k] * dz[pixel][co].
+// Wave w owns output channels 16 w .. 16 w + 15 and both 16-row halves of k; per k-step (32 pixels) the dz fragment
+// is one transposed-read pair (layout and k <-> pixel map of WgradPol<PolBF16>) and the patch fragments are gathered
+// from the bf16 halo.  LDS: two halo buffers + one dz tile (256 pixels x 160 B); dz and the next halo wait in registers.
+__global__ __launch_bounds__(C3_T, 2) void conv3x3_c3_wgrad_kernel(C3Args a) {
+    typedef WgradPol<PolBF16> WP;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* hb0 = smem;
+    char* hb1 = smem + C3_HB;
+    char* dzt = smem + 2 * C3_HB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const int npix = a.n * a.h * a.w_img;
+    const C3Halo hsl = c3_halo_setup(tid);
+    const auto rsx = wave_uniform_rsrc(a.x, npix * 12);
+    const auto rsd = wave_uniform_rsrc(a.dz, npix * 128);
+    // patch fragment (operand A): row m = (lane & 15) + 16 mt is the K index, element j is pixel
+    // ks*32 + 16 (j >> 2) + 4 grp + (j & 3) of the tile = (row 2 ks + (j >> 2), col 4 grp + (j & 3))
+    int moff[2], joff[8];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int m = (lane & 15) + 16 * mt;
+        moff[mt] = m < 27 ? (m + 45 * (m / 9)) * 2 : -1;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) joff[j] = (((j >> 2) * 18 + 4 * grp + (j & 3)) * 3) * 2;
+    const int dzo = (grp * 4 + q) * WP::DZS + wave * 32 + p * 8;
+    // dz slot i: s = tid + 256 i -> tile pixel s / 8, 16-byte part s % 8
+    const int dpart = (tid & 7) * 16, dcol = (tid >> 3) & 15, drow0 = tid >> 7;       // row drow0 + 2 i
+    const int dlds = (tid >> 3) * WP::DZS + dpart;                                      // + 32 i * DZS
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    unsigned hv[4];
+    u32x4 dv[8];
+#define C3_LOAD_DZ(NN, Y0, X0)                                                                            \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                       \
+        const int y_ = (Y0) + drow0 + 2 * i, x_ = (X0) + dcol;                                            \
+        const bool ok_ = y_ < a.h && x_ < a.w_img;                                                        \
+        dv[i] = __builtin_amdgcn_raw_buffer_load_b128(                                                    \
+            rsd, ok_ ? (unsigned)((((NN) * a.h + y_) * a.w_img + x_) * 128 + dpart) : WR_OOB, 0, 0);      \
+    }
+    {
+        C3_TILE((int)blockIdx.x)
+        C3_LOAD_HALO(hv, rsx, nn, y0, x0)
+        C3_LOAD_DZ(nn, y0, x0)
+    }
+    int buf = 0;
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        char* hb = buf ? hb1 : hb0;
+        C3_STORE_HALO(hv, hb)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<u32x4*>(dzt + dlds + 32 * i * WP::DZS) = dv[i];
+        lds_barrier();
+        {
+            C3_TILE(tile + (int)gridDim.x)
+            C3_LOAD_HALO(hv, rsx, nn, y0, x0)
+            C3_LOAD_DZ(nn, y0, x0)
+        }
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const bf16x8 bfr = WP::tr_pair(dzt + dzo + ks * 32 * WP::DZS, dzt + dzo + (ks * 32 + 16) * WP::DZS);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                bf16x8 afr;
+                const char* pb = hb + (2 * ks * 18 * 3) * 2 + (moff[mt] >= 0 ? moff[mt] : 0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    afr[j] = moff[mt] >= 0 ? *reinterpret_cast<const bf16_t*>(pb + joff[j]) : (bf16_t)0.f;
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr, acc[mt], 0, 0, 0);
+            }
+        }
+        lds_barrier();                              // the dz tile is single buffered
+        buf ^= 1;
+    }
+    // D[row = K index][col = channel]: lane holds rows (lane >> 4) * 4 + r of column lane & 15
+    float* slab = a.ws + (size_t)blockIdx.x * (27 * 64);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = 16 * mt + grp * 4 + r;
+            if (k < 27) slab[k * 64 + wave * 16 + (lane & 15)] = acc[mt][r];
+        }
+#undef C3_LOAD_DZ
+}
+#undef C3_LOAD_HALO
+#undef C3_STORE_HALO
+#undef C3_TILE
+
 // dw_hwio[tap][ci][co] = sum over splits of the slabs, fixed order (deterministic).
 // block = 64 consecutive (tap, ci, co) columns x 4 split groups.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
@@ -1818,6 +2041,61 @@ extern "C" size_t ad_conv3x3_fwd_ws_bytes(int n, int h, int w, int cin, int cout
     const int nitems = g.tiles_x * g.tiles_y * g.tiles_i * (cout / BN);
     const int ks = pick_ksplit(nitems, cin / (dtype == AD_BF16 ? PolBF16::CK : PolF32::CK));
     return ks > 1 ? (size_t)ks * n * h * w * cout * sizeof(float) : 0;
+}
+
+// ---- first layer (3 input channels, 64 output channels, bf16)
+static bool c3_plan(int n, int h, int w, C3Args* a, int* grid) {
+    if (n <= 0 || h <= 0 || w <= 0 || (long long)n * h * w * 128 > WR_MAX_BYTES) return false;
+    a->n = n; a->h = h; a->w_img = w;
+    a->tiles_x = (w + 15) / 16; a->tiles_y = (h + 15) / 16;
+    a->ntiles = a->tiles_x * a->tiles_y * n;
+    *grid = a->ntiles < 2 * NUM_CU ? a->ntiles : 2 * NUM_CU;
+    return true;
+}
+
+extern "C" int ad_conv3x3_c3_supported(int n, int h, int w, int cout, int dtype) {
+    C3Args a; int grid;
+    return dtype == AD_BF16 && cout == 64 && c3_plan(n, h, w, &a, &grid);
+}
+
+extern "C" int ad_conv3x3_c3_ln_relu_fwd(const float* x, const float* w_hwio, const float* bias, const float* gamma,
+                                         const float* beta, float eps, void* z, void* act, float* mean, float* rstd,
+                                         int n, int h, int w, int dtype, void* stream) {
+    AD_REQUIRE(dtype == AD_BF16, "ad_conv3x3_c3_ln_relu_fwd: bf16 only (dtype %d)", dtype);
+    AD_REQUIRE(x && w_hwio && gamma && beta && z && act && mean && rstd, "ad_conv3x3_c3_ln_relu_fwd: NULL operand");
+    C3Args a; int grid;
+    AD_REQUIRE(c3_plan(n, h, w, &a, &grid), "ad_conv3x3_c3_ln_relu_fwd: unsupported shape n=%d h=%d w=%d", n, h, w);
+    a.x = x; a.w = w_hwio; a.bias = bias; a.gamma = gamma; a.beta = beta; a.eps = eps;
+    a.z = (char*)z; a.act = (char*)act; a.mean = mean; a.rstd = rstd; a.dz = nullptr; a.ws = nullptr;
+    conv3x3_c3_fwd_kernel<<<grid, C3_T, 2 * C3_HB + 3 * BN * 4, (hipStream_t)stream>>>(a);
+    AD_LAUNCH_CHECK("ad_conv3x3_c3_ln_relu_fwd");
+    return AD_OK;
+}
+
+extern "C" size_t ad_conv3x3_c3_wgrad_ws_bytes(int n, int h, int w) {
+    C3Args a; int grid;
+    if (!c3_plan(n, h, w, &a, &grid)) return 0;
+    return (size_t)grid * 27 * 64 * sizeof(float);
+}
+
+extern "C" int ad_conv3x3_c3_wgrad(const float* x, const void* dz, float* dw_hwio, int n, int h, int w, void* ws,
+                                   size_t ws_bytes, int dtype, void* stream) {
+    AD_REQUIRE(dtype == AD_BF16, "ad_conv3x3_c3_wgrad: bf16 only (dtype %d)", dtype);
+    AD_REQUIRE(x && dz && dw_hwio, "ad_conv3x3_c3_wgrad: NULL operand");
+    C3Args a; int grid;
+    AD_REQUIRE(c3_plan(n, h, w, &a, &grid), "ad_conv3x3_c3_wgrad: unsupported shape n=%d h=%d w=%d", n, h, w);
+    const size_t need = (size_t)grid * 27 * 64 * sizeof(float);
+    if (ws == nullptr || ws_bytes < need)
+        return ad_set_error(AD_ERR_WS, "ad_conv3x3_c3_wgrad: workspace %zu < %zu bytes", ws_bytes, need);
+    a.x = x; a.w = nullptr; a.bias = a.gamma = a.beta = nullptr; a.eps = 0.f;
+    a.z = a.act = nullptr; a.mean = a.rstd = nullptr; a.dz = (const char*)dz; a.ws = (float*)ws;
+    hipStream_t s = (hipStream_t)stream;
+    conv3x3_c3_wgrad_kernel<<<grid, C3_T, 2 * C3_HB + TM * WgradPol<PolBF16>::DZS, s>>>(a);
+    AD_LAUNCH_CHECK("ad_conv3x3_c3_wgrad");
+    // slabs [grid][27][64] -> dw_hwio [3][3][3][64]: the generic slab reduce with 3-channel input blocks
+    wgrad_reduce_kernel<<<(27 * 64 + 63) / 64, 256, 0, s>>>((const float*)ws, dw_hwio, grid, 1, 1, 3, 3, 64);
+    AD_LAUNCH_CHECK("wgrad_reduce");
+    return AD_OK;
 }
 
 extern "C" size_t ad_conv3x3_wgrad_ws_bytes(int n, int h, int w, int cin, int cout, int dtype) {

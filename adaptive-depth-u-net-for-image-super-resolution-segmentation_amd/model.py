@@ -360,14 +360,24 @@ class Model:
         loss_kind = self.loss.kind if self.loss is not None else 0
         eps = self.loss.eps if self.loss is not None else 1e-3
         tape: List[tuple] = []
-        cur1, cur2 = ops.pad_channels(x, ops.cin_granule(self.dtype), self.dtype), None
+        first = next(iter(self.convs.values()))
+        # bf16: the first conv (3 -> 64) runs on the raw fp32 batch through the dedicated 3-channel kernels; otherwise the
+        # input is zero-padded to the conv channel granule once
+        c3 = first.cin == 3 and first.ln is not None and ops.conv3x3_c3_supported(x, first.cout, self.dtype)
+        cur1, cur2 = (x if c3 else ops.pad_channels(x, ops.cin_granule(self.dtype), self.dtype)), None
         skips: List[torch.Tensor] = []
         for step in self._plan:
             kind = step[0]
             if kind == "block":
                 for cs in step[1]:
-                    z, a, mean, rstd = ops.conv3x3_ln_relu_fwd(cur1, cur2, self._packs[cs.name][0], self.param(cs.name + "/bias"),
-                                                               self.param(cs.ln + "/gamma"), self.param(cs.ln + "/beta"), cs.cout)
+                    if c3 and cs is first:
+                        z, a, mean, rstd = ops.conv3x3_c3_ln_relu_fwd(cur1, self.param(cs.name + "/kernel"),
+                                                                      self.param(cs.name + "/bias"),
+                                                                      self.param(cs.ln + "/gamma"), self.param(cs.ln + "/beta"))
+                    else:
+                        z, a, mean, rstd = ops.conv3x3_ln_relu_fwd(cur1, cur2, self._packs[cs.name][0],
+                                                                   self.param(cs.name + "/bias"), self.param(cs.ln + "/gamma"),
+                                                                   self.param(cs.ln + "/beta"), cs.cout)
                     if keep:
                         tape.append(("cla", cs, cur1, cur2, z, mean, rstd, step[2]))
                     cur1, cur2 = a, None
@@ -415,7 +425,10 @@ class Model:
                 dz = ops.layernorm_relu_bwd(d, z, mean, rstd, self.param(cs.ln + "/gamma"), self.param(cs.ln + "/beta"),
                                             self.grad(cs.ln + "/gamma"), self.grad(cs.ln + "/beta"),
                                             self.grad(cs.name + "/bias"), ws)
-                ops.conv3x3_wgrad(x1, x2, dz, self.grad(cs.name + "/kernel"), cs.cin, ws)
+                if x1.dtype == torch.float32 and self.dtype != torch.float32:      # raw 3-channel batch: first layer
+                    ops.conv3x3_c3_wgrad(x1, dz, self.grad(cs.name + "/kernel"), ws)
+                else:
+                    ops.conv3x3_wgrad(x1, x2, dz, self.grad(cs.name + "/kernel"), cs.cin, ws)
                 self._done(cs.name + "/kernel")
                 if not cs.need_dgrad:
                     d = None

@@ -197,6 +197,39 @@ def conv3x3_ln_relu_fwd(x1: torch.Tensor, x2: Optional[torch.Tensor], w_packed: 
     return z, act, mean, rstd
 
 
+def conv3x3_c3_supported(x: torch.Tensor, cout: int, dtype: torch.dtype) -> bool:
+    """True when the dedicated 3-input-channel first-layer kernels take this batch ([N,H,W,3] fp32, bf16 compute)."""
+    if x.dim() != 4 or x.shape[-1] != 3 or x.dtype != torch.float32:
+        return False
+    n, h, w, _ = x.shape
+    return bool(_lib.load().ad_conv3x3_c3_supported(n, h, w, cout, dt(dtype)))
+
+
+def conv3x3_c3_ln_relu_fwd(x: torch.Tensor, w_hwio: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.Tensor,
+                           beta: torch.Tensor, eps: float = LN_EPS):
+    """First conv_block step on the raw [N,H,W,3] fp32 input: returns (z, act, mean, rstd) in bf16 / fp32."""
+    n, h, w, _ = x.shape
+    z = torch.empty((n, h, w, 64), dtype=torch.bfloat16, device=x.device)
+    act = torch.empty_like(z)
+    mean = torch.empty(n * h * w, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(n * h * w, dtype=torch.float32, device=x.device)
+    with _timed("conv3x3_c3_ln_relu_fwd", 2.0 * n * h * w * 27 * 64):
+        check(_lib.load().ad_conv3x3_c3_ln_relu_fwd(_p(x), _p(w_hwio), _p(bias), _p(gamma), _p(beta), eps, _p(z), _p(act),
+                                                    _p(mean), _p(rstd), n, h, w, AD_BF16, _stream()),
+              "ad_conv3x3_c3_ln_relu_fwd")
+    return z, act, mean, rstd
+
+
+def conv3x3_c3_wgrad(x: torch.Tensor, dz: torch.Tensor, dw_out: torch.Tensor, ws: Workspace):
+    """dw_out: fp32 [3,3,3,64] view of the flat gradient buffer; x the raw [N,H,W,3] fp32 input."""
+    n, h, w, _ = x.shape
+    lib = _lib.load()
+    ws.ensure(lib.ad_conv3x3_c3_wgrad_ws_bytes(n, h, w))
+    with _timed("conv3x3_wgrad"):
+        check(lib.ad_conv3x3_c3_wgrad(_p(x), _p(dz), _p(dw_out), n, h, w, ws.ptr, ws.nbytes, AD_BF16, _stream()),
+              "ad_conv3x3_c3_wgrad")
+
+
 def conv3x3_wgrad(x1: torch.Tensor, x2: Optional[torch.Tensor], dz: torch.Tensor, dw_out: torch.Tensor, cin_real: int,
                   ws: Workspace):
     """dw_out: fp32 [3,3,cin_real,cout] view (e.g. a slice of the flat gradient buffer)."""

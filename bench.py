@@ -177,6 +177,8 @@ def main():
         # algorithmic ones: what the wrappers launched minus the zero-padded channels of the first conv (3 -> 32).
         n_launch, ms = summ["conv3x3_fwd"]
         padded_first = first * (model._cin_pad(next(iter(model.convs.values()))) / 3.0 - 1.0) * batch * timed_steps
+        if "conv3x3_c3_ln_relu_fwd" in summ:      # bf16: the first conv has its own 3-channel kernel, nothing was padded
+            padded_first = 0.0
         flops_kernel = timer.work("conv3x3_fwd") - padded_first
         achieved = flops_kernel / (ms * 1e-3) / 1e12
         fused = summ.get("conv3x3_ln_relu_fwd", (0, 0.0))

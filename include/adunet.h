@@ -106,6 +106,20 @@ int ad_conv3x3_ln_relu_fwd(const void* x1, int c1, const void* x2, int c2,
                            int n, int h, int w, int cout,
                            void* ws, size_t ws_bytes, int dtype, void* stream);
 
+/* The network's first conv_block step -- L.Conv2D(base_channels, 3, padding="same") on the 3-channel input followed
+ * by LayerNormalization and ReLU (train_adaptive_unet.py:202-204 with inputs of :225) -- and its weight gradient,
+ * without the zero-padded copy of the input: x is the raw [n, h, w, 3] fp32 batch, w_hwio the fp32 master kernel
+ * [3, 3, 3, 64]; K = 27 is padded to one 32-deep MFMA step inside the kernels.  bf16 outputs, cout = 64 only
+ * (ad_conv3x3_c3_supported tells); other first layers use ad_pad_channels + the general entry points. */
+int ad_conv3x3_c3_supported(int n, int h, int w, int cout, int dtype);
+int ad_conv3x3_c3_ln_relu_fwd(const float* x, const float* w_hwio, const float* bias,
+                              const float* gamma, const float* beta, float eps,
+                              void* z, void* act, float* mean, float* rstd,
+                              int n, int h, int w, int dtype, void* stream);
+size_t ad_conv3x3_c3_wgrad_ws_bytes(int n, int h, int w);
+int ad_conv3x3_c3_wgrad(const float* x, const void* dz, float* dw_hwio,
+                        int n, int h, int w, void* ws, size_t ws_bytes, int dtype, void* stream);
+
 /* ---------------------------------------------------- LayerNorm (+ ReLU) -- */
 
 /* L.LayerNormalization(axis=-1) (eps 1e-3) followed by L.Activation("relu"):

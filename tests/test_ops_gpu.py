@@ -264,6 +264,39 @@ def test_conv3x3_ln_relu_fwd(device, case):
     assert torch.equal(z, z2) and torch.equal(act, act2) and torch.equal(mean, mean2) and torch.equal(rstd, rstd2)
 
 
+@pytest.mark.parametrize("shape", [(2, 24, 24), (3, 37, 29), (1, 16, 16), (2, 5, 70)])
+def test_first_layer_three_channel_kernels(device, ws, shape):
+    """Dedicated Cin = 3 kernels (K = 27 in one MFMA step) on the raw fp32 input: conv + LayerNorm + ReLU forward and
+    the weight gradient, whole tensors against the oracle (ragged tiles, maps smaller than a tile)."""
+    from adunet_amd import ops
+    n, h, w = shape
+    rng = np.random.default_rng(31)
+    x = rng.random((n, h, w, 3)).astype(np.float32)
+    xb = rnd(x.astype(np.float64), BF16)                       # the kernels round the input to bf16 in LDS
+    wk = rnd(rng.standard_normal((3, 3, 3, 64)) * 0.2, BF16)
+    b = rng.standard_normal(64).astype(np.float32).astype(np.float64)
+    gam = rng.uniform(0.5, 1.5, 64).astype(np.float32).astype(np.float64)
+    bet = (0.3 * rng.standard_normal(64)).astype(np.float32).astype(np.float64)
+    f = lambda v: torch.tensor(v, dtype=F32, device=device)
+    xd = torch.tensor(x, device=device)
+    assert ops.conv3x3_c3_supported(xd, 64, BF16) and not ops.conv3x3_c3_supported(xd, 128, BF16)
+    z, act, mean, rstd = ops.conv3x3_c3_ln_relu_fwd(xd, f(wk), f(b), f(gam), f(bet))
+    zw = ref.conv2d_same_fwd(xb, wk, b)
+    aw = np.maximum(ref.layernorm_fwd(zw, gam, bet)[0], 0)
+    assert relerr(z, zw) < TOL[BF16] and relerr(act, aw) < 2 * TOL[BF16]
+    assert relerr(mean.view(n, h, w), zw.mean(-1)) < TOL[BF16]
+    got_r = rstd.view(n, h, w).to(torch.float64).cpu().numpy()
+    assert np.abs(got_r * np.sqrt(zw.var(-1) + 1e-3) - 1).max() < 2e-2
+    dz = rnd(rng.standard_normal((n, h, w, 64)), BF16)
+    _, want, _ = ref.conv2d_same_bwd(xb, wk, dz, need_dx=False)
+    dw = torch.full((3, 3, 3, 64), float("nan"), dtype=F32, device=device)
+    ops.conv3x3_c3_wgrad(xd, to_dev(dz, BF16, device), dw, ws)
+    assert relerr(dw, want) < 1e-3
+    dw2 = torch.empty_like(dw)
+    ops.conv3x3_c3_wgrad(xd, to_dev(dz, BF16, device), dw2, ws)
+    assert torch.equal(dw, dw2)
+
+
 @pytest.mark.parametrize("dtype", [F32, BF16])
 def test_first_layer_padded_channels(device, ws, dtype):
     """3-channel network input zero-padded to the conv granule; wgrad writes only the 3 real rows."""
