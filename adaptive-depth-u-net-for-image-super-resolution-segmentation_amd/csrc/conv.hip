@@ -1728,7 +1728,7 @@ __global__ __launch_bounds__(C3_T, 2) void conv3x3_c3_wgrad_kernel(C3Args a) {
 // block = 64 consecutive (tap, ci, co) columns x 4 split groups.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
                                                            int nsplit, int ncib, int ncob, int ck, int cin_real,
-                                                           int cout) {
+                                                           int cout, int accumulate = 0) {
     __shared__ float sm[4][64];
     const int tid = threadIdx.x, cl = tid & 63, rg = tid >> 6;
     const int idx = blockIdx.x * 64 + cl;
@@ -1746,7 +1746,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
     sm[rg][cl] = s;
     __syncthreads();
-    if (rg == 0 && idx < total) dw[idx] = (sm[0][cl] + sm[1][cl]) + (sm[2][cl] + sm[3][cl]);
+    if (rg == 0 && idx < total) {
+        const float t = (sm[0][cl] + sm[1][cl]) + (sm[2][cl] + sm[3][cl]);
+        dw[idx] = accumulate ? dw[idx] + t : t;      // later runs of an image-chunked launch add to the first
+    }
 }
 
 // ------------------------------------------------------------------ weight packing
@@ -1804,6 +1807,50 @@ static int fwd_ws_kind(int n, int h, int w, int c1, int c2, int cout, bool ln) {
     if (nch == 2 && nitems >= 4 * NUM_CU) return 1;
     if (nch >= 2 && nch % 2 == 0 && nitems >= NUM_CU) return 2;
     return 0;
+}
+
+// Tensors of 2 GiB and more do not fit the 32-bit buffer offsets of the wave-specialised kernels; a batch that is
+// only too large as a whole is cut into runs of `chunk` images (NHWC: a run is a pointer offset) when every run
+// still qualifies for a specialised kernel.  chunk == n: a single launch.
+static int images_per_launch(int n, int h, int w, int c1, int c2, int cout, bool ln, bool wgrad) {
+    const long long widest = c1 > c2 ? (c1 > cout ? c1 : cout) : (c2 > cout ? c2 : cout);
+    const long long per_img = (long long)h * w * widest * 2;
+    if ((long long)n * per_img <= WR_MAX_BYTES || per_img > WR_MAX_BYTES || n < 2) return n;
+    const int cap = (int)(WR_MAX_BYTES / per_img);
+    const int runs = (n + cap - 1) / cap;
+    const int chunk = (n + runs - 1) / runs;
+    const int last = n - (runs - 1) * chunk;
+    (void)wgrad;
+    if (last < 1) return n;
+    if (!wgrad && (!fwd_ws_kind(chunk, h, w, c1, c2, cout, ln) || !fwd_ws_kind(last, h, w, c1, c2, cout, ln))) return n;
+    return chunk;
+}
+
+template <typename P>
+int launch_fwd(ConvArgs a, void* ws, size_t ws_bytes, hipStream_t s);
+
+template <typename P>
+int launch_fwd_runs(ConvArgs a, void* ws, size_t ws_bytes, hipStream_t s) {
+    int chunk = a.n;
+    if constexpr (sizeof(typename P::T) == 2)
+        chunk = images_per_launch(a.n, a.h, a.w, a.c1, a.c2, a.cout, a.epilogue == AD_EPI_LN_RELU, false);
+    if (chunk >= a.n) return launch_fwd<P>(a, ws, ws_bytes, s);
+    constexpr size_t TSZ = sizeof(typename P::T);
+    for (int i0 = 0; i0 < a.n; i0 += chunk) {
+        ConvArgs b = a;
+        const size_t pix0 = (size_t)i0 * a.h * a.w;
+        b.n = a.n - i0 < chunk ? a.n - i0 : chunk;
+        b.x1 = a.x1 + pix0 * a.c1 * TSZ;
+        if (a.x2) b.x2 = a.x2 + pix0 * a.c2 * TSZ;
+        b.y1 = a.y1 + pix0 * a.cy1 * TSZ;
+        if (a.y2) b.y2 = a.y2 + pix0 * (a.cout - a.cy1) * TSZ;
+        if (a.a_out) { b.a_out = a.a_out + pix0 * a.cout * TSZ; b.ln_mean = a.ln_mean + pix0; b.ln_rstd = a.ln_rstd + pix0; }
+        pick_geo(b.n, b.h, b.w, &b.g);
+        b.ntiles = b.g.tiles_x * b.g.tiles_y * b.g.tiles_i;
+        const int rc = launch_fwd<P>(b, ws, ws_bytes, s);
+        if (rc) return rc;
+    }
+    return AD_OK;
 }
 
 template <typename P>
@@ -1992,7 +2039,7 @@ extern "C" int ad_conv3x3_fwd(const void* x1, int c1, const void* x2, int c2, co
     pick_geo(n, h, w, &a.g);
     a.ntiles = a.g.tiles_x * a.g.tiles_y * a.g.tiles_i;
     hipStream_t s = (hipStream_t)stream;
-    return dtype == AD_BF16 ? launch_fwd<PolBF16>(a, ws, ws_bytes, s) : launch_fwd<PolF32>(a, ws, ws_bytes, s);
+    return dtype == AD_BF16 ? launch_fwd_runs<PolBF16>(a, ws, ws_bytes, s) : launch_fwd_runs<PolF32>(a, ws, ws_bytes, s);
 }
 
 extern "C" int ad_layernorm_relu_fwd(const void* z, const float* gamma, const float* beta, void* y, float* mean,
@@ -2000,7 +2047,8 @@ extern "C" int ad_layernorm_relu_fwd(const void* z, const float* gamma, const fl
 
 extern "C" int ad_conv3x3_ln_relu_is_fused(int n, int h, int w, int c1, int c2, int cout, int dtype) {
     if (dtype != AD_BF16 || n <= 0 || h <= 0 || w <= 0 || c1 <= 0 || c2 < 0 || cout <= 0 || cout % BN) return 0;
-    return fwd_ws_kind(n, h, w, c1, c2, cout, true) != 0;
+    const int chunk = images_per_launch(n, h, w, c1, c2, cout, true, false);
+    return fwd_ws_kind(chunk, h, w, c1, c2, cout, true) != 0;
 }
 
 extern "C" int ad_conv3x3_ln_relu_fwd(const void* x1, int c1, const void* x2, int c2, const void* w_packed,
@@ -2026,10 +2074,10 @@ extern "C" int ad_conv3x3_ln_relu_fwd(const void* x1, int c1, const void* x2, in
     pick_geo(n, h, w, &a.g);
     a.ntiles = a.g.tiles_x * a.g.tiles_y * a.g.tiles_i;
     hipStream_t s = (hipStream_t)stream;
-    int rc = dtype == AD_BF16 ? launch_fwd<PolBF16>(a, ws, ws_bytes, s) : launch_fwd<PolF32>(a, ws, ws_bytes, s);
+    int rc = dtype == AD_BF16 ? launch_fwd_runs<PolBF16>(a, ws, ws_bytes, s) : launch_fwd_runs<PolF32>(a, ws, ws_bytes, s);
     if (rc != AD_ERR_UNFUSED) return rc;
     a.epilogue = AD_EPI_NONE;
-    rc = dtype == AD_BF16 ? launch_fwd<PolBF16>(a, ws, ws_bytes, s) : launch_fwd<PolF32>(a, ws, ws_bytes, s);
+    rc = dtype == AD_BF16 ? launch_fwd_runs<PolBF16>(a, ws, ws_bytes, s) : launch_fwd_runs<PolF32>(a, ws, ws_bytes, s);
     if (rc) return rc;
     return ad_layernorm_relu_fwd(z, gamma, beta, act, mean, rstd, (int64_t)n * h * w, cout, eps, 1, dtype, stream);
 }
@@ -2102,7 +2150,15 @@ extern "C" size_t ad_conv3x3_wgrad_ws_bytes(int n, int h, int w, int cin, int co
     WgradPlan p;
     if (n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0 || cout % BN) return 0;
     plan_wgrad(n, h, w, cin, 0, cout, dtype, &p);     // the split of cin does not change the slab size
-    return p.ws_bytes;
+    size_t need = p.ws_bytes;
+    const int chunk = dtype == AD_BF16 ? images_per_launch(n, h, w, cin, 0, cout, false, true) : n;
+    if (chunk < n) {                                  // image runs of a >= 2 GiB batch plan their own slabs
+        plan_wgrad(chunk, h, w, cin, 0, cout, dtype, &p);
+        if (p.ws_bytes > need) need = p.ws_bytes;
+        plan_wgrad(n - (n - 1) / chunk * chunk, h, w, cin, 0, cout, dtype, &p);
+        if (p.ws_bytes > need) need = p.ws_bytes;
+    }
+    return need;
 }
 
 extern "C" int ad_conv3x3_wgrad(const void* x1, int c1, const void* x2, int c2, const void* dz, float* dw_hwio,
@@ -2117,24 +2173,31 @@ extern "C" int ad_conv3x3_wgrad(const void* x1, int c1, const void* x2, int c2, 
     AD_REQUIRE(cout > 0 && cout % BN == 0, "ad_conv3x3_wgrad: cout=%d must be a multiple of %d", cout, BN);
     const int cin = c1 + c2;
     AD_REQUIRE(cin_real > 0 && cin_real <= cin, "ad_conv3x3_wgrad: cin_real=%d", cin_real);
-    WgradPlan p;
-    plan_wgrad(n, h, w, c1, c2, cout, dtype, &p);
-    if (ws == nullptr || ws_bytes < p.ws_bytes)
-        return ad_set_error(AD_ERR_WS, "ad_conv3x3_wgrad: workspace %zu < %zu bytes", ws_bytes, p.ws_bytes);
-    WgradArgs a;
-    a.x1 = (const char*)x1; a.x2 = (const char*)x2; a.c1 = c1; a.c2 = c2;
-    a.dz = (const char*)dz; a.ws = (float*)ws;
-    a.n = n; a.h = h; a.w = w; a.cout = cout;
-    a.ntiles = p.ntiles; a.tiles_per_split = p.tiles_per_split; a.ncib = p.ncib; a.ncob = p.ncob;
-    a.g = p.g;
-    const bool direct = p.nsplit == 1 && !p.specialised;
-    a.dw = direct ? dw_hwio : nullptr; a.cin_real = cin_real;
+    // batches whose tensors reach 2 GiB: runs of `chunk` images, the first run writes dw, the others add to it
+    const int chunk = dtype == AD_BF16 ? images_per_launch(n, h, w, c1, c2, cout, false, true) : n;
     hipStream_t s = (hipStream_t)stream;
-    int rc = dtype == AD_BF16 ? launch_wgrad<PolBF16>(a, p, s) : launch_wgrad<PolF32>(a, p, s);
-    if (rc || direct) return rc;
-    int total = 9 * cin_real * cout;
-    wgrad_reduce_kernel<<<(total + 63) / 64, 256, 0, s>>>((const float*)ws, dw_hwio, p.nsplit, p.ncib, p.ncob, p.ck,
-                                                         cin_real, cout);
-    AD_LAUNCH_CHECK("wgrad_reduce");
+    const size_t tsz = dtype == AD_BF16 ? 2 : 4;
+    for (int i0 = 0; i0 < n; i0 += chunk) {
+        const int nr = n - i0 < chunk ? n - i0 : chunk;
+        const size_t pix0 = (size_t)i0 * h * w;
+        WgradPlan p;
+        plan_wgrad(nr, h, w, c1, c2, cout, dtype, &p);
+        if (ws == nullptr || ws_bytes < p.ws_bytes)
+            return ad_set_error(AD_ERR_WS, "ad_conv3x3_wgrad: workspace %zu < %zu bytes", ws_bytes, p.ws_bytes);
+        WgradArgs a;
+        a.x1 = (const char*)x1 + pix0 * c1 * tsz; a.x2 = x2 ? (const char*)x2 + pix0 * c2 * tsz : nullptr; a.c1 = c1; a.c2 = c2;
+        a.dz = (const char*)dz + pix0 * cout * tsz; a.ws = (float*)ws;
+        a.n = nr; a.h = h; a.w = w; a.cout = cout;
+        a.ntiles = p.ntiles; a.tiles_per_split = p.tiles_per_split; a.ncib = p.ncib; a.ncob = p.ncob;
+        a.g = p.g;
+        const bool direct = p.nsplit == 1 && !p.specialised && chunk >= n;
+        a.dw = direct ? dw_hwio : nullptr; a.cin_real = cin_real;
+        int rc = dtype == AD_BF16 ? launch_wgrad<PolBF16>(a, p, s) : launch_wgrad<PolF32>(a, p, s);
+        if (rc || direct) return rc;
+        int total = 9 * cin_real * cout;
+        wgrad_reduce_kernel<<<(total + 63) / 64, 256, 0, s>>>((const float*)ws, dw_hwio, p.nsplit, p.ncib, p.ncob, p.ck,
+                                                             cin_real, cout, i0 > 0);
+        AD_LAUNCH_CHECK("wgrad_reduce");
+    }
     return AD_OK;
 }

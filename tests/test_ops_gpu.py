@@ -264,6 +264,40 @@ def test_conv3x3_ln_relu_fwd(device, case):
     assert torch.equal(z, z2) and torch.equal(act, act2) and torch.equal(mean, mean2) and torch.equal(rstd, rstd2)
 
 
+def test_conv3x3_batches_of_2gib_and_more_run_in_image_chunks(device, ws):
+    """A batch whose tensors reach 2 GiB (32-bit buffer offsets of the wave-specialised kernels) is cut into runs of
+    images inside the library: forward, fused LayerNorm forward and wgrad must equal the same calls on the runs."""
+    from adunet_amd import ops
+    n, h, w, c = 70, 512, 512, 64          # 70 x 512 x 512 x 64 bf16 = 2.35 GB per tensor
+    g = torch.Generator(device=device).manual_seed(5)
+    x = (torch.rand((n, h, w, c), device=device, generator=g) - 0.5).bfloat16()
+    wk = (torch.rand((3, 3, c, c), device=device, generator=g) - 0.5) * 0.2
+    b = torch.rand(c, device=device, generator=g)
+    gam = torch.rand(c, device=device, generator=g) + 0.5
+    bet = torch.rand(c, device=device, generator=g) - 0.5
+    wf, _ = ops.conv3x3_pack(wk, c, BF16, want_dgrad=False)
+    half = 35
+    y = ops.conv3x3_fwd(x, None, wf, b, c)
+    for lo in (0, half):
+        assert torch.equal(y[lo:lo + half], ops.conv3x3_fwd(x[lo:lo + half], None, wf, b, c))
+    z, act, mean, rstd = ops.conv3x3_ln_relu_fwd(x, None, wf, b, gam, bet, c)
+    npx = half * h * w
+    for lo in (0, half):
+        z2, a2, m2, r2 = ops.conv3x3_ln_relu_fwd(x[lo:lo + half], None, wf, b, gam, bet, c)
+        assert torch.equal(z[lo:lo + half], z2) and torch.equal(act[lo:lo + half], a2)
+        assert torch.equal(mean[lo * h * w:lo * h * w + npx], m2) and torch.equal(rstd[lo * h * w:lo * h * w + npx], r2)
+    del act, mean, rstd, y
+    dz = z                                   # any bf16 tensor of the right shape
+    dw = torch.empty((3, 3, c, c), dtype=F32, device=device)
+    ops.conv3x3_wgrad(x, None, dz, dw, c, ws)
+    acc = torch.zeros_like(dw)
+    part = torch.empty_like(dw)
+    for lo in (0, half):
+        ops.conv3x3_wgrad(x[lo:lo + half], None, dz[lo:lo + half], part, c, ws)
+        acc += part
+    assert float((dw - acc).abs().max() / acc.abs().max()) < 1e-5
+
+
 @pytest.mark.parametrize("shape", [(2, 24, 24), (3, 37, 29), (1, 16, 16), (2, 5, 70)])
 def test_first_layer_three_channel_kernels(device, ws, shape):
     """Dedicated Cin = 3 kernels (K = 27 in one MFMA step) on the raw fp32 input: conv + LayerNorm + ReLU forward and
