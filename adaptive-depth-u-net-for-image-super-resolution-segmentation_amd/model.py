@@ -14,6 +14,8 @@ conv kernels additionally keep MFMA-operand packs of their weights in the comput
 """
 from __future__ import annotations
 
+import os
+
 import math
 import time
 from collections import OrderedDict
@@ -508,7 +510,7 @@ class Model:
         _, loss, psnr, _ = self.forward_loss(lr_img, hr_img, keep=False)
         return loss, psnr
 
-    def make_graphed_train_step(self, lr_example, hr_example):
+    def make_graphed_train_step(self, lr_example, hr_example, capture_only: bool = False):
         """Capture one full train step (forward, loss, backward, Adam, repack: ~190 launches) into hipGraphs and
         return `step(lr, hr) -> (loss, psnr)` that copies the batch into the graphs' static inputs and replays them.
         The launch-bound host loop disappears; the step-dependent Adam factor is fed through device memory.
@@ -516,7 +518,11 @@ class Model:
         Under DataParallel the step is cut into segments at the points where a gradient bucket becomes final: the
         segments are replayed back to back on the compute stream and each bucket's RCCL all-reduce is launched eagerly
         (not captured) on the communication stream right after the segment that completes it, so the exchange of the
-        decoder / bottleneck gradients (86 % of the bytes) overlaps the encoder's backward pass as in the eager path."""
+        decoder / bottleneck gradients (86 % of the bytes) overlaps the encoder's backward pass as in the eager path.
+
+        The capture needs one eager warm-up step.  By default the example batch is then trained on twice (warm-up and
+        first replay); with capture_only the weights, Adam moments and iteration count are put back afterwards, so the
+        example batch has not been trained on when the function returns (fit() uses this)."""
         if self.optimizer is None:
             raise RuntimeError("call compile() first")
         dp = getattr(self, "_dp", None)
@@ -574,6 +580,7 @@ class Model:
             opt.iterations += 1
             alpha_dev.fill_(ops.adam_alpha(opt.lr_at(opt.iterations - 1), opt.beta_1, opt.beta_2, opt.iterations))
 
+        saved_state = (self.P.clone(), self.M.clone(), self.V.clone(), opt.iterations) if capture_only else None
         side = torch.cuda.Stream(device=self.device)       # warm-up on a side stream, as torch's capture recipe asks
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -608,8 +615,14 @@ class Model:
                 if sync:
                     dp.wait_all()
 
-        # the capture itself did not execute the step: run it once so that iteration counts stay truthful
-        run()
+        if capture_only:
+            self.P.copy_(saved_state[0]); self.M.copy_(saved_state[1]); self.V.copy_(saved_state[2])
+            opt.iterations = saved_state[3]
+            self._repack()
+            torch.cuda.synchronize()
+        else:
+            # the capture itself did not execute the step: run it once so that iteration counts stay truthful
+            run()
 
         def step(lr_img, hr_img):
             sx.copy_(self._to_dev(lr_img), non_blocking=True)
@@ -639,6 +652,23 @@ class Model:
             raise ValueError("evaluate() received an empty dataset")
         res = {k: float(v) / nb for k, v in zip(keys, tot)}
         return res if return_dict else [res[k] for k in keys]
+
+    def _fit_step(self, lr_img, hr_img):
+        """One training step of fit(): replayed from a hipGraph captured per batch shape on the GPU (bitwise the eager
+        step, minus ~2 ms of Python launch overhead); eager on other devices or with ADUNET_EAGER_FIT=1."""
+        if os.environ.get("ADUNET_EAGER_FIT") == "1" or type(self).train_on_batch is not Model.train_on_batch:
+            return self.train_on_batch(lr_img, hr_img)      # subclasses with their own step (segmentation) stay eager
+        self._require_device()
+        if self.device.type != "cuda":
+            return self.train_on_batch(lr_img, hr_img)
+        steps = self.__dict__.setdefault("_graph_steps", {})
+        key = (tuple(lr_img.shape), self.optimizer, self.loss)
+        step = steps.get(key)
+        if step is None:
+            if len(steps) >= 4:                     # e.g. a ragged last batch every epoch: do not hoard graph memory
+                return self.train_on_batch(lr_img, hr_img)
+            step = steps[key] = self.make_graphed_train_step(lr_img, hr_img, capture_only=True)
+        return tuple(v.clone() for v in step(lr_img, hr_img))   # the graph's outputs are overwritten by the next replay
 
     def fit(self, dataset: Iterable, epochs: int = 1, initial_epoch: int = 0, steps_per_epoch: Optional[int] = None,
             validation_data: Optional[Iterable] = None, validation_steps: Optional[int] = None,
@@ -676,7 +706,7 @@ class Model:
                         batch = next(it)
                     except StopIteration:
                         raise ValueError("fit() received an empty dataset") from None
-                vals = self.train_on_batch(batch[0], batch[1])
+                vals = self._fit_step(batch[0], batch[1])
                 tot = list(vals) if tot is None else [a + b for a, b in zip(tot, vals)]
                 nb += 1
             if steps_per_epoch is None:

@@ -217,3 +217,26 @@ def test_segmented_graph_step_under_data_parallel(device):
         if created:
             torch.cuda.synchronize()
             dist.barrier()
+
+
+def test_fit_replays_graphs_and_matches_eager_fit(device, monkeypatch):
+    """fit() captures one hipGraph per batch shape (without training on the example batch) and must reproduce the eager
+    fit bit for bit, including a ragged last batch that gets its own graph."""
+    from adunet_amd.model import Adam, build_losses_and_metrics, build_super_resolution_unet
+    rng = np.random.default_rng(23)
+    data = [synth(rng, 3, 32) for _ in range(3)] + [synth(rng, 2, 32)]
+    results = []
+    for eager in ("1", "0"):
+        monkeypatch.setenv("ADUNET_EAGER_FIT", eager)
+        model, _ = build_super_resolution_unet(0.5, depth_override=2, input_size=32, dtype=torch.bfloat16, device=device)
+        loss, metrics = build_losses_and_metrics("charbonnier")
+        model.compile(optimizer=Adam(1e-3), loss=loss, metrics=metrics)
+        model._require_device()
+        model.set_weights(model.initial_weights(np.random.default_rng(1), head_uniform=0.05))
+        hist = model.fit(data, epochs=2, verbose=0)
+        results.append((hist.history["loss"], model.P.clone(), model.optimizer.iterations))
+        if eager == "0":
+            assert len(model._graph_steps) == 2
+    assert results[0][2] == results[1][2] == 8
+    assert results[0][0] == results[1][0]
+    assert torch.equal(results[0][1], results[1][1])
