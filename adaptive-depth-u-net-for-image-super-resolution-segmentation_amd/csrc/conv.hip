@@ -1785,6 +1785,46 @@ __global__ void pack_kernel(const float* __restrict__ w, int cin, int cout, int 
     }
 }
 
+// All layers of a model in one launch.  Work is cut into quanta of PACK_Q elements (forward pack followed by dgrad
+// pack of a job); block b serves quantum b - first_block of the job whose block range contains it, so the launch is
+// balanced whatever the mix of layer sizes (1.7 K ... 9.4 M weights per layer).
+struct PackJob {
+    const float* w; void* wf; void* wd;     // wd may be NULL
+    int cin, cout, cin_pad, first_block;
+};
+constexpr int PACK_Q = 16384;
+template <typename T>
+__global__ __launch_bounds__(256) void pack_batch_kernel(const PackJob* __restrict__ jobs, int njobs) {
+    int jn = 0;
+    while (jn + 1 < njobs && jobs[jn + 1].first_block <= (int)blockIdx.x) ++jn;      // block-uniform scan, <= 64 jobs
+    const PackJob j = jobs[jn];
+    constexpr int KV = 16 / (int)sizeof(T);
+    const float* __restrict__ w = j.w;
+    T* __restrict__ wf = (T*)j.wf;
+    T* __restrict__ wd = (T*)j.wd;
+    const int cin = j.cin, cout = j.cout, cin_pad = j.cin_pad;
+    const int total_f = 9 * cin_pad * cout;
+    const int total = wd ? 2 * total_f : total_f;
+    const int lo = ((int)blockIdx.x - j.first_block) * PACK_Q;
+    const int hi = lo + PACK_Q < total ? lo + PACK_Q : total;
+    for (int e = lo + threadIdx.x; e < hi; e += 256) {
+        if (e < total_f) {
+            int kv = e % KV, r = e / KV;
+            int co = r % cout; r /= cout;
+            int kc = r % (cin_pad / KV), tap = r / (cin_pad / KV);
+            int ci = kc * KV + kv;
+            wf[e] = (T)(ci < cin ? w[((size_t)tap * cin + ci) * cout + co] : 0.f);
+        } else {
+            const int i = e - total_f;
+            int kv = i % KV, r = i / KV;
+            int ci = r % cin_pad; r /= cin_pad;
+            int kc = r % (cout / KV), tap = r / (cout / KV);
+            int co = kc * KV + kv;
+            wd[i] = (T)(ci < cin ? w[((size_t)(8 - tap) * cin + ci) * cout + co] : 0.f);
+        }
+    }
+}
+
 template <typename K>
 static void allow_big_lds(K kern) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -2012,6 +2052,22 @@ extern "C" int ad_conv3x3_pack(const float* w_hwio, int cin, int cout, int cin_p
     else
         pack_kernel<float><<<blocks, 256, 0, s>>>(w_hwio, cin, cout, cin_pad, (float*)w_fwd, (float*)w_dgrad);
     AD_LAUNCH_CHECK("ad_conv3x3_pack");
+    return AD_OK;
+}
+
+extern "C" size_t ad_conv3x3_pack_job_bytes(void) { return sizeof(PackJob); }
+
+extern "C" int ad_conv3x3_pack_quantum(void) { return PACK_Q; }
+
+extern "C" int ad_conv3x3_pack_batch(const void* jobs_dev, int njobs, int nblocks, int dtype, void* stream) {
+    AD_REQUIRE(dtype == AD_BF16 || dtype == AD_F32, "ad_conv3x3_pack_batch: bad dtype %d", dtype);
+    AD_REQUIRE(jobs_dev != nullptr && njobs > 0 && njobs <= 64 && nblocks > 0,
+               "ad_conv3x3_pack_batch: bad job table (%d jobs, %d blocks)", njobs, nblocks);
+    if (dtype == AD_BF16)
+        pack_batch_kernel<bf16_t><<<nblocks, 256, 0, (hipStream_t)stream>>>((const PackJob*)jobs_dev, njobs);
+    else
+        pack_batch_kernel<float><<<nblocks, 256, 0, (hipStream_t)stream>>>((const PackJob*)jobs_dev, njobs);
+    AD_LAUNCH_CHECK("ad_conv3x3_pack_batch");
     return AD_OK;
 }
 

@@ -344,12 +344,15 @@ class Model:
         return (cs.cin + g - 1) // g * g
 
     def _repack(self):
-        """Refresh the MFMA operand packs (compute dtype) from the fp32 master weights."""
-        for cs in self.convs.values():
-            if cs.k != 3:
-                continue
-            self._packs[cs.name] = ops.conv3x3_pack(self.param(cs.name + "/kernel"), self._cin_pad(cs), self.dtype,
-                                                    want_dgrad=cs.need_dgrad, out=self._packs.get(cs.name))
+        """Refresh the MFMA operand packs (compute dtype) from the fp32 master weights: one launch for all layers."""
+        batch = self.__dict__.get("_pack_batch")
+        if batch is None or batch.owner is not self.P:
+            layers = [(cs.name, self.param(cs.name + "/kernel"), self._cin_pad(cs), cs.need_dgrad)
+                      for cs in self.convs.values() if cs.k == 3]
+            batch = self._pack_batch = ops.PackBatch(layers, self.dtype, self.device)
+            batch.owner = self.P                        # the table holds pointers into this buffer
+            self._packs.update(batch.packs)
+        batch.run()
 
     # ------------------------------------------------------------------ forward / backward
     def _to_dev(self, a) -> torch.Tensor:

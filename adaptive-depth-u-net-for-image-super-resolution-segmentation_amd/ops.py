@@ -138,6 +138,42 @@ def conv3x3_pack(w_hwio: torch.Tensor, cin_pad: int, dtype: torch.dtype, want_dg
     return wf, wd
 
 
+class PackBatch:
+    """All conv layers of a model repacked by one launch (ad_conv3x3_pack_batch).  Allocates the operand tensors once;
+    `packs[name] = (w_fwd, w_dgrad)` keep their addresses, the job table lives in device memory."""
+
+    def __init__(self, layers, dtype: torch.dtype, device):
+        """layers: iterable of (name, w_hwio fp32 view [3,3,cin,cout], cin_pad, want_dgrad)."""
+        lib = _lib.load()
+        rec = np.dtype([("w", "<u8"), ("wf", "<u8"), ("wd", "<u8"), ("cin", "<i4"), ("cout", "<i4"), ("cin_pad", "<i4"),
+                        ("first_block", "<i4")])
+        assert rec.itemsize == lib.ad_conv3x3_pack_job_bytes()
+        quantum = lib.ad_conv3x3_pack_quantum()
+        nblocks = 0
+        self.packs = {}
+        self._keep = []
+        rows = []
+        for name, w, cin_pad, want_dgrad in layers:
+            kh, kw, cin, cout = w.shape
+            assert (kh, kw) == (3, 3) and w.dtype == torch.float32 and w.is_contiguous()
+            wf = torch.empty(9 * cin_pad * cout, dtype=dtype, device=device)
+            wd = torch.empty(9 * cout * cin_pad, dtype=dtype, device=device) if want_dgrad else None
+            self.packs[name] = (wf, wd)
+            self._keep.append(w)
+            rows.append((w.data_ptr(), wf.data_ptr(), wd.data_ptr() if wd is not None else 0, cin, cout, cin_pad, nblocks))
+            nblocks += -(-(9 * cin_pad * cout * (2 if want_dgrad else 1)) // quantum)
+        self.njobs = len(rows)
+        self.nblocks = nblocks
+        self.dtype = dtype
+        table = np.array(rows, dtype=rec)
+        self.table = torch.from_numpy(table.view(np.uint8).copy()).to(device)
+
+    def run(self):
+        with _timed("conv3x3_pack"):
+            check(_lib.load().ad_conv3x3_pack_batch(_p(self.table), self.njobs, self.nblocks, dt(self.dtype), _stream()),
+                  "ad_conv3x3_pack_batch")
+
+
 _conv_ws: dict = {}   # per-device scratch for the split-K path of tiny feature maps
 
 

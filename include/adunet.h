@@ -62,6 +62,15 @@ int ad_pad_channels(const float* x, void* y, int64_t npix, int c, int cpad, int 
 int ad_conv3x3_pack(const float* w_hwio, int cin, int cout, int cin_pad,
                     void* w_fwd, void* w_dgrad, int dtype, void* stream);
 
+/* The same for up to 64 layers of a model in ONE launch.  jobs_dev: device array of njobs records
+ *   struct { const float* w_hwio; void* w_fwd; void* w_dgrad (or NULL); int cin, cout, cin_pad, first_block; }
+ * (ad_conv3x3_pack_job_bytes() = 40).  A job owns ceil(elements / ad_conv3x3_pack_quantum()) consecutive blocks,
+ * elements = 9*cin_pad*cout (x2 with w_dgrad); first_block is the running sum, nblocks the total.  All layers share
+ * dtype.  The table is caller-owned and read at run time, so a captured hipGraph keeps using it. */
+size_t ad_conv3x3_pack_job_bytes(void);
+int ad_conv3x3_pack_quantum(void);
+int ad_conv3x3_pack_batch(const void* jobs_dev, int njobs, int nblocks, int dtype, void* stream);
+
 /* ------------------------------------------------------------ convolution -- */
 
 /* Conv2D 3x3, stride 1, padding "same" (+bias, +optional ReLU):

@@ -264,6 +264,26 @@ def test_conv3x3_ln_relu_fwd(device, case):
     assert torch.equal(z, z2) and torch.equal(act, act2) and torch.equal(mean, mean2) and torch.equal(rstd, rstd2)
 
 
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_pack_batch_equals_single_packs(device, dtype):
+    """One launch for all layers (ad_conv3x3_pack_batch) writes the same operand packs as ad_conv3x3_pack per layer."""
+    from adunet_amd import ops
+    g = torch.Generator(device=device).manual_seed(7)
+    gran = ops.cin_granule(dtype)
+    specs = [("a", 3, 64, gran, False), ("b", 64, 64, 64, True), ("c", 128, 64, 128, True), ("d", 64, 192, 64, True)]
+    flat = torch.rand(sum(9 * ci * co for _, ci, co, _, _ in specs), device=device, generator=g) - 0.5
+    layers, off = [], 0
+    for name, ci, co, pad, dgrad in specs:
+        layers.append((name, flat[off:off + 9 * ci * co].view(3, 3, ci, co), pad, dgrad))
+        off += 9 * ci * co
+    batch = ops.PackBatch(layers, dtype, device)
+    batch.run()
+    for name, w, pad, dgrad in layers:
+        wf, wd = ops.conv3x3_pack(w, pad, dtype, want_dgrad=dgrad)
+        assert torch.equal(batch.packs[name][0], wf)
+        assert (wd is None and batch.packs[name][1] is None) or torch.equal(batch.packs[name][1], wd)
+
+
 def test_conv3x3_batches_of_2gib_and_more_run_in_image_chunks(device, ws):
     """A batch whose tensors reach 2 GiB (32-bit buffer offsets of the wave-specialised kernels) is cut into runs of
     images inside the library: forward, fused LayerNorm forward and wgrad must equal the same calls on the runs."""
