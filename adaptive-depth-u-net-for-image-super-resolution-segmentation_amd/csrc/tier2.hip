@@ -48,15 +48,27 @@ __global__ __launch_bounds__(256) void colstats_kernel(const T* __restrict__ x, 
     }
 }
 
-// out0[ch] = sum_b part[b][0][ch] * scale0 (+ add0[ch]), out1[ch] = sum_b part[b][1][ch] * scale1
-__global__ void colstats_finish_kernel(const float* __restrict__ part, int nblocks, int c, float scale0, float scale1,
-                                       const float* __restrict__ add0, float* __restrict__ out0, float* __restrict__ out1) {
-    int ch = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ch >= c) return;
-    float a = 0.f, b = 0.f;
-    for (int k = 0; k < nblocks; ++k) { a += part[(size_t)k * 2 * c + ch]; b += part[(size_t)k * 2 * c + c + ch]; }
-    if (out0) out0[ch] = a * scale0 + (add0 ? add0[ch] : 0.f);
-    if (out1) out1[ch] = b * scale1;
+// out0[ch] = sum_b part[b][0][ch] * scale0 (+ add0[ch]), out1[ch] = sum_b part[b][1][ch] * scale1.
+// The job is latency bound (nblocks x 2c floats): a block folds 4 of the 2c columns with 64 row groups through LDS in a
+// fixed order (deterministic); one thread per channel walking all the blocks took 50-140 us per call.
+__global__ __launch_bounds__(256) void colstats_finish_kernel(const float* __restrict__ part, int nblocks, int c, float scale0,
+                                                              float scale1, const float* __restrict__ add0,
+                                                              float* __restrict__ out0, float* __restrict__ out1) {
+    __shared__ float sm[64][5];
+    const int tid = threadIdx.x, cl = tid & 3, rg = tid >> 2;
+    const int i = blockIdx.x * 4 + cl;              // column of the [nblocks][2c] partial matrix
+    float s = 0.f;
+    if (i < 2 * c)
+        for (int b = rg; b < nblocks; b += 64) s += part[(size_t)b * 2 * c + i];
+    sm[rg][cl] = s;
+    __syncthreads();
+    if (rg == 0 && i < 2 * c) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 64; ++r) t += sm[r][cl];
+        if (i < c) { if (out0) out0[i] = t * scale0 + (add0 ? add0[i] : 0.f); }
+        else if (out1) out1[i - c] = t * scale1;
+    }
 }
 
 // rstd = rsqrt(var + eps); moving <- moving * m + batch * (1 - m)   (Keras BatchNormalization, momentum 0.99)
@@ -69,7 +81,8 @@ __global__ void bn_finalize_kernel(const float* __restrict__ mean, const float* 
     if (mvar) mvar[ch] = mvar[ch] * momentum + var[ch] * (1.f - momentum);
 }
 
-// y = relu?((x - mean) * rstd * gamma + beta)
+// y = relu?((x - mean) * rstd * gamma + beta).  The grid stride (gridDim.x * 256) is a multiple of the vectors per pixel
+// (c / EPT divides 256: chan_ok), so a thread always sees the same EPT channels and keeps their parameters in registers.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ mean,
                                                        const float* __restrict__ rstd, const float* __restrict__ gamma,
@@ -78,16 +91,21 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
     constexpr int EPT = ElemTraits<T>::EPT;
     const int vecs = c / EPT;
     const int64_t total = npix * vecs;
+    const int v = (int)(((int64_t)blockIdx.x * 256 + threadIdx.x) % vecs);
+    float mu[EPT], rs[EPT], ga[EPT], be[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int ch = v * EPT + e;
+        mu[e] = mean[ch]; rs[e] = rstd[ch]; ga[e] = gamma[ch]; be[e] = beta[ch];
+    }
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int v = (int)(i % vecs);
         Vec16<T> ld, st;
         float f[EPT], o[EPT];
         ld.load(x + i * EPT);
         ld.to_f32(f);
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
-            const int ch = v * EPT + e;
-            float t = (f[e] - mean[ch]) * rstd[ch] * gamma[ch] + beta[ch];
+            const float t = (f[e] - mu[e]) * rs[e] * ga[e] + be[e];
             o[e] = relu ? fmaxf(t, 0.f) : t;
         }
         st.from_f32(o);
@@ -145,7 +163,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     }
 }
 
-// backward pass 2: dx = gamma * rstd * (dyl - dbeta/m - xhat * dgamma/m)
+// backward pass 2: dx = gamma * rstd * (dyl - dbeta/m - xhat * dgamma/m); per-thread channel parameters as bn_apply_kernel
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -156,8 +174,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     const int vecs = c / EPT;
     const int64_t total = npix * vecs;
     const float inv_m = 1.0f / (float)npix;
+    const int v = (int)(((int64_t)blockIdx.x * 256 + threadIdx.x) % vecs);
+    float mu[EPT], rs[EPT], ga[EPT], be[EPT], k0[EPT], k1[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int ch = v * EPT + e;
+        mu[e] = mean[ch]; rs[e] = rstd[ch]; ga[e] = gamma[ch]; be[e] = beta[ch];
+        k0[e] = dbeta[ch] * inv_m; k1[e] = dgamma[ch] * inv_m;
+    }
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int v = (int)(i % vecs);
         Vec16<T> l0, l1, st;
         float f[EPT], d[EPT], o[EPT];
         l0.load(x + i * EPT);
@@ -166,10 +191,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         l1.to_f32(d);
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
-            const int ch = v * EPT + e;
-            float h = (f[e] - mean[ch]) * rstd[ch];
-            float dl = (relu && !(h * gamma[ch] + beta[ch] > 0.f)) ? 0.f : d[e];
-            o[e] = gamma[ch] * rstd[ch] * (dl - dbeta[ch] * inv_m - h * dgamma[ch] * inv_m);
+            const float h = (f[e] - mu[e]) * rs[e];
+            const float dl = (relu && !(h * ga[e] + be[e] > 0.f)) ? 0.f : d[e];
+            o[e] = ga[e] * rs[e] * (dl - k0[e] - h * k1[e]);
         }
         st.from_f32(o);
         st.store(dx + i * EPT);
@@ -411,7 +435,7 @@ static int ew_blocks(int64_t total) {
     return (int)(b < 16384 ? b : 16384);
 }
 
-static bool chan_ok(int c, int ept) { return c > 0 && c % ept == 0 && (c / ept) <= 256; }
+static bool chan_ok(int c, int ept) { return c > 0 && c % ept == 0 && (c / ept) <= 256 && 256 % (c / ept) == 0; }
 
 template <typename T>
 int colstats(const void* x, const float* shift, float* part, int64_t npix, int c, hipStream_t s, int* nblocks) {
@@ -444,10 +468,10 @@ extern "C" int ad_batchnorm_relu_fwd_train(const void* z, const float* gamma, co
     // pass 1: mean; pass 2: centred second moment (biased variance, as Keras)
     rc = dtype == AD_BF16 ? colstats<bf16_t>(z, nullptr, part, npix, c, s, &nb) : colstats<float>(z, nullptr, part, npix, c, s, &nb);
     if (rc) return rc;
-    colstats_finish_kernel<<<(c + 255) / 256, 256, 0, s>>>(part, nb, c, 1.0f / (float)npix, 0.f, nullptr, save_mean, nullptr);
+    colstats_finish_kernel<<<(2 * c + 3) / 4, 256, 0, s>>>(part, nb, c, 1.0f / (float)npix, 0.f, nullptr, save_mean, nullptr);
     rc = dtype == AD_BF16 ? colstats<bf16_t>(z, save_mean, part, npix, c, s, &nb) : colstats<float>(z, save_mean, part, npix, c, s, &nb);
     if (rc) return rc;
-    colstats_finish_kernel<<<(c + 255) / 256, 256, 0, s>>>(part, nb, c, 0.f, 1.0f / (float)npix, nullptr, nullptr, save_var);
+    colstats_finish_kernel<<<(2 * c + 3) / 4, 256, 0, s>>>(part, nb, c, 0.f, 1.0f / (float)npix, nullptr, nullptr, save_var);
     bn_finalize_kernel<<<(c + 255) / 256, 256, 0, s>>>(save_mean, save_var, save_rstd, moving_mean, moving_var, momentum, eps, c);
     const int blocks = ew_blocks(npix * (c / ept));
     if (dtype == AD_BF16)
@@ -493,7 +517,7 @@ extern "C" int ad_batchnorm_relu_bwd(const void* dy, const void* z, const float*
         bn_bwd_reduce_kernel<bf16_t><<<nb, 256, lds, s>>>((const bf16_t*)dy, (const bf16_t*)z, save_mean, save_rstd, gamma, beta, part, npix, c, relu);
     else
         bn_bwd_reduce_kernel<float><<<nb, 256, lds, s>>>((const float*)dy, (const float*)z, save_mean, save_rstd, gamma, beta, part, npix, c, relu);
-    colstats_finish_kernel<<<(c + 255) / 256, 256, 0, s>>>(part, nb, c, 1.f, 1.f, nullptr, dgamma, dbeta);
+    colstats_finish_kernel<<<(2 * c + 3) / 4, 256, 0, s>>>(part, nb, c, 1.f, 1.f, nullptr, dgamma, dbeta);
     const int blocks = ew_blocks(npix * vecs);
     if (dtype == AD_BF16)
         bn_bwd_apply_kernel<bf16_t><<<blocks, 256, 0, s>>>((const bf16_t*)dy, (const bf16_t*)z, save_mean, save_rstd, gamma, beta, dgamma, dbeta, (bf16_t*)dz, npix, c, relu);
@@ -512,7 +536,7 @@ extern "C" int ad_colsum(const void* x, float* out, int64_t npix, int c, void* w
     int nb = 0;
     int rc = dtype == AD_BF16 ? colstats<bf16_t>(x, nullptr, (float*)ws, npix, c, s, &nb) : colstats<float>(x, nullptr, (float*)ws, npix, c, s, &nb);
     if (rc) return rc;
-    colstats_finish_kernel<<<(c + 255) / 256, 256, 0, s>>>((const float*)ws, nb, c, 1.f, 0.f, nullptr, out, nullptr);
+    colstats_finish_kernel<<<(2 * c + 3) / 4, 256, 0, s>>>((const float*)ws, nb, c, 1.f, 0.f, nullptr, out, nullptr);
     AD_LAUNCH_CHECK("ad_colsum");
     return AD_OK;
 }
