@@ -108,6 +108,51 @@ def test_conv3x3_wgrad(device, ws, dtype, shape):
     assert torch.equal(dw, dw2), "wgrad must be bitwise deterministic"
 
 
+def _random_conv_shapes(count):
+    rng = np.random.default_rng(2026)
+    out = []
+    for _ in range(count):
+        n = int(rng.integers(1, 6))
+        h, w = int(rng.integers(1, 40)), int(rng.integers(1, 40))
+        if (h == 1) != (w == 1):           # maps with exactly one unit extent are rejected by the library (documented)
+            h = w = 1
+        c1 = 32 * int(rng.integers(1, 4))
+        c2 = 32 * int(rng.integers(0, 3))
+        cout = 64 * int(rng.integers(1, 3))
+        out.append((n, h, w, c1, c2, cout))
+    return out
+
+
+@pytest.mark.parametrize("shape", _random_conv_shapes(12))
+def test_conv3x3_random_shapes_all_three_passes(device, ws, shape):
+    """Seeded random shapes (odd extents, 1..5 images, concat or not): forward, dgrad and wgrad against the oracle."""
+    from adunet_amd import ops
+    n, h, w, c1, c2, cout = shape
+    cin = c1 + c2
+    rng = np.random.default_rng(hash(shape) % 2**31)
+    x = rnd(rng.standard_normal((n, h, w, cin)), BF16)
+    wk = rnd(rng.standard_normal((3, 3, cin, cout)) * 0.1, BF16)
+    b = rng.standard_normal(cout).astype(np.float32).astype(np.float64)
+    dz = rnd(rng.standard_normal((n, h, w, cout)), BF16)
+    x1 = to_dev(x[..., :c1], BF16, device)
+    x2 = to_dev(x[..., c1:], BF16, device) if c2 else None
+    wf, wd = ops.conv3x3_pack(torch.tensor(wk, dtype=F32, device=device), cin, BF16)
+    y = ops.conv3x3_fwd(x1, x2, wf, torch.tensor(b, dtype=F32, device=device), cout)
+    assert relerr(y, ref.conv2d_same_fwd(x, wk, b)) < TOL[BF16]
+    want_dx, want_dw, _ = ref.conv2d_same_bwd(x, wk, dz)
+    dzd = to_dev(dz, BF16, device)
+    if cin % 64 == 0 and (c2 == 0 or c1 % 64 == 0):     # dgrad writes 64-channel output blocks (and splits on them)
+        if c2:
+            d1, d2 = ops.conv3x3_fwd(dzd, None, wd, None, cin, split=c1)
+            got = torch.cat([d1, d2], dim=-1)
+        else:
+            got = ops.conv3x3_fwd(dzd, None, wd, None, cin)
+        assert relerr(got, want_dx) < TOL[BF16]
+    dw = torch.full((3, 3, cin, cout), float("nan"), dtype=F32, device=device)
+    ops.conv3x3_wgrad(x1, x2, dzd, dw, cin, ws)
+    assert relerr(dw, want_dw) < 1e-3
+
+
 # ---- large launches: the wave-specialised kernels (weights-resident forward/dgrad, 64-channel-block wgrad) only run
 # when a launch has >= 4 tiles per CU, far beyond what the NumPy oracle can convolve whole.  A 3x3 conv is local, so
 # the oracle is evaluated on windows (corners, edges, ragged last tiles, interior) and, for the whole tensor, the
