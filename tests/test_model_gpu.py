@@ -240,3 +240,17 @@ def test_fit_replays_graphs_and_matches_eager_fit(device, monkeypatch):
     assert results[0][2] == results[1][2] == 8
     assert results[0][0] == results[1][0]
     assert torch.equal(results[0][1], results[1][1])
+
+
+def test_two_rank_data_parallel_on_one_gpu_equals_single_process(device):
+    """World size 2 on real device tensors (gloo transport; RCCL refuses two ranks on one GPU): each rank trains on half of
+    every batch, eagerly and through the segmented graph replay; both must equal one process on the whole batch."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29673", os.path.join(root, "tools", "dp2_gloo_gpu_check.py")]
+    res = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert "eager == graph bitwise: True" in res.stdout
