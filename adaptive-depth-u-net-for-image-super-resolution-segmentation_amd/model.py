@@ -513,6 +513,21 @@ class Model:
         _, loss, psnr, _ = self.forward_loss(lr_img, hr_img, keep=False)
         return loss, psnr
 
+    # ---- hooks of the graph-replayed step (overridden by the segmentation model)
+    def _graph_inputs(self, a, b):
+        """Device tensors of one batch, in the layout the captured step reads."""
+        return self._to_dev(a), self._to_dev(b)
+
+    def _graph_forward_backward(self, sx: torch.Tensor, st: torch.Tensor):
+        """Forward, loss and backward on the static inputs; returns the device scalars the step reports."""
+        out, loss, psnr, (tape, x, t) = self.forward_loss(sx, st, keep=True)
+        self._backward(tape, x, t, 1.0 / float(x.numel()))
+        return loss, psnr
+
+    def _graph_extra_state(self) -> List[torch.Tensor]:
+        """Tensors besides P / M / V that a train step changes (put back after a capture-only warm-up)."""
+        return []
+
     def make_graphed_train_step(self, lr_example, hr_example, capture_only: bool = False):
         """Capture one full train step (forward, loss, backward, Adam, repack: ~190 launches) into hipGraphs and
         return `step(lr, hr) -> (loss, psnr)` that copies the batch into the graphs' static inputs and replays them.
@@ -532,7 +547,7 @@ class Model:
         if self.grad_sync is not None and dp is None:
             raise RuntimeError("graph capture needs the DataParallel object that installed the gradient hooks")
         self._require_device()
-        sx, st = self._to_dev(lr_example).clone(), self._to_dev(hr_example).clone()
+        sx, st = (t.clone() for t in self._graph_inputs(lr_example, hr_example))
         alpha_dev = torch.zeros(1, dtype=torch.float32, device=self.device)
         opt = self.optimizer
         gscale = 1.0 / dp.world if dp is not None else 1.0
@@ -561,8 +576,7 @@ class Model:
                 seg_begin()
 
         def body(capturing: bool):
-            out, loss, psnr, (tape, x, t) = self.forward_loss(sx, st, keep=True)
-            self._backward(tape, x, t, 1.0 / float(x.numel()))
+            outputs = self._graph_forward_backward(sx, st)
             if dp is not None:
                 if capturing:
                     rest = dp.buckets[cap["next"]:]
@@ -577,13 +591,15 @@ class Model:
             ops.adam_step_dev(self.P, self.G, self.M, self.V, alpha_dev, b1=opt.beta_1, b2=opt.beta_2, eps=opt.epsilon,
                               gscale=gscale)
             self._repack()
-            return loss, psnr
+            return outputs
 
         def set_alpha():
             opt.iterations += 1
             alpha_dev.fill_(ops.adam_alpha(opt.lr_at(opt.iterations - 1), opt.beta_1, opt.beta_2, opt.iterations))
 
-        saved_state = (self.P.clone(), self.M.clone(), self.V.clone(), opt.iterations) if capture_only else None
+        extra = self._graph_extra_state()        # e.g. BatchNorm moving statistics (subclasses)
+        saved_state = ((self.P.clone(), self.M.clone(), self.V.clone(), opt.iterations, [t.clone() for t in extra])
+                       if capture_only else None)
         side = torch.cuda.Stream(device=self.device)       # warm-up on a side stream, as torch's capture recipe asks
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -595,7 +611,7 @@ class Model:
         if dp is None:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                loss, psnr = body(True)
+                outputs = body(True)
             segs.append((graph, [], False))
         else:
             saved = self.grad_ready
@@ -603,7 +619,7 @@ class Model:
             try:
                 with torch.cuda.stream(side):
                     seg_begin()
-                    loss, psnr = body(True)
+                    outputs = body(True)
                     seg_end([])
             finally:
                 self.grad_ready = saved
@@ -621,6 +637,8 @@ class Model:
         if capture_only:
             self.P.copy_(saved_state[0]); self.M.copy_(saved_state[1]); self.V.copy_(saved_state[2])
             opt.iterations = saved_state[3]
+            for t, saved in zip(extra, saved_state[4]):
+                t.copy_(saved)
             self._repack()
             torch.cuda.synchronize()
         else:
@@ -628,11 +646,12 @@ class Model:
             run()
 
         def step(lr_img, hr_img):
-            sx.copy_(self._to_dev(lr_img), non_blocking=True)
-            st.copy_(self._to_dev(hr_img), non_blocking=True)
+            a, b = self._graph_inputs(lr_img, hr_img)
+            sx.copy_(a, non_blocking=True)
+            st.copy_(b, non_blocking=True)
             set_alpha()
             run()
-            return loss, psnr
+            return outputs
 
         step.graph = segs[0][0]
         step.segments = segs
@@ -659,8 +678,9 @@ class Model:
     def _fit_step(self, lr_img, hr_img):
         """One training step of fit(): replayed from a hipGraph captured per batch shape on the GPU (bitwise the eager
         step, minus ~2 ms of Python launch overhead); eager on other devices or with ADUNET_EAGER_FIT=1."""
-        if os.environ.get("ADUNET_EAGER_FIT") == "1" or type(self).train_on_batch is not Model.train_on_batch:
-            return self.train_on_batch(lr_img, hr_img)      # subclasses with their own step (segmentation) stay eager
+        if os.environ.get("ADUNET_EAGER_FIT") == "1" or (type(self).train_on_batch is not Model.train_on_batch
+                                                         and type(self)._graph_forward_backward is Model._graph_forward_backward):
+            return self.train_on_batch(lr_img, hr_img)      # a subclass with its own step and no graph hooks stays eager
         self._require_device()
         if self.device.type != "cuda":
             return self.train_on_batch(lr_img, hr_img)

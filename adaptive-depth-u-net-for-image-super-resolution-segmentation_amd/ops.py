@@ -476,15 +476,21 @@ def pixel_shuffle2(x, to_space: bool):
     return y
 
 
-def conv_transpose2x2s2_pack(w_t: torch.Tensor, dtype: torch.dtype):
+def conv_transpose2x2s2_pack(w_t: torch.Tensor, dtype: torch.dtype, out=None):
     """Keras Conv2DTranspose kernel [2,2,Cout,Cin] -> operand packs of the equivalent pointwise GEMM Cin -> 4*Cout
-    (output block a*2+b holds W[a,b]^T).  Returns (w_fwd, w_dgrad)."""
+    (output block a*2+b holds W[a,b]^T).  Returns (w_fwd, w_dgrad, staging).  `out` = a previous result: the packs and
+    the fp32 staging tensor are refreshed in place, so they keep their addresses (a captured hipGraph relies on it)."""
     kh, kw, cout, cin = w_t.shape
     assert (kh, kw) == (2, 2)
     wg = w_t.permute(3, 0, 1, 2).reshape(cin, 4 * cout)               # [Cin][(a,b,o)]
-    w9 = torch.zeros((3, 3, cin, 4 * cout), dtype=torch.float32, device=w_t.device)
-    w9[1, 1] = wg                                                     # pointwise = centre tap of the 3x3 operand
-    return conv3x3_pack(w9.contiguous(), cin, dtype, want_dgrad=True)
+    if out is not None:
+        wf, wd, w9 = out
+    else:
+        wf = wd = None
+        w9 = torch.zeros((3, 3, cin, 4 * cout), dtype=torch.float32, device=w_t.device)
+    w9[1, 1].copy_(wg)                                                # pointwise = centre tap of the 3x3 operand
+    wf, wd = conv3x3_pack(w9, cin, dtype, want_dgrad=True, out=(wf, wd) if wf is not None else None)
+    return wf, wd, w9
 
 
 def conv_transpose2x2s2_fwd(x, w_fwd, bias, cout: int):

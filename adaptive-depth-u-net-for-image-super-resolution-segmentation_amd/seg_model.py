@@ -236,7 +236,7 @@ class SegModel(Model):
         Model._repack(self)
         for t in self.ups:
             if t is not None:
-                self._tpacks[t] = ops.conv_transpose2x2s2_pack(self.param(t + "/kernel"), self.dtype)
+                self._tpacks[t] = ops.conv_transpose2x2s2_pack(self.param(t + "/kernel"), self.dtype, out=self._tpacks.get(t))
 
     # ------------------------------------------------------------------ forward / backward
     def _up_tables(self, h: int, transposed: bool):
@@ -390,6 +390,18 @@ class SegModel(Model):
                       b1=opt.beta_1, b2=opt.beta_2, eps=opt.epsilon, gscale=gscale)
         self._repack()
         return self._metrics_from(sums, float(m.numel()))
+
+    # ---- graph-replayed train step (Model.make_graphed_train_step / fit): same hooks, segmentation flavour
+    def _graph_inputs(self, img, mask):
+        return self._to_dev(img), self._to_dev_mask(mask)
+
+    def _graph_forward_backward(self, sx, sm):
+        prob, sums, tape = self._forward_seg(sx, sm, training=True, keep=True)
+        self._backward_seg(tape, sm)
+        return self._metrics_from(sums, float(sm.numel()))
+
+    def _graph_extra_state(self):
+        return [self.S]                     # BatchNorm moving statistics
 
     def test_on_batch(self, img, mask):
         self._require_device()

@@ -101,3 +101,25 @@ def test_seg_builders_contract():
     with pytest.raises(NotImplementedError):
         S.build_unet(128, 19, 64, 4)
     assert S.PROTOCOLS["B"].loss_builder().dice_weight == 1.0 and S.PROTOCOLS["B"].batch_size == 16
+
+
+@pytest.mark.parametrize("kind", ["bn", "ln"])
+def test_seg_fit_replays_graphs_and_matches_eager_fit(device, kind, monkeypatch):
+    """fit() of the segmentation models goes through the same per-shape hipGraph replay as the SR model (BatchNorm moving
+    statistics included in what the capture-only warm-up puts back): weights, state and history equal the eager fit."""
+    results = []
+    for eager in ("1", "0"):
+        monkeypatch.setenv("ADUNET_EAGER_FIT", eager)
+        S, model, oracle, params, state, img, mask = build(kind, torch.bfloat16, device)
+        proto = S.PROTOCOLS["A"]
+        model.compile(optimizer=S.build_optimizer(proto, steps_per_epoch=3, epochs=2), loss=proto.loss_builder())
+        rng = np.random.default_rng(9)
+        data = [(rng.random((3, 32, 32, 3), dtype=np.float32), (rng.random((3, 32, 32, 1)) < 0.4).astype(np.float32))
+                for _ in range(3)]
+        hist = model.fit(data, epochs=2, verbose=0)
+        results.append((hist.history["loss"], model.P.clone(), model.S.clone(), model.optimizer.iterations))
+        if eager == "0":
+            assert len(model._graph_steps) == 1
+    assert results[0][3] == results[1][3] == 6
+    assert results[0][0] == results[1][0]
+    assert torch.equal(results[0][1], results[1][1]) and torch.equal(results[0][2], results[1][2])

@@ -75,7 +75,7 @@ def test_conv_transpose2x2s2(device, ws, dtype):
     wt = rnd(rng.standard_normal((2, 2, cout, cin)) * 0.1, dtype)
     b = rng.standard_normal(cout).astype(np.float32).astype(np.float64)
     want = ref.conv_transpose2x2s2_fwd(x, wt, b)
-    wf, wd = ops.conv_transpose2x2s2_pack(torch.tensor(wt, dtype=F32, device=device), dtype)
+    wf, wd, _ = ops.conv_transpose2x2s2_pack(torch.tensor(wt, dtype=F32, device=device), dtype)
     xd = to_dev(x, dtype, device)
     y = ops.conv_transpose2x2s2_fwd(xd, wf, torch.tensor(b, dtype=F32, device=device), cout)
     assert tuple(y.shape) == (n, 2 * h, 2 * w, cout) and relerr(y, want) < TOL[dtype]

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Throughput of the rows next to the headline: SR inference (forward only) and the two segmentation models' train
-step (tier 2: BatchNorm / max-pool / bilinear x2 and LayerNorm / Conv2DTranspose), bf16, eager launches."""
+step (tier 2: BatchNorm / max-pool / bilinear x2 and LayerNorm / Conv2DTranspose), bf16, eager and graph replay."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -33,5 +33,8 @@ for name, build, b in (("adaptive_unet depth4 c64 (BN, maxpool, bilinear)", lamb
     img = rng.random((b, 256, 256, 3), dtype=np.float32)
     mask = (rng.random((b, 256, 256, 1)) < 0.35).astype(np.float32)
     dt = timeit(lambda: m.train_on_batch(img, mask))
-    print(f"seg train {name} P256 b{b}: {b / dt:8.1f} img/s  {dt * 1e3:6.2f} ms")
-    del m
+    step = m.make_graphed_train_step(img, mask)
+    xi, xm = m._graph_inputs(img, mask)
+    dg = timeit(lambda: step(xi, xm))
+    print(f"seg train {name} P256 b{b}: eager {b / dt:8.1f} img/s {dt * 1e3:6.2f} ms | graph replay {b / dg:8.1f} img/s {dg * 1e3:6.2f} ms")
+    del m, step
