@@ -62,6 +62,18 @@ def test_antialiased_resize_matches_torch(sizes):
     assert np.allclose(ops.resize_aa_bwd(dy, i, i), xt.grad.numpy(), atol=5e-6)
 
 
+@pytest.mark.parametrize("sizes", [(37, 23), (64, 16), (256, 154), (40, 10), (23, 37), (16, 64)])
+def test_antialiased_resize_matches_pillow(sizes):
+    """A third implementation of the same triangle-filter resize (Pillow's BILINEAR, which widens the support when
+    shrinking, as tf.image.resize(antialias=True) does): float32 inside Pillow, hence the 5e-5 bound."""
+    Image = pytest.importorskip("PIL.Image")
+    i, o = sizes
+    x = RNG.standard_normal((i, i)).astype(np.float32)
+    want = np.asarray(Image.fromarray(x, mode="F").resize((o, o), resample=Image.BILINEAR))
+    got = ops.resize_aa_fwd(x[None, :, :, None].astype(np.float64), o, o)[0, :, :, 0]
+    assert np.abs(got - want).max() < 5e-5
+
+
 def test_upsample_is_plain_half_pixel_bilinear():
     x = RNG.standard_normal((1, 6, 6, 2))
     want = F.interpolate(nchw(t(x)), scale_factor=2, mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
