@@ -89,3 +89,26 @@ def test_metrics_definitions():
     assert np.allclose(metrics.msssim_per_image(big, big), 1.0, atol=1e-6)
     noisy = np.clip(big + 0.1 * rng.standard_normal(big.shape).astype(np.float32), 0, 1)
     assert 0 < float(metrics.msssim_per_image(big, noisy)[0]) < 1
+
+
+def test_ssim_against_a_direct_2d_gaussian_filter():
+    """tf.image.ssim restated twice: metrics.py filters separably; here the 11x11 sigma-1.5 window is applied as one 2-D
+    VALID correlation (scipy.signal) and the SSIM map is formed from scratch."""
+    from scipy.signal import correlate2d
+    from adunet_amd import metrics
+    rng = np.random.default_rng(4)
+    a = rng.random((2, 40, 37, 1))
+    b = np.clip(a + 0.1 * rng.standard_normal(a.shape), 0, 1)
+    x = np.arange(11) - 5.0
+    g = np.exp(-x * x / (2 * 1.5 ** 2))
+    g2 = np.outer(g, g)
+    g2 /= g2.sum()
+    want = []
+    for i in range(2):
+        p, q = a[i, :, :, 0], b[i, :, :, 0]
+        f = lambda m: correlate2d(m, g2, mode="valid")
+        mp, mq = f(p), f(q)
+        vp, vq, cov = f(p * p) - mp * mp, f(q * q) - mq * mq, f(p * q) - mp * mq
+        c1, c2 = 0.01 ** 2, 0.03 ** 2
+        want.append((((2 * mp * mq + c1) * (2 * cov + c2)) / ((mp * mp + mq * mq + c1) * (vp + vq + c2))).mean())
+    assert np.allclose(metrics.ssim_per_image(a, b), np.asarray(want), atol=1e-6)
