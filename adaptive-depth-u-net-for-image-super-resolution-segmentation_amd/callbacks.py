@@ -26,14 +26,16 @@ class EarlyStopping(Callback):
             return
         if self._better(v):
             self.best, self.wait = v, 0
-            if self.restore:
-                self.best_weights = self.model.P.clone()
+            if self.restore:      # trainable parameters AND the non-trainable state (BatchNorm moving statistics)
+                self.best_weights = (self.model.P.clone(), [t.clone() for t in self.model._graph_extra_state()])
         else:
             self.wait += 1
             if self.wait >= self.patience:
                 self.model.stop_training = True
                 if self.restore and self.best_weights is not None:
-                    self.model.P.copy_(self.best_weights)
+                    self.model.P.copy_(self.best_weights[0])
+                    for t, saved in zip(self.model._graph_extra_state(), self.best_weights[1]):
+                        t.copy_(saved)
                     self.model._repack()
 
 

@@ -76,26 +76,31 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ xh,
     }
 }
 
-// stats[0] = sum of all loss partials; sqerr[img] = sum of that image's squared-error partials
+// stats[0] = sum of all loss partials, stats[2] = their mean over all elements; stats[1] = mean over the images of tf.image.psnr(max_val = 1) = -10 log10(MSE)
+// (+inf at MSE 0, as TensorFlow returns); sqerr[img] = sum of that image's squared-error partials
 __global__ __launch_bounds__(256) void head_stats_kernel(const float* __restrict__ part, int n, int bpi,
-                                                         float* __restrict__ stats, float* __restrict__ sqerr) {
+                                                         float* __restrict__ stats, float* __restrict__ sqerr,
+                                                         float elems_per_img) {
     __shared__ float sm[256];
+    __shared__ float sp[256];
     const int tid = threadIdx.x;
     float s = 0.f;
     for (int i = tid; i < n * bpi; i += 256) s += part[(size_t)i * 2];
+    float ps = 0.f;
+    for (int img = tid; img < n; img += 256) {
+        float q = 0.f;
+        for (int k = 0; k < bpi; ++k) q += part[((size_t)img * bpi + k) * 2 + 1];
+        if (sqerr) sqerr[img] = q;
+        ps += -10.f * log10f(q / elems_per_img);
+    }
     sm[tid] = s;
+    sp[tid] = ps;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
-        if (tid < o) sm[tid] += sm[tid + o];
+        if (tid < o) { sm[tid] += sm[tid + o]; sp[tid] += sp[tid + o]; }
         __syncthreads();
     }
-    if (tid == 0 && stats) stats[0] = sm[0];
-    if (sqerr)
-        for (int img = tid; img < n; img += 256) {
-            float q = 0.f;
-            for (int k = 0; k < bpi; ++k) q += part[((size_t)img * bpi + k) * 2 + 1];
-            sqerr[img] = q;
-        }
+    if (tid == 0 && stats) { stats[0] = sm[0]; stats[1] = sp[0] / (float)n; stats[2] = sm[0] / ((float)n * elems_per_img); }
 }
 
 template <typename T, int G>
@@ -245,7 +250,7 @@ extern "C" int ad_head_fwd(const void* xh, const float* w, const float* b, const
     }
     AD_LAUNCH_CHECK("ad_head_fwd");
     if (target) {
-        head_stats_kernel<<<1, 256, 0, s>>>(part, n, bpi, stats, sqerr);
+        head_stats_kernel<<<1, 256, 0, s>>>(part, n, bpi, stats, sqerr, (float)pix_per_img * 3.f);
         AD_LAUNCH_CHECK("head_stats");
     }
     return AD_OK;

@@ -37,9 +37,27 @@ class EvalResults:
     samples: int
 
 
-def load_checkpoint_model(model_path: Path, scale: float, patch_size: int, depth_override: int | None, **build_kw):
-    """evaluate_model.py:57-91 -- rebuild the architecture and load the weights."""
-    model, _ = build_super_resolution_unet(scale=scale, input_size=patch_size, depth_override=depth_override, **build_kw)
+def checkpoint_compute_dtype(model_path: Path):
+    """The compute dtype a checkpoint was trained under (safetensors metadata written by Model.save_weights), or None."""
+    import torch
+    if str(model_path).endswith(".safetensors") and Path(model_path).exists():
+        from safetensors import safe_open
+        with safe_open(str(model_path), framework="numpy") as fh:
+            name = (fh.metadata() or {}).get("compute_dtype")
+        return {"float32": torch.float32, "bfloat16": torch.bfloat16, "float16": torch.float16}.get(name)
+    return None
+
+
+def load_checkpoint_model(model_path: Path, scale: float, patch_size: int, depth_override: int | None, dtype=None,
+                          **build_kw):
+    """evaluate_model.py:57-91 -- rebuild the architecture and load the weights.  Keras reloads a model under the
+    policy it was saved with (float32 unless --mixed_precision): here the policy travels in the checkpoint metadata;
+    `dtype` overrides it, and a checkpoint without metadata is evaluated in float32."""
+    import torch
+    if dtype is None:
+        dtype = checkpoint_compute_dtype(model_path) or torch.float32
+    model, _ = build_super_resolution_unet(scale=scale, input_size=patch_size, depth_override=depth_override, dtype=dtype,
+                                           **build_kw)
     try:
         model.load_weights(str(model_path))
     except FileNotFoundError:
@@ -116,6 +134,9 @@ def parse_args(argv=None) -> argparse.Namespace:
     p.add_argument("--output-dir", type=Path, default=Path("evaluation"))
     p.add_argument("--run-name", type=str, default=None)
     p.add_argument("--skip-per-image", action="store_true")
+    p.add_argument("--dtype", choices=["float32", "bfloat16", "float16"], default=None,
+                   help="compute dtype (default: the one recorded in the checkpoint, else float32)")
+    p.add_argument("--mixed-precision", action="store_true", help="shorthand for --dtype bfloat16")
     return p.parse_args(argv)
 
 
@@ -131,7 +152,11 @@ def main(argv=None) -> None:
         raise ValueError(f"No high-resolution PNG files found in {hr_dir}")
     eval_ds, total, labels = make_eval_patch_dataset(hr_files, patch_size=args.patch_size, scale=args.scale,
                                                      batch_size=args.batch_size, stride=args.eval_stride)
-    model = load_checkpoint_model(args.model_path.expanduser(), args.scale, args.patch_size, args.depth_override)
+    import torch
+    dtype = {"float32": torch.float32, "bfloat16": torch.bfloat16, "float16": torch.float16, None: None}[args.dtype]
+    if dtype is None and args.mixed_precision:
+        dtype = torch.bfloat16
+    model = load_checkpoint_model(args.model_path.expanduser(), args.scale, args.patch_size, args.depth_override, dtype=dtype)
     shave = infer_eval_shave(args.scale, args.eval_shave)
     summary, per_patch = evaluate(model, eval_ds, eval_shave=shave)
     attach_filenames(per_patch, labels)
@@ -146,6 +171,7 @@ def main(argv=None) -> None:
               "patch_size": args.patch_size, "eval_stride": args.eval_stride or args.patch_size,
               "batch_size": args.batch_size, "limit": args.limit, "eval_shave": shave,
               "depth_override": args.depth_override, "samples": summary.samples, "images": len(hr_files),
+              "compute_dtype": str(model.dtype).replace("torch.", ""),
               "created_at": timestamp}
     write_outputs(run_dir, summary, per_patch, config, write_per_image=not args.skip_per_image)
     print(f"[done] Report written to {run_dir}")

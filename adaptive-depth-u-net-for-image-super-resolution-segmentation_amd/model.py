@@ -323,7 +323,8 @@ class Model:
     def save_weights(self, path: str):
         from safetensors.numpy import save_file
         save_file({k: np.ascontiguousarray(v) for k, v in self.get_weights().items()}, str(path),
-                  metadata={"model": self.name, "format": "adunet_amd-flat-v1"})
+                  metadata={"model": self.name, "format": "adunet_amd-flat-v1",
+                            "compute_dtype": str(self.dtype).replace("torch.", "")})
 
     def load_weights(self, path: str):
         path = str(path)
@@ -489,10 +490,8 @@ class Model:
         if x.shape != t.shape:
             raise ValueError(f"input/target shape mismatch: {tuple(x.shape)} vs {tuple(t.shape)}")
         out, stats, sqerr, tape = self._forward(x, t, keep=keep)
-        per_img = x.shape[1] * x.shape[2] * 3
-        loss = stats[0] / float(x.shape[0] * per_img)
-        psnr = (-10.0 * torch.log10(sqerr / float(per_img))).mean()    # tf.image.psnr, inf at MSE 0 (:308-311)
-        return out, loss, psnr, (tape, x, t)
+        # stats = (loss sum, mean tf.image.psnr (:308-311), loss mean) straight from the head kernel: views, no torch op
+        return out, stats[2], stats[1], (tape, x, t)
 
     def train_on_batch(self, lr_img, hr_img):
         """One Keras train step: forward, loss, backward, (gradient all-reduce), Keras-form Adam."""
@@ -764,11 +763,6 @@ class Model:
             if hasattr(cb, "on_train_end"):
                 cb.on_train_end({})
         return hist
-
-
-def conv_block_spec(nf: int) -> str:
-    """The reference's conv_block (:200-210): [Conv3x3 same + bias -> LayerNorm(axis=-1) -> ReLU] x 2."""
-    return f"[Conv2D({nf},3,same) -> LayerNormalization(axis=-1) -> ReLU] x2"
 
 
 def build_super_resolution_unet(scale: float, base_channels: int = DEFAULT_BASE_CHANNELS,

@@ -95,13 +95,21 @@ def cin_granule(dtype: torch.dtype) -> int:
 
 
 class Workspace:
-    """One scratch buffer reused by every call (the ABI never allocates)."""
+    """One scratch buffer reused by every call (the ABI never allocates).  Every use is confined to one ABI call (a
+    kernel writes partials, the next launch of the same call folds them), so nothing is carried between calls.
+
+    A captured hipGraph bakes the buffer's address into its kernel arguments.  When a later, larger request makes the
+    buffer grow, the previous allocation is therefore RETIRED, not freed: it stays owned by this object, so replays of
+    graphs captured earlier keep writing scratch into memory nobody else can receive from the caching allocator.  Growth
+    is geometric, so the retired buffers sum to less than four times the live one."""
 
     def __init__(self, device, nbytes: int = 64 << 20):
         self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        self._retired = []
 
     def ensure(self, nbytes: int):
         if self.buf.numel() < nbytes:
+            self._retired.append(self.buf)
             self.buf = torch.empty(int(nbytes * 1.25), dtype=torch.uint8, device=self.buf.device)
 
     @property
@@ -342,12 +350,12 @@ def resample(x: torch.Tensor, tab: ResampleTables, out: Optional[torch.Tensor] =
 
 
 def head_fwd(xh, w, b, inp, target, ws: Workspace, loss_kind: int = 0, eps: float = CHARBONNIER_EPS):
-    """Returns (out[n,h,w,3] fp32, stats[1] loss SUM or None, sqerr[n] or None)."""
+    """Returns (out[n,h,w,3] fp32, stats[3] = (loss SUM, mean PSNR, loss MEAN) or None, sqerr[n] or None)."""
     n, h, wd, ch = xh.shape
     out = torch.empty((n, h, wd, 3), dtype=torch.float32, device=xh.device)
     stats = sqerr = None
     if target is not None:
-        stats = torch.empty(1, dtype=torch.float32, device=xh.device)
+        stats = torch.empty(3, dtype=torch.float32, device=xh.device)
         sqerr = torch.empty(n, dtype=torch.float32, device=xh.device)
     lib = _lib.load()
     ws.ensure(lib.ad_head_ws_bytes(n, ch))

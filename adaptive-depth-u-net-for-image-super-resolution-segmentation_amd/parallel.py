@@ -47,6 +47,8 @@ class DataParallel:
         self.buckets = plan_buckets(model.index, model.count_params(), max(1, bucket_bytes // 4))
         self._next = 0
         self._works = []
+        self._waits = []
+        self.measure = False          # bench.py: time the compute stream's wait for the exchange with HIP events
         self._cuda = model.G.is_cuda
         self._comm = torch.cuda.Stream(device=model.G.device) if self._cuda else None
         dist.broadcast(model.P, src=0, group=group)
@@ -82,6 +84,21 @@ class DataParallel:
         return 1.0 / self.world
 
     def wait_all(self):
+        timed = self.measure and self._cuda and self._works
+        if timed:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
         for w in self._works:
             w.wait()           # the compute stream waits for the collective; the host does not block
+        if timed:              # e0 -> e1 on the compute stream = the time it sat idle waiting for the exchange
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self._waits.append((e0, e1))
         self._works.clear()
+
+    def exposed_ms(self) -> float:
+        """Total time the compute stream waited for gradient exchange since `measure` was switched on (call after a
+        device synchronize); clears the record."""
+        total = sum(a.elapsed_time(b) for a, b in self._waits)
+        self._waits.clear()
+        return total

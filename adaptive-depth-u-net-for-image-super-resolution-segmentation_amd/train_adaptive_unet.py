@@ -111,7 +111,10 @@ def train(args: argparse.Namespace):
                         validation_data=val_ds, callbacks=cbs, verbose=2)
 
     shave = metrics.infer_eval_shave(args.scale, args.eval_shave)
-    shave = min(shave, max(0, (patch_size - 1) // 2))                   # cap as at :665-671
+    if shave * 2 >= patch_size and patch_size > 0:                      # cap exactly as at :665-671
+        adjusted = max(0, patch_size // 2 - 1)
+        print(f"[warn] eval_shave={shave} removes the full frame for hr_size={patch_size}; reducing to {adjusted} pixels.")
+        shave = adjusted
     final = {}
     for name, files in (("val", va), ("test", te)):
         if files:

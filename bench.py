@@ -85,6 +85,21 @@ def cpu_baseline(scale, depth, patch, budget_seconds=12.0):
             "sample": f"{budget_images} train step(s) of batch 1 on the same model (NumPy float32 oracle, {dt:.1f} s)"}
 
 
+def launch_ranks(n: int) -> int:
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node n ... bench.py <same flags>` as a child process."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:          # a free rendezvous port on the loopback interface
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -101,9 +116,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "RANK" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves.  Nothing in this process has touched the GPU
+        # yet (no HIP call, no torch.cuda query), the ranks are fresh child processes (not an exec of this one), rank 0
+        # prints the JSON line on the inherited stdout and the children's return code becomes ours.
+        raise SystemExit(launch_ranks(args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
         args.gpus = world
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)

@@ -176,8 +176,12 @@ int ad_resample(const void* x, void* y,
  *   out = clip(inp + xh @ w[ch,3] + b, 0, 1)           (fp32, [npix,3])
  *   stats[0] = sum sqrt((t-out)^2 + eps^2)   (loss_kind 0, Charbonnier)
  *            | sum |t-out|                   (loss_kind 1, L1)
+ *   stats[1] = mean over the n images of tf.image.psnr(target, out, max_val=1)
+ *            = mean(-10 log10(sqerr[img] / (pix_per_img*3)))   (psnr_metric, :308-311;
+ *              +inf at MSE 0 as in TensorFlow)
+ *   stats[2] = stats[0] / (n * pix_per_img * 3)          (the Keras loss value: mean over all elements)
  *   sqerr[img] = sum over the image of (t-out)^2   (PSNR / MSE numerator)
- * stats/sqerr are overwritten (deterministic two-stage reduction through ws). */
+ * stats (3 floats) / sqerr are overwritten (deterministic two-stage reduction through ws). */
 size_t ad_head_ws_bytes(int n, int ch);
 int ad_head_fwd(const void* xh, const float* w, const float* b, const float* inp,
                 const float* target, float* out, float* stats, float* sqerr,

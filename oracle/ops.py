@@ -13,6 +13,30 @@ from typing import Dict, Tuple
 import numpy as np
 
 # --------------------------------------------------------------------------- #
+# Storage rounding of the reduced-precision product paths.  The reference's mixed-precision policy
+# (Super_resolution/code/train_adaptive_unet.py:471-477) keeps variables in float32 and STORES activations in a
+# 16-bit type; the arithmetic inside an op is wider.  The oracle mimics that by rounding tensors at exactly the
+# points where the product stores them, while every sum stays float64.
+# --------------------------------------------------------------------------- #
+
+
+def bf16_round(x: np.ndarray) -> np.ndarray:
+    """Round to the nearest bfloat16 (ties to even), returned in x's dtype."""
+    f = np.ascontiguousarray(x, dtype=np.float32)
+    u = f.view(np.uint32)
+    r = ((u.astype(np.uint64) + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32)
+    out = r.view(np.float32)
+    out = np.where(np.isfinite(f), out, f)
+    return out.astype(x.dtype) if hasattr(x, "dtype") else out
+
+
+def fp16_round(x: np.ndarray) -> np.ndarray:
+    """Round to the nearest IEEE half (ties to even; overflow -> inf, as the hardware conversion does)."""
+    with np.errstate(over="ignore"):
+        return np.asarray(x).astype(np.float16).astype(np.asarray(x).dtype)
+
+
+# --------------------------------------------------------------------------- #
 # Conv2D 3x3 / 1x1, stride 1, padding "same", bias
 #   Super_resolution/code/train_adaptive_unet.py:202,207,259,267-274
 #   kernel layout HWIO (Keras), zero padding.

@@ -83,52 +83,64 @@ class SegUNetOracle:
         return params, state
 
     # ------------------------------------------------------------------
-    def _block_fwd(self, x, names, params, state, training, tape):
+    def _block_fwd(self, x, names, params, state, training, tape, st):
+        q = st.q
         for c, nn in names:
-            z = ops.conv2d_same_fwd(x, params[c + "/kernel"], params[c + "/bias"])
+            w = q(params[c + "/kernel"])
+            z = ops.conv2d_same_fwd(x, w, params[c + "/bias"])
+            zs = q(z)                                # the conv output as stored
             g, b = params[nn + "/gamma"], params[nn + "/beta"]
-            if self.norm == "bn":
+            if self.norm == "bn":                    # BatchNorm is always its own kernel: statistics of the stored z
                 if training:
-                    y, cache, mu, var = ops.batchnorm_train_fwd(z, g, b)
+                    y, (xhat, rstd), mu, var = ops.batchnorm_train_fwd(zs, g, b)
                     state[nn + "/moving_mean"] = state[nn + "/moving_mean"] * ops.BN_MOMENTUM + mu * (1 - ops.BN_MOMENTUM)
                     state[nn + "/moving_variance"] = state[nn + "/moving_variance"] * ops.BN_MOMENTUM + var * (1 - ops.BN_MOMENTUM)
+                    cache = (zs, mu, rstd)
                 else:
-                    y, cache = ops.batchnorm_infer_fwd(z, g, b, state[nn + "/moving_mean"], state[nn + "/moving_variance"]), None
+                    y, cache = ops.batchnorm_infer_fwd(zs, g, b, state[nn + "/moving_mean"], state[nn + "/moving_variance"]), None
             else:
-                y, cache = ops.layernorm_fwd(z, g, b)
-            a = ops.relu_fwd(y)
+                zin = z if st.fused(c, x.shape[0], x.shape[1], x.shape[2], x.shape[3], w.shape[3]) else zs
+                y, (xhat, rstd) = ops.layernorm_fwd(zin, g, b)
+                cache = (zs, zin.mean(axis=-1, keepdims=True), rstd)
+            a = q(ops.relu_fwd(y))
             tape.append(("cna", c, nn, x, cache, a))
             x = a
         return x
 
-    def forward(self, params, state, img, training=False):
+    def forward(self, params, state, img, training=False, storage=None):
+        """storage: oracle.sr_unet.Storage (None = exact arithmetic), see SRUNetOracle.forward."""
+        from .sr_unet import Storage
+        st = storage or Storage()
+        q = st.q
         tape, skips = [], []
-        x = img
+        x = q(img)
         for lvl in range(self.depth):
-            x = self._block_fwd(x, self.blocks[lvl], params, state, training, tape)
+            x = self._block_fwd(x, self.blocks[lvl], params, state, training, tape, st)
             skips.append(x)
             tape.append(("pool", x, lvl))
             x = ops.maxpool2_fwd(x)
-        x = self._block_fwd(x, self.blocks[self.depth], params, state, training, tape)
+        x = self._block_fwd(x, self.blocks[self.depth], params, state, training, tape, st)
         for i, lvl in enumerate(reversed(range(self.depth))):
             if self.up == "convT":
                 t = self.ups[i]
                 tape.append(("convT", t, x))
-                x = ops.conv_transpose2x2s2_fwd(x, params[t + "/kernel"], params[t + "/bias"])
+                x = q(ops.conv_transpose2x2s2_fwd(x, q(params[t + "/kernel"]), params[t + "/bias"]))
             else:
                 tape.append(("up2", x.shape[1]))
-                x = ops.upsample2_bilinear_fwd(x)
+                x = q(ops.upsample2_bilinear_fwd(x))
             tape.append(("concat", x.shape[-1], lvl))
             x = np.concatenate([x, skips[lvl]], axis=-1)
-            x = self._block_fwd(x, self.blocks[self.depth + 1 + i], params, state, training, tape)
+            x = self._block_fwd(x, self.blocks[self.depth + 1 + i], params, state, training, tape, st)
         logit = ops.conv2d_same_fwd(x, params[self.head + "/kernel"], params[self.head + "/bias"])
         p = ops.sigmoid(logit)
         tape.append(("head", x, p))
         self._tape = tape
+        self._storage = st
         return p
 
-    def loss_and_grads(self, params, state, img, mask, bce_weight, dice_weight):
-        p = self.forward(params, state, img, training=True)
+    def loss_and_grads(self, params, state, img, mask, bce_weight, dice_weight, storage=None):
+        p = self.forward(params, state, img, training=True, storage=storage)
+        q = self._storage.q
         loss, dp = ops.seg_loss_fwd_bwd(mask, p, bce_weight, dice_weight)
         grads = {}
         dskips = {}
@@ -138,29 +150,35 @@ class SegUNetOracle:
             if kind == "head":
                 _, xh, pp = rec
                 d, dw, db = ops.conv2d_same_bwd(xh, params[self.head + "/kernel"], dp * pp * (1 - pp))
+                d = q(d)
                 grads[self.head + "/kernel"], grads[self.head + "/bias"] = dw, db
             elif kind == "cna":
-                _, c, nn, xin, cache, a = rec
-                dy = ops.relu_bwd(d, a)
+                _, c, nn, xin, (zs, mu, rstd), a = rec
+                xhat = (zs - mu) * rstd               # from what was saved: stored z, mean, rstd (ReLU mask re-derived)
+                dy = d * (xhat * params[nn + "/gamma"] + params[nn + "/beta"] > 0)
                 if self.norm == "bn":
-                    dz, dg, dbeta = ops.batchnorm_train_bwd(dy, params[nn + "/gamma"], cache)
+                    dz, dg, dbeta = ops.batchnorm_train_bwd(dy, params[nn + "/gamma"], (xhat, rstd))
                 else:
-                    dz, dg, dbeta = ops.layernorm_bwd(dy, params[nn + "/gamma"], cache)
+                    dz, dg, dbeta = ops.layernorm_bwd(dy, params[nn + "/gamma"], (xhat, rstd))
+                dz = q(dz)
                 grads[nn + "/gamma"], grads[nn + "/beta"] = dg, dbeta
-                d, dw, db = ops.conv2d_same_bwd(xin, params[c + "/kernel"], dz, need_dx=xin.shape[-1] != 3)
+                need_dx = xin.shape[-1] != 3
+                d, dw, db = ops.conv2d_same_bwd(xin, q(params[c + "/kernel"]), dz, need_dx=need_dx)
+                d = q(d) if need_dx else None
                 grads[c + "/kernel"], grads[c + "/bias"] = dw, db
             elif kind == "concat":
                 _, c1, lvl = rec
                 dskips[lvl] = d[..., c1:]
                 d = d[..., :c1]
             elif kind == "up2":
-                d = ops.resize_aa_bwd(d, rec[1], rec[1])
+                d = q(ops.resize_aa_bwd(d, rec[1], rec[1]))
             elif kind == "convT":
                 _, t, xin = rec
-                d, dw, db = ops.conv_transpose2x2s2_bwd(xin, params[t + "/kernel"], d)
+                d, dw, db = ops.conv_transpose2x2s2_bwd(xin, q(params[t + "/kernel"]), d)
+                d = q(d)
                 grads[t + "/kernel"], grads[t + "/bias"] = dw, db
             elif kind == "pool":
-                d = ops.maxpool2_bwd(d, rec[1]) + dskips[rec[2]]
+                d = q(ops.maxpool2_bwd(d, rec[1]) + dskips[rec[2]])
         dice = ops.dice_coefficient(mask, p)
         iou = ops.iou_score(mask, p)
         return float(loss), grads, p, float(dice), float(iou)

@@ -21,6 +21,23 @@ def _uname(counter: Dict[str, int], base: str) -> str:
     return base if k == 0 else f"{base}_{k}"
 
 
+class Storage:
+    """Where the reduced-precision product path rounds.  `round` maps an array to the storage type's values
+    (ops.bf16_round / ops.fp16_round; None = no rounding).  `fused(conv, n, h, w, cin, cout)` tells whether the product
+    runs that Conv2D -> LayerNormalization link as one kernel (statistics from the fp32 accumulators) or as two
+    (statistics from the stored conv output); the tests ask the library itself."""
+
+    def __init__(self, round=None, fused=None):
+        self._round = round
+        self._fused = fused
+
+    def q(self, x):
+        return x if self._round is None else self._round(x)
+
+    def fused(self, conv, n, h, w, cin, cout) -> bool:
+        return False if self._fused is None else bool(self._fused(conv, n, h, w, cin, cout))
+
+
 class SRUNetOracle:
     """Float64 (or float32) CPU model with manual backward."""
 
@@ -142,47 +159,60 @@ class SRUNetOracle:
         return params
 
     # ------------------------------------------------------------------ #
-    def forward(self, params, x, keep: bool = True):
+    def forward(self, params, x, keep: bool = True, storage: "Storage | None" = None):
+        """storage = None: exact arithmetic in the dtype of the inputs.  storage = Storage(round, fused): the product's
+        reduced-precision path, i.e. the same float64 sums with tensors rounded where the product stores them."""
+        st = storage or Storage()
+        q = st.q
         tape = []
         skips = []
         inp = x
+        x = q(x)                                   # the first conv reads the batch in the storage type
+        n = x.shape[0]
         for step in self._plan:
             kind = step[0]
             if kind == "block":
                 for conv, ln in step[1]:
-                    z = ops.conv2d_same_fwd(x, params[conv + "/kernel"], params[conv + "/bias"])
-                    y, cache = ops.layernorm_fwd(z, params[ln + "/gamma"], params[ln + "/beta"])
-                    a = ops.relu_fwd(y)
-                    tape.append(("cla", conv, ln, x, cache, a))
+                    w = q(params[conv + "/kernel"])
+                    z = ops.conv2d_same_fwd(x, w, params[conv + "/bias"])
+                    zs = q(z)                      # the conv output as stored (read again by the backward pass)
+                    # statistics: from the fp32 accumulators where conv + LayerNorm are one kernel, else from stored z
+                    zin = z if st.fused(conv, n, x.shape[1], x.shape[2], x.shape[3], w.shape[3]) else zs
+                    y, (xhat, rstd) = ops.layernorm_fwd(zin, params[ln + "/gamma"], params[ln + "/beta"])
+                    mu = zin.mean(axis=-1, keepdims=True)
+                    a = q(ops.relu_fwd(y))
+                    tape.append(("cla", conv, ln, x, (zs, mu, rstd), a))
                     x = a
             elif kind == "down":
                 h = x.shape[1]
                 tape.append(("down", h, len(skips)))
                 skips.append(x)
-                x = ops.resize_aa_fwd(x, step[2], step[2])
+                x = q(ops.resize_aa_fwd(x, step[2], step[2]))
             elif kind == "up":
                 h = x.shape[1]
                 tape.append(("up", h))
-                x = ops.resize_aa_fwd(x, step[2], step[2])
+                x = q(ops.resize_aa_fwd(x, step[2], step[2]))
             elif kind == "upconv":
                 conv = step[1]
-                a = ops.relu_fwd(ops.conv2d_same_fwd(x, params[conv + "/kernel"], params[conv + "/bias"]))
+                a = q(ops.relu_fwd(ops.conv2d_same_fwd(x, q(params[conv + "/kernel"]), params[conv + "/bias"])))
                 tape.append(("ca", conv, x, a))
                 x = a
             elif kind == "concat":
                 skip = skips[step[1]]
                 tape.append(("concat", x.shape[-1], step[1]))
                 x = np.concatenate([x, skip], axis=-1)
-            elif kind == "head":
+            elif kind == "head":           # fp32 weights and arithmetic on the stored head activations; fp32 output
                 r = ops.conv2d_same_fwd(x, params["residual_rgb/kernel"], params["residual_rgb/bias"])
                 out, pre = ops.clip_add_fwd(inp, r)
                 tape.append(("head", x, pre))
                 x = out
         self._tape = tape if keep else None
         self._nskips = len(skips)
+        self._storage = st
         return x
 
     def backward(self, params, dout):
+        q = self._storage.q
         grads = {}
         dskips = [None] * self._nskips
         d = dout
@@ -192,33 +222,39 @@ class SRUNetOracle:
                 _, xh, pre = rec
                 dr = ops.clip_add_bwd(d, pre)
                 d, dw, db = ops.conv2d_same_bwd(xh, params["residual_rgb/kernel"], dr)
+                d = q(d)
                 grads["residual_rgb/kernel"], grads["residual_rgb/bias"] = dw, db
             elif kind == "cla":
-                _, conv, ln, xin, cache, a = rec
-                dy = ops.relu_bwd(d, a)
-                dz, dg, dbeta = ops.layernorm_bwd(dy, params[ln + "/gamma"], cache)
+                _, conv, ln, xin, (zs, mu, rstd), a = rec
+                # LayerNorm + ReLU backward from what was saved: stored z, mean, rstd (the ReLU mask is re-derived)
+                xhat = (zs - mu) * rstd
+                dy = d * (xhat * params[ln + "/gamma"] + params[ln + "/beta"] > 0)
+                dz, dg, dbeta = ops.layernorm_bwd(dy, params[ln + "/gamma"], (xhat, rstd))
+                dz = q(dz)
                 grads[ln + "/gamma"], grads[ln + "/beta"] = dg, dbeta
                 need_dx = xin.shape[-1] != 3 or conv != "conv2d"
-                d, dw, db = ops.conv2d_same_bwd(xin, params[conv + "/kernel"], dz, need_dx=need_dx)
+                d, dw, db = ops.conv2d_same_bwd(xin, q(params[conv + "/kernel"]), dz, need_dx=need_dx)
+                d = q(d) if need_dx else None
                 grads[conv + "/kernel"], grads[conv + "/bias"] = dw, db
             elif kind == "ca":
                 _, conv, xin, a = rec
                 dz = ops.relu_bwd(d, a)
-                d, dw, db = ops.conv2d_same_bwd(xin, params[conv + "/kernel"], dz)
+                d, dw, db = ops.conv2d_same_bwd(xin, q(params[conv + "/kernel"]), dz)
+                d = q(d)
                 grads[conv + "/kernel"], grads[conv + "/bias"] = dw, db
             elif kind == "concat":
                 _, c1, lvl = rec
                 dskips[lvl] = d[..., c1:]
                 d = d[..., :c1]
             elif kind == "up":
-                d = ops.resize_aa_bwd(d, rec[1], rec[1])
+                d = q(ops.resize_aa_bwd(d, rec[1], rec[1]))
             elif kind == "down":
-                d = ops.resize_aa_bwd(d, rec[1], rec[1]) + dskips[rec[2]]
+                d = q(ops.resize_aa_bwd(d, rec[1], rec[1]) + dskips[rec[2]])
         return grads
 
     # ------------------------------------------------------------------ #
-    def loss_and_grads(self, params, lr_img, hr_img, loss: str = "charbonnier"):
-        out = self.forward(params, lr_img)
+    def loss_and_grads(self, params, lr_img, hr_img, loss: str = "charbonnier", storage: "Storage | None" = None):
+        out = self.forward(params, lr_img, storage=storage)
         if loss == "charbonnier":
             val = ops.charbonnier_fwd(hr_img, out)
             dout = ops.charbonnier_bwd(hr_img, out)
@@ -231,9 +267,10 @@ class SRUNetOracle:
         psnr = float(np.mean(ops.psnr_per_image(hr_img, out)))
         return float(val), grads, out, psnr
 
-    def train_step(self, params, opt_state, lr_img, hr_img, lr=1e-4, loss: str = "charbonnier"):
+    def train_step(self, params, opt_state, lr_img, hr_img, lr=1e-4, loss: str = "charbonnier",
+                   storage: "Storage | None" = None):
         """One Keras train step (forward, loss, backward, Keras-form Adam). Mutates params/state."""
-        val, grads, out, psnr = self.loss_and_grads(params, lr_img, hr_img, loss)
+        val, grads, out, psnr = self.loss_and_grads(params, lr_img, hr_img, loss, storage=storage)
         opt_state["step"] = opt_state.get("step", 0) + 1
         for name in params:
             m = opt_state.setdefault("m/" + name, np.zeros_like(params[name]))

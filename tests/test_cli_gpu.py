@@ -47,3 +47,34 @@ def test_train_then_evaluate(device, tmp_path):
         T.train(T.parse_args(argv + ["--initial_epoch", "5"]))
     with pytest.raises(FileNotFoundError):
         T.train(T.parse_args(["--scale", "0.5", "--high_res_dir", str(tmp_path / "nope")]))
+
+
+def test_fp32_checkpoint_is_evaluated_in_fp32(device, tmp_path):
+    """The offline evaluation reloads a model under the policy it was trained with (Keras behaviour,
+    evaluate_model.py:57-91): an fp32-trained checkpoint must give the fp32 model's PSNR (1e-3 dB), not a bf16 re-run."""
+    import torch
+    from adunet_amd import evaluate_model, train_adaptive_unet as T
+    from adunet_amd.pipeline import make_eval_patch_dataset, sorted_alphanumeric
+    hr = tmp_path / "hr"
+    hr.mkdir()
+    _pngs(hr, 6)
+    argv = ["--scale", "0.5", "--high_res_dir", str(hr), "--patch_size", "32", "--depth_override", "1", "--batch_size", "4",
+            "--epochs", "1", "--patches_per_image", "2", "--learning_rate", "1e-3", "--model_dir", str(tmp_path / "models"),
+            "--log_dir", str(tmp_path / "logs"), "--run_name", "t32", "--shuffle_buffer", "8"]
+    T.train(T.parse_args(argv))
+    ckpt = tmp_path / "models" / "unet_adaptive_scale_new_loss0.50_depth1.safetensors"
+    assert evaluate_model.checkpoint_compute_dtype(ckpt) == torch.float32
+    common = ["--model-path", str(ckpt), "--scale", "0.5", "--hr-dir", str(hr), "--patch-size", "32", "--depth-override", "1",
+              "--output-dir", str(tmp_path / "eval"), "--batch-size", "4"]
+    evaluate_model.main(common + ["--run-name", "auto"])
+    cfg = json.loads((tmp_path / "eval" / "auto" / "config.json").read_text())
+    assert cfg["compute_dtype"] == "float32"
+    got = json.loads((tmp_path / "eval" / "auto" / "metrics.json").read_text())["psnr_mean"]
+    files = sorted_alphanumeric([str(f) for f in hr.glob("*.png")])
+    ds, _, _ = make_eval_patch_dataset(files, patch_size=32, scale=0.5, batch_size=4)
+    model = evaluate_model.load_checkpoint_model(ckpt, 0.5, 32, 1, dtype=torch.float32)
+    want, _ = evaluate_model.evaluate(model, ds, eval_shave=evaluate_model.infer_eval_shave(0.5, None))
+    assert abs(got - want.psnr_mean) < 1e-3
+    evaluate_model.main(common + ["--run-name", "mp", "--mixed-precision"])
+    cfg = json.loads((tmp_path / "eval" / "mp" / "config.json").read_text())
+    assert cfg["compute_dtype"] == "bfloat16"

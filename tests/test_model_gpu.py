@@ -1,14 +1,20 @@
 """End-to-end GPU parity: the HIP-kernel model vs the NumPy float64 oracle on identical inputs and weights.
 
-Bars (north_star): fp32 path within 1e-3 relative (outputs, loss, every gradient tensor), PSNR equal to
-3 decimal places.  bf16 path: activations and weight operands carry 8 significant bits, so gradients are
-compared at 6e-2 of each tensor's max magnitude and PSNR within 0.05 dB (tolerances stated inline).
+Error metric throughout: `rel(got, want) = max|got - want| / max|want|` per tensor, i.e. the maximum error normalised by
+the tensor's largest magnitude (not an element-wise relative error).
+
+Bars (north_star): fp32 path within 1e-3 (outputs, loss, every gradient tensor), PSNR equal to 3 decimal places.
+bf16 path: compared with the oracle's bf16-STORAGE mode (oracle.sr_unet.Storage): the same float64 sums with every
+tensor rounded to bf16 exactly where the product stores it (activations, conv outputs, weight operands, gradients of
+activations).  What remains is fp32-vs-float64 accumulation order plus the rare 1-ulp rounding flips it causes, so the
+bf16 path is held to 3e-2 per gradient tensor, 1e-2 on outputs and 0.01 dB on PSNR (tolerances stated inline).
 """
 import numpy as np
 import pytest
 import torch
 
-from oracle.sr_unet import SRUNetOracle
+from oracle import ops as ref
+from oracle.sr_unet import SRUNetOracle, Storage
 
 pytestmark = pytest.mark.gpu
 
@@ -33,8 +39,50 @@ def build_pair(scale, depth, p, dtype, device, head_uniform=0.05, seed=1234):
     return oracle, params, model, rng
 
 
+def storage_of(model, n):
+    """The oracle-side description of where `model` rounds: nothing for fp32; for bf16 every stored tensor, with the
+    Conv2D -> LayerNorm links the library runs as ONE kernel (statistics from the fp32 accumulators) asked from the
+    library itself."""
+    from adunet_amd import _lib, ops
+    if model.dtype == torch.float32:
+        return None
+    lib = _lib.load()
+    fused = {}
+    first = next(iter(model.convs.values()))
+    for step in model._plan:
+        if step[0] != "block":
+            continue
+        for i, cs in enumerate(step[1]):
+            c1, c2 = (cs.cin // 2, cs.cin // 2) if (step[2] is not None and i == 0) else (model._cin_pad(cs), 0)
+            if cs is first and cs.cin == 3 and lib.ad_conv3x3_c3_supported(n, cs.hw, cs.hw, cs.cout, ops.dt(model.dtype)):
+                fused[cs.name] = True                      # dedicated first-layer kernel: always conv + LayerNorm in one
+            else:
+                fused[cs.name] = bool(lib.ad_conv3x3_ln_relu_is_fused(n, cs.hw, cs.hw, c1, c2, cs.cout, ops.dt(model.dtype)))
+    return Storage(ref.bf16_round, lambda conv, *shape: fused[conv])
+
+
 def rel(got, want):
     return float(np.abs(np.asarray(got, np.float64) - want).max() / (np.abs(want).max() + 1e-30))
+
+
+def check_step_against_oracle(oracle, params, model, lr, hr, *, f32, grad_tol=None):
+    """Forward, loss, PSNR, every gradient tensor of one batch against the oracle (bf16: its storage mode)."""
+    n = lr.shape[0]
+    want_loss, want_grads, want_out, want_psnr = oracle.loss_and_grads(
+        params, lr.astype(np.float64), hr.astype(np.float64), storage=storage_of(model, n))
+    out, loss, psnr, (tape, x, t) = model.forward_loss(lr, hr, keep=True)
+    model._backward(tape, x, t, 1.0 / x.numel())
+    assert rel(out.cpu().numpy(), want_out) < (1e-3 if f32 else 1e-2)
+    assert abs(float(loss) - want_loss) < (1e-3 if f32 else 5e-3) * want_loss
+    assert abs(float(psnr) - want_psnr) < (1e-3 if f32 else 1e-2)          # dB (north_star: 0.01 dB)
+    grads = model.get_grads()
+    worst = max((rel(grads[k], want_grads[k]), k) for k in want_grads)
+    assert worst[0] < (grad_tol or (1e-3 if f32 else 3e-2)), worst
+    ga = np.concatenate([grads[k].reshape(-1) for k in want_grads]).astype(np.float64)
+    gb = np.concatenate([want_grads[k].reshape(-1) for k in want_grads])
+    cos = float(ga @ gb / (np.linalg.norm(ga) * np.linalg.norm(gb)))
+    assert cos > (0.999999 if f32 else 0.9999), cos
+    return out, want_grads
 
 
 CASES = [
@@ -51,22 +99,7 @@ def test_forward_loss_and_gradients(device, dtype, case):
     scale, depth, p, n = case
     oracle, params, model, rng = build_pair(scale, depth, p, dtype, device)
     lr, hr = synth(rng, n, p)
-    want_loss, want_grads, want_out, want_psnr = oracle.loss_and_grads(params, lr.astype(np.float64), hr.astype(np.float64))
-    out, loss, psnr, (tape, x, t) = model.forward_loss(lr, hr, keep=True)
-    model._backward(tape, x, t, 1.0 / x.numel())
-    f32 = dtype == torch.float32
-    assert rel(out.cpu().numpy(), want_out) < (1e-3 if f32 else 2e-2)
-    assert abs(float(loss) - want_loss) < (1e-3 if f32 else 2e-2) * want_loss
-    assert abs(float(psnr) - want_psnr) < (1e-3 if f32 else 5e-2)          # dB
-    grads = model.get_grads()
-    worst = max((rel(grads[k], want_grads[k]), k) for k in want_grads)
-    # bf16: per-tensor bound is loose for the tiny-spatial bottleneck (few pixels => noisy sums of 8-bit
-    # operands); the flat gradient direction is held to cosine > 0.995 on top of it
-    assert worst[0] < (1e-3 if f32 else 0.15), worst
-    ga = np.concatenate([grads[k].reshape(-1) for k in want_grads]).astype(np.float64)
-    gb = np.concatenate([want_grads[k].reshape(-1) for k in want_grads])
-    cos = float(ga @ gb / (np.linalg.norm(ga) * np.linalg.norm(gb)))
-    assert cos > (0.999999 if f32 else 0.995), cos
+    out, _ = check_step_against_oracle(oracle, params, model, lr, hr, f32=dtype == torch.float32)
     # inference entry point returns the same tensor
     y = model(lr, training=False)
     assert np.array_equal(y, out.cpu().numpy())
@@ -79,17 +112,131 @@ def test_training_trajectory(device, dtype):
     oracle, params, model, rng = build_pair(scale, depth, p, dtype, device, head_uniform=0.0)   # reference init: zero head
     state = {}
     f32 = dtype == torch.float32
+    storage = storage_of(model, n)
     for step in range(5):
         lr, hr = synth(rng, n, p)
-        want_loss, want_psnr = oracle.train_step(params, state, lr.astype(np.float64), hr.astype(np.float64), lr=1e-3)
+        want_loss, want_psnr = oracle.train_step(params, state, lr.astype(np.float64), hr.astype(np.float64), lr=1e-3,
+                                                 storage=storage)
         loss, psnr = model.train_on_batch(lr, hr)
-        assert abs(float(loss) - want_loss) < (1e-3 if f32 else 3e-2) * want_loss, step
-        assert abs(float(psnr) - want_psnr) < (1e-3 if f32 else 0.1), step
+        # bf16: Adam turns a rounding flip in a tiny gradient into a full +-lr step of that weight, so the two
+        # trajectories drift apart slowly; 1e-2 on the loss / 0.05 dB after five steps
+        assert abs(float(loss) - want_loss) < (1e-3 if f32 else 1e-2) * want_loss, step
+        assert abs(float(psnr) - want_psnr) < (1e-3 if f32 else 5e-2), step
     if f32:
         got = model.get_weights()
         # Adam normalises every update to ~lr, so compare against the size of the total update (5e-3)
         worst = max((float(np.abs(got[k] - params[k]).max()), k) for k in params)
         assert worst[0] < 2e-4, worst
+
+
+# ----------------------------------------------------------------------------- BASELINE.json configurations
+# K2' (the `metric` headline: x4, depth 4, 256-pixel patches; pyramid 256/64/16/4/1, 1024-channel 1x1 bottleneck,
+# split-K launches, the wave-specialised and fused-LayerNorm kernels inside one model), R3 (the reference's own
+# Experiment-1 shape) -- batch 2 / 1 against the oracle.
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_k2p_config_against_oracle(device, dtype):
+    oracle, params, model, rng = build_pair(0.25, 4, 256, dtype, device)
+    assert model.count_params() == 34_599_363 and model.sizes == [256, 64, 16, 4, 1]
+    lr, hr = synth(rng, 2, 256)
+    f32 = dtype == torch.float32
+    _, want_grads = check_step_against_oracle(oracle, params, model, lr, hr, f32=f32)
+    # ... and the Adam update that follows from those gradients (Keras form, epsilon outside the bias correction)
+    before = model.get_weights()
+    model.train_on_batch(lr, hr)
+    after = model.get_weights()
+    for name in ("conv2d_9/kernel", "conv2d_1/kernel", "residual_rgb/kernel", "layer_normalization_3/gamma"):
+        p0 = before[name].astype(np.float64)
+        m, v = np.zeros_like(p0), np.zeros_like(p0)
+        ref.adam_step(p0, want_grads[name], m, v, 1, lr=1e-3)
+        # first Adam step = -lr * sign(g) up to epsilon: compare where the oracle gradient is well away from zero
+        big = np.abs(want_grads[name]) > 1e-3 * np.abs(want_grads[name]).max()
+        assert np.abs(after[name] - p0)[big].max() < (2e-6 if f32 else 2e-5), name
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_r3_config_against_oracle(device, dtype):
+    oracle, params, model, rng = build_pair(0.5, 3, 256, dtype, device)
+    assert model.count_params() == 8_637_379 and model.sizes == [256, 128, 64, 32]
+    lr, hr = synth(rng, 1, 256)
+    check_step_against_oracle(oracle, params, model, lr, hr, f32=dtype == torch.float32)
+
+
+FULL_SIZE = [
+    # name, scale, depth, patch, per-GPU batch of bench.py
+    ("K2p", 0.25, 4, 256, 64),
+    ("K2", 0.25, 4, 512, 16),
+    ("R3", 0.5, 3, 256, 64),
+]
+
+
+@pytest.mark.parametrize("case", FULL_SIZE, ids=[c[0] for c in FULL_SIZE])
+def test_full_size_properties(device, case):
+    """The benchmarked configurations at their full batch (far beyond what the oracle can convolve): the train step is
+    deterministic (two models, same data -> bitwise equal weights), the hipGraph replay equals the eager step bit for
+    bit, the loss is finite and falls over five steps on a fixed batch, and the K2'/batch-2 oracle-checked forward is
+    reproduced by the first two images of the big batch (samples are independent: LayerNorm has no batch statistic)."""
+    from adunet_amd.model import Adam, build_losses_and_metrics, build_super_resolution_unet
+    name, scale, depth, p, n = case
+    rng = np.random.default_rng(77)
+    lr, hr = synth(rng, n, p)
+    dlr, dhr = torch.from_numpy(lr).to(device), torch.from_numpy(hr).to(device)
+    finals = []
+    for mode in ("eager", "eager", "graph"):
+        model, _ = build_super_resolution_unet(scale, depth_override=depth, input_size=p, dtype=torch.bfloat16, device=device)
+        loss, metrics = build_losses_and_metrics("charbonnier")
+        model.compile(optimizer=Adam(1e-3), loss=loss, metrics=metrics)
+        model._require_device()
+        model.set_weights(model.initial_weights(np.random.default_rng(1), head_uniform=0.05))
+        if mode == "graph":
+            step = model.make_graphed_train_step(dlr, dhr)          # trains on the batch twice (warm-up + first replay)
+            losses = [None, None] + [float(step(dlr, dhr)[0]) for _ in range(3)]
+        else:
+            losses = [float(model.train_on_batch(dlr, dhr)[0]) for _ in range(5)]
+        finals.append((losses, model.P.clone()))
+        if mode == "eager" and len(finals) == 1:
+            small = model(dlr[:2], training=False)
+            big = model(dlr, training=False)
+            # (different launch shapes pick different kernels / accumulation orders: equal up to bf16 rounding flips)
+            assert rel(big[:2].cpu().numpy(), small.cpu().numpy().astype(np.float64)) < 1e-2
+        del model
+        torch.cuda.empty_cache()
+    (l0, p0), (l1, p1), (l2, p2) = finals
+    assert all(np.isfinite(v) for v in l0) and l0[-1] < l0[0], l0
+    assert l0 == l1 and torch.equal(p0, p1)                          # deterministic
+    assert l0[2:] == l2[2:] and torch.equal(p0, p2)                  # graph replay == eager, bitwise
+
+
+def test_graph_replay_survives_workspace_growth(device):
+    """A hipGraph bakes the scratch addresses in.  A later, larger request (here: an eager step on twice the batch)
+    makes the workspaces grow; the retired buffers must stay owned so that replaying the earlier graph still equals the
+    eager trajectory bit for bit."""
+    from adunet_amd.model import Adam, build_losses_and_metrics, build_super_resolution_unet
+    from adunet_amd import ops
+    rng = np.random.default_rng(31)
+    small = [synth(rng, 2, 64) for _ in range(3)]
+    big = synth(rng, 8, 64)
+    results = []
+    for graphed in (False, True):
+        ops._conv_ws.clear()                                         # both runs start from fresh, minimal workspaces
+        model, _ = build_super_resolution_unet(0.25, depth_override=2, input_size=64, dtype=torch.bfloat16, device=device)
+        loss, metrics = build_losses_and_metrics("charbonnier")
+        model.compile(optimizer=Adam(1e-3), loss=loss, metrics=metrics)
+        model._require_device()
+        model._ws = ops.Workspace(device, 1 << 16)
+        model.set_weights(model.initial_weights(np.random.default_rng(1), head_uniform=0.05))
+        if graphed:
+            step = model.make_graphed_train_step(*small[0])
+            ptr = model._ws.ptr
+        else:
+            step = model.train_on_batch
+            step(*small[0]); step(*small[0])
+        step(*small[1])
+        model.train_on_batch(*big)                                   # eager, 4x the pixels: every workspace grows
+        if graphed:
+            assert model._ws.ptr != ptr and model._ws._retired
+        losses = [float(step(*small[2])[0])]
+        results.append((losses, model.P.clone()))
+    assert results[0][0] == results[1][0] and torch.equal(results[0][1], results[1][1])
 
 
 def test_identity_at_initialisation(device):
@@ -104,14 +251,7 @@ def test_k1_config_fp32(device):
     """BASELINE config 1 (K1): x2 SR, 128-pixel patches, depth 2, batch 4, fp32."""
     oracle, params, model, rng = build_pair(0.5, 2, 128, torch.float32, device)
     lr, hr = synth(rng, 4, 128)
-    want_loss, want_grads, want_out, want_psnr = oracle.loss_and_grads(params, lr.astype(np.float64), hr.astype(np.float64))
-    out, loss, psnr, (tape, x, t) = model.forward_loss(lr, hr, keep=True)
-    model._backward(tape, x, t, 1.0 / x.numel())
-    assert rel(out.cpu().numpy(), want_out) < 1e-3
-    assert abs(float(psnr) - want_psnr) < 1e-3
-    grads = model.get_grads()
-    worst = max((rel(grads[k], want_grads[k]), k) for k in want_grads)
-    assert worst[0] < 1e-3, worst
+    check_step_against_oracle(oracle, params, model, lr, hr, f32=True)
 
 
 def test_train_step_is_deterministic(device):
@@ -217,6 +357,7 @@ def test_segmented_graph_step_under_data_parallel(device):
         if created:
             torch.cuda.synchronize()
             dist.barrier()
+            dist.destroy_process_group()
 
 
 def test_fit_replays_graphs_and_matches_eager_fit(device, monkeypatch):
