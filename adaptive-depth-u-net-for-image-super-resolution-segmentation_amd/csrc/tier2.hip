@@ -13,7 +13,7 @@ constexpr int NBLK = 512;   // blocks of the column-reduction kernels (partials 
 // part[block][2][c] = { sum_p (x[p][ch] - shift[ch]), sum_p (x[p][ch] - shift[ch])^2 }
 template <typename T>
 __global__ __launch_bounds__(256) void colstats_kernel(const T* __restrict__ x, const float* __restrict__ shift,
-                                                       float* __restrict__ part, int64_t npix, int c) {
+                                                       float* __restrict__ part, int64_t npix, int c, int ld) {
     constexpr int EPT = ElemTraits<T>::EPT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = reinterpret_cast<float*>(smem);   // [rows][2][c]
@@ -22,13 +22,14 @@ __global__ __launch_bounds__(256) void colstats_kernel(const T* __restrict__ x, 
     const int tid = threadIdx.x;
     const int v = tid % vecs, r = tid / vecs;
     float s1[EPT], s2[EPT], sh[EPT];
+    const int64_t ldx = ld;                       // row stride in elements (>= c: the launch may cover a channel slice)
 #pragma unroll
     for (int e = 0; e < EPT; ++e) { s1[e] = s2[e] = 0.f; sh[e] = shift ? shift[v * EPT + e] : 0.f; }
     if (r < rows)
         for (int64_t p = (int64_t)blockIdx.x * rows + r; p < npix; p += (int64_t)gridDim.x * rows) {
             Vec16<T> ld;
             float f[EPT];
-            ld.load(x + p * c + v * EPT);
+            ld.load(x + p * ldx + v * EPT);
             ld.to_f32(f);
 #pragma unroll
             for (int e = 0; e < EPT; ++e) { float d = f[e] - sh[e]; s1[e] += d; s2[e] += d * d; }
@@ -87,7 +88,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ mean,
                                                        const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, T* __restrict__ y, int64_t npix, int c,
-                                                       int relu) {
+                                                       int relu, int ld) {
     constexpr int EPT = ElemTraits<T>::EPT;
     const int vecs = c / EPT;
     const int64_t total = npix * vecs;
@@ -99,17 +100,18 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
         mu[e] = mean[ch]; rs[e] = rstd[ch]; ga[e] = gamma[ch]; be[e] = beta[ch];
     }
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        Vec16<T> ld, st;
+        Vec16<T> ld16, st;
         float f[EPT], o[EPT];
-        ld.load(x + i * EPT);
-        ld.to_f32(f);
+        const int64_t off = (i / vecs) * ld + v * EPT;        // ld: row stride in elements (channel-slice launches)
+        ld16.load(x + off);
+        ld16.to_f32(f);
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
             const float t = (f[e] - mu[e]) * rs[e] * ga[e] + be[e];
             o[e] = relu ? fmaxf(t, 0.f) : t;
         }
         st.from_f32(o);
-        st.store(y + i * EPT);
+        st.store(y + off);
     }
 }
 
@@ -118,7 +120,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                            float* __restrict__ part, int64_t npix, int c, int relu) {
+                                                            float* __restrict__ part, int64_t npix, int c, int relu, int ld) {
     constexpr int EPT = ElemTraits<T>::EPT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = reinterpret_cast<float*>(smem);
@@ -136,8 +138,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
         for (int64_t p = (int64_t)blockIdx.x * rows + r; p < npix; p += (int64_t)gridDim.x * rows) {
             Vec16<T> l0, l1;
             float f[EPT], d[EPT];
-            l0.load(x + p * c + v * EPT);
-            l1.load(dy + p * c + v * EPT);
+            l0.load(x + p * (int64_t)ld + v * EPT);
+            l1.load(dy + p * (int64_t)ld + v * EPT);
             l0.to_f32(f);
             l1.to_f32(d);
 #pragma unroll
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            const float* __restrict__ dgamma, const float* __restrict__ dbeta,
-                                                           T* __restrict__ dx, int64_t npix, int c, int relu) {
+                                                           T* __restrict__ dx, int64_t npix, int c, int relu, int ld) {
     constexpr int EPT = ElemTraits<T>::EPT;
     const int vecs = c / EPT;
     const int64_t total = npix * vecs;
@@ -185,8 +187,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         Vec16<T> l0, l1, st;
         float f[EPT], d[EPT], o[EPT];
-        l0.load(x + i * EPT);
-        l1.load(dy + i * EPT);
+        const int64_t off = (i / vecs) * ld + v * EPT;
+        l0.load(x + off);
+        l1.load(dy + off);
         l0.to_f32(f);
         l1.to_f32(d);
 #pragma unroll
@@ -196,7 +199,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
             o[e] = ga[e] * rs[e] * (dl - k0[e] - h * k1[e]);
         }
         st.from_f32(o);
-        st.store(dx + i * EPT);
+        st.store(dx + off);
     }
 }
 
@@ -435,18 +438,61 @@ static int ew_blocks(int64_t total) {
     return (int)(b < 16384 ? b : 16384);
 }
 
-static bool chan_ok(int c, int ept) { return c > 0 && c % ept == 0 && (c / ept) <= 256 && 256 % (c / ept) == 0; }
+// Channel counts: a multiple of the 16-byte vector; per launch at most 256 vectors per pixel (one thread each) with
+// 256 % vectors == 0.  Wider tensors (c = 2048 fp32 at the depth-5 bottleneck) run as channel slices of 256 vectors: the
+// kernels take the row stride separately, the per-channel statistics of different slices are independent.
+static bool chan_ok(int c, int ept) {
+    if (c <= 0 || c % ept) return false;
+    const int vecs = c / ept;
+    return vecs <= 256 ? 256 % vecs == 0 : vecs % 256 == 0;
+}
+static int slice_channels(int c, int ept) { return c / ept <= 256 ? c : 256 * ept; }
 
 template <typename T>
-int colstats(const void* x, const float* shift, float* part, int64_t npix, int c, hipStream_t s, int* nblocks) {
+int colstats(const void* x, const float* shift, float* part, int64_t npix, int c, int ld, hipStream_t s, int* nblocks) {
     const int vecs = c / ElemTraits<T>::EPT;
     const int rows = 256 / vecs > 0 ? 256 / vecs : 1;
     int64_t nb = (npix + rows - 1) / rows;
     *nblocks = (int)(nb < NBLK ? nb : NBLK);
     size_t lds = (size_t)rows * 2 * c * sizeof(float);
     if (lds > 64 * 1024) return ad_set_error(AD_ERR_ARG, "batchnorm: c=%d too wide", c);
-    colstats_kernel<T><<<*nblocks, 256, lds, s>>>((const T*)x, shift, part, npix, c);
+    colstats_kernel<T><<<*nblocks, 256, lds, s>>>((const T*)x, shift, part, npix, c, ld);
     AD_LAUNCH_CHECK("colstats");
+    return AD_OK;
+}
+
+template <typename T>
+int bn_fwd_train(const T* z, const float* gamma, const float* beta, T* y, float* save_mean, float* save_rstd, float* save_var,
+                 float* moving_mean, float* moving_var, float momentum, int64_t npix, int c, int ld, float eps, int relu,
+                 float* part, hipStream_t s) {
+    int nb = 0;
+    // pass 1: mean; pass 2: centred second moment (biased variance, as Keras)
+    int rc = colstats<T>(z, nullptr, part, npix, c, ld, s, &nb);
+    if (rc) return rc;
+    colstats_finish_kernel<<<(2 * c + 3) / 4, 256, 0, s>>>(part, nb, c, 1.0f / (float)npix, 0.f, nullptr, save_mean, nullptr);
+    rc = colstats<T>(z, save_mean, part, npix, c, ld, s, &nb);
+    if (rc) return rc;
+    colstats_finish_kernel<<<(2 * c + 3) / 4, 256, 0, s>>>(part, nb, c, 0.f, 1.0f / (float)npix, nullptr, nullptr, save_var);
+    bn_finalize_kernel<<<(c + 255) / 256, 256, 0, s>>>(save_mean, save_var, save_rstd, moving_mean, moving_var, momentum, eps, c);
+    bn_apply_kernel<T><<<ew_blocks(npix * (c / ElemTraits<T>::EPT)), 256, 0, s>>>(z, save_mean, save_rstd, gamma, beta, y, npix,
+                                                                                   c, relu, ld);
+    AD_LAUNCH_CHECK("ad_batchnorm_relu_fwd_train");
+    return AD_OK;
+}
+
+template <typename T>
+int bn_bwd(const T* dy, const T* z, const float* save_mean, const float* save_rstd, const float* gamma, const float* beta,
+           T* dz, float* dgamma, float* dbeta, int64_t npix, int c, int ld, int relu, float* part, hipStream_t s) {
+    const int vecs = c / ElemTraits<T>::EPT;
+    const int rows = 256 / vecs > 0 ? 256 / vecs : 1;
+    int64_t nbl = (npix + rows - 1) / rows;
+    const int nb = (int)(nbl < NBLK ? nbl : NBLK);
+    size_t lds = (size_t)rows * 2 * c * sizeof(float);
+    bn_bwd_reduce_kernel<T><<<nb, 256, lds, s>>>(dy, z, save_mean, save_rstd, gamma, beta, part, npix, c, relu, ld);
+    colstats_finish_kernel<<<(2 * c + 3) / 4, 256, 0, s>>>(part, nb, c, 1.f, 1.f, nullptr, dgamma, dbeta);
+    bn_bwd_apply_kernel<T><<<ew_blocks(npix * vecs), 256, 0, s>>>(dy, z, save_mean, save_rstd, gamma, beta, dgamma, dbeta, dz, npix,
+                                                                  c, relu, ld);
+    AD_LAUNCH_CHECK("ad_batchnorm_relu_bwd");
     return AD_OK;
 }
 
@@ -463,22 +509,17 @@ extern "C" int ad_batchnorm_relu_fwd_train(const void* z, const float* gamma, co
     AD_REQUIRE(npix > 0 && chan_ok(c, ept), "ad_batchnorm_relu_fwd_train: unsupported npix=%ld c=%d", (long)npix, c);
     if (!ws || ws_bytes < ad_batchnorm_ws_bytes(c)) return ad_set_error(AD_ERR_WS, "ad_batchnorm: workspace too small");
     hipStream_t s = (hipStream_t)stream;
-    float* part = (float*)ws;
-    int nb = 0, rc;
-    // pass 1: mean; pass 2: centred second moment (biased variance, as Keras)
-    rc = dtype == AD_BF16 ? colstats<bf16_t>(z, nullptr, part, npix, c, s, &nb) : colstats<float>(z, nullptr, part, npix, c, s, &nb);
-    if (rc) return rc;
-    colstats_finish_kernel<<<(2 * c + 3) / 4, 256, 0, s>>>(part, nb, c, 1.0f / (float)npix, 0.f, nullptr, save_mean, nullptr);
-    rc = dtype == AD_BF16 ? colstats<bf16_t>(z, save_mean, part, npix, c, s, &nb) : colstats<float>(z, save_mean, part, npix, c, s, &nb);
-    if (rc) return rc;
-    colstats_finish_kernel<<<(2 * c + 3) / 4, 256, 0, s>>>(part, nb, c, 0.f, 1.0f / (float)npix, nullptr, nullptr, save_var);
-    bn_finalize_kernel<<<(c + 255) / 256, 256, 0, s>>>(save_mean, save_var, save_rstd, moving_mean, moving_var, momentum, eps, c);
-    const int blocks = ew_blocks(npix * (c / ept));
-    if (dtype == AD_BF16)
-        bn_apply_kernel<bf16_t><<<blocks, 256, 0, s>>>((const bf16_t*)z, save_mean, save_rstd, gamma, beta, (bf16_t*)y, npix, c, relu);
-    else
-        bn_apply_kernel<float><<<blocks, 256, 0, s>>>((const float*)z, save_mean, save_rstd, gamma, beta, (float*)y, npix, c, relu);
-    AD_LAUNCH_CHECK("ad_batchnorm_relu_fwd_train");
+    const int cs = slice_channels(c, ept);
+    for (int c0 = 0; c0 < c; c0 += cs) {
+        const int rc = dtype == AD_BF16
+            ? bn_fwd_train<bf16_t>((const bf16_t*)z + c0, gamma + c0, beta + c0, (bf16_t*)y + c0, save_mean + c0, save_rstd + c0,
+                                   save_var + c0, moving_mean ? moving_mean + c0 : nullptr, moving_var ? moving_var + c0 : nullptr,
+                                   momentum, npix, cs, c, eps, relu, (float*)ws, s)
+            : bn_fwd_train<float>((const float*)z + c0, gamma + c0, beta + c0, (float*)y + c0, save_mean + c0, save_rstd + c0,
+                                  save_var + c0, moving_mean ? moving_mean + c0 : nullptr, moving_var ? moving_var + c0 : nullptr,
+                                  momentum, npix, cs, c, eps, relu, (float*)ws, s);
+        if (rc) return rc;
+    }
     return AD_OK;
 }
 
@@ -490,11 +531,16 @@ extern "C" int ad_batchnorm_relu_fwd_infer(const void* z, const float* gamma, co
     AD_REQUIRE(npix > 0 && chan_ok(c, ept), "ad_batchnorm_relu_fwd_infer: unsupported npix=%ld c=%d", (long)npix, c);
     hipStream_t s = (hipStream_t)stream;
     bn_finalize_kernel<<<(c + 255) / 256, 256, 0, s>>>(moving_mean, moving_var, rstd_tmp, nullptr, nullptr, 0.f, eps, c);
-    const int blocks = ew_blocks(npix * (c / ept));
-    if (dtype == AD_BF16)
-        bn_apply_kernel<bf16_t><<<blocks, 256, 0, s>>>((const bf16_t*)z, moving_mean, rstd_tmp, gamma, beta, (bf16_t*)y, npix, c, relu);
-    else
-        bn_apply_kernel<float><<<blocks, 256, 0, s>>>((const float*)z, moving_mean, rstd_tmp, gamma, beta, (float*)y, npix, c, relu);
+    const int cs = slice_channels(c, ept);
+    const int blocks = ew_blocks(npix * (cs / ept));
+    for (int c0 = 0; c0 < c; c0 += cs) {
+        if (dtype == AD_BF16)
+            bn_apply_kernel<bf16_t><<<blocks, 256, 0, s>>>((const bf16_t*)z + c0, moving_mean + c0, rstd_tmp + c0, gamma + c0,
+                                                           beta + c0, (bf16_t*)y + c0, npix, cs, relu, c);
+        else
+            bn_apply_kernel<float><<<blocks, 256, 0, s>>>((const float*)z + c0, moving_mean + c0, rstd_tmp + c0, gamma + c0,
+                                                          beta + c0, (float*)y + c0, npix, cs, relu, c);
+    }
     AD_LAUNCH_CHECK("ad_batchnorm_relu_fwd_infer");
     return AD_OK;
 }
@@ -507,23 +553,15 @@ extern "C" int ad_batchnorm_relu_bwd(const void* dy, const void* z, const float*
     AD_REQUIRE(npix > 0 && chan_ok(c, ept), "ad_batchnorm_relu_bwd: unsupported npix=%ld c=%d", (long)npix, c);
     if (!ws || ws_bytes < ad_batchnorm_ws_bytes(c)) return ad_set_error(AD_ERR_WS, "ad_batchnorm: workspace too small");
     hipStream_t s = (hipStream_t)stream;
-    float* part = (float*)ws;
-    const int vecs = c / ept;
-    const int rows = 256 / vecs > 0 ? 256 / vecs : 1;
-    int64_t nbl = (npix + rows - 1) / rows;
-    const int nb = (int)(nbl < NBLK ? nbl : NBLK);
-    size_t lds = (size_t)rows * 2 * c * sizeof(float);
-    if (dtype == AD_BF16)
-        bn_bwd_reduce_kernel<bf16_t><<<nb, 256, lds, s>>>((const bf16_t*)dy, (const bf16_t*)z, save_mean, save_rstd, gamma, beta, part, npix, c, relu);
-    else
-        bn_bwd_reduce_kernel<float><<<nb, 256, lds, s>>>((const float*)dy, (const float*)z, save_mean, save_rstd, gamma, beta, part, npix, c, relu);
-    colstats_finish_kernel<<<(2 * c + 3) / 4, 256, 0, s>>>(part, nb, c, 1.f, 1.f, nullptr, dgamma, dbeta);
-    const int blocks = ew_blocks(npix * vecs);
-    if (dtype == AD_BF16)
-        bn_bwd_apply_kernel<bf16_t><<<blocks, 256, 0, s>>>((const bf16_t*)dy, (const bf16_t*)z, save_mean, save_rstd, gamma, beta, dgamma, dbeta, (bf16_t*)dz, npix, c, relu);
-    else
-        bn_bwd_apply_kernel<float><<<blocks, 256, 0, s>>>((const float*)dy, (const float*)z, save_mean, save_rstd, gamma, beta, dgamma, dbeta, (float*)dz, npix, c, relu);
-    AD_LAUNCH_CHECK("ad_batchnorm_relu_bwd");
+    const int cs = slice_channels(c, ept);
+    for (int c0 = 0; c0 < c; c0 += cs) {
+        const int rc = dtype == AD_BF16
+            ? bn_bwd<bf16_t>((const bf16_t*)dy + c0, (const bf16_t*)z + c0, save_mean + c0, save_rstd + c0, gamma + c0, beta + c0,
+                             (bf16_t*)dz + c0, dgamma + c0, dbeta + c0, npix, cs, c, relu, (float*)ws, s)
+            : bn_bwd<float>((const float*)dy + c0, (const float*)z + c0, save_mean + c0, save_rstd + c0, gamma + c0, beta + c0,
+                            (float*)dz + c0, dgamma + c0, dbeta + c0, npix, cs, c, relu, (float*)ws, s);
+        if (rc) return rc;
+    }
     return AD_OK;
 }
 
@@ -533,10 +571,14 @@ extern "C" int ad_colsum(const void* x, float* out, int64_t npix, int c, void* w
     AD_REQUIRE(npix > 0 && chan_ok(c, ept), "ad_colsum: unsupported npix=%ld c=%d", (long)npix, c);
     if (!ws || ws_bytes < ad_batchnorm_ws_bytes(c)) return ad_set_error(AD_ERR_WS, "ad_colsum: workspace too small");
     hipStream_t s = (hipStream_t)stream;
-    int nb = 0;
-    int rc = dtype == AD_BF16 ? colstats<bf16_t>(x, nullptr, (float*)ws, npix, c, s, &nb) : colstats<float>(x, nullptr, (float*)ws, npix, c, s, &nb);
-    if (rc) return rc;
-    colstats_finish_kernel<<<(2 * c + 3) / 4, 256, 0, s>>>((const float*)ws, nb, c, 1.f, 0.f, nullptr, out, nullptr);
+    const int cs = slice_channels(c, ept);
+    for (int c0 = 0; c0 < c; c0 += cs) {
+        int nb = 0;
+        int rc = dtype == AD_BF16 ? colstats<bf16_t>((const bf16_t*)x + c0, nullptr, (float*)ws, npix, cs, c, s, &nb)
+                                  : colstats<float>((const float*)x + c0, nullptr, (float*)ws, npix, cs, c, s, &nb);
+        if (rc) return rc;
+        colstats_finish_kernel<<<(2 * cs + 3) / 4, 256, 0, s>>>((const float*)ws, nb, cs, 1.f, 0.f, nullptr, out + c0, nullptr);
+    }
     AD_LAUNCH_CHECK("ad_colsum");
     return AD_OK;
 }

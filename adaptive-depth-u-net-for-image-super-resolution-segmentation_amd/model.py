@@ -147,6 +147,10 @@ class Model:
         self.stop_training = False
         self.grad_sync: Optional[Callable[["Model"], float]] = None   # data-parallel hook (parallel.py)
         self.grad_ready: Optional[Callable[[int], None]] = None       # called with the low offset of finished grads
+        # Parity instrumentation: when set to a list, every forward / backward step appends (kind, name, tensors...) with
+        # the device tensors it read and wrote, so a test can re-run each step's arithmetic on the product's OWN inputs
+        # (tests/test_layerwise_gpu.py).  None (the default) costs nothing.
+        self.audit: Optional[list] = None
 
     # ------------------------------------------------------------------ graph
     def _register(self, name: str, shape: Tuple[int, ...]):
@@ -386,22 +390,32 @@ class Model:
                                                                    self.param(cs.ln + "/beta"), cs.cout)
                     if keep:
                         tape.append(("cla", cs, cur1, cur2, z, mean, rstd, step[2]))
+                    if self.audit is not None:
+                        self.audit.append(("fwd_cla", cs.name, cur1, cur2, z, a, mean, rstd))
                     cur1, cur2 = a, None
             elif kind == "down":
                 skips.append(cur1)
                 if keep:
                     tape.append(("down", step[1], cur1.shape[1], cur1.shape[2]))
-                cur1 = self.enc_down(cur1)
+                small = self.enc_down(cur1)
+                if self.audit is not None:
+                    self.audit.append(("fwd_resize", "enc_down", cur1, small))
+                cur1 = small
             elif kind == "up":
                 if keep:
                     tape.append(("up", cur1.shape[1], cur1.shape[2]))
-                cur1 = self.dec_up((cur1, skips[step[1]]))
+                big = self.dec_up((cur1, skips[step[1]]))
+                if self.audit is not None:
+                    self.audit.append(("fwd_resize", "dec_up", cur1, big))
+                cur1 = big
                 cur2 = None
             elif kind == "upconv":
                 cs, lvl = step[1], step[2]
                 u = ops.conv3x3_fwd(cur1, None, self._packs[cs.name][0], self.param(cs.name + "/bias"), cs.cout, relu=True)
                 if keep:
                     tape.append(("ca", cs, cur1, u))
+                if self.audit is not None:
+                    self.audit.append(("fwd_ca", cs.name, cur1, u))
                 # L.Concatenate()([x, skip]) (:261) is virtual: the skip joins as the second operand of the next conv
                 cur1, cur2 = u, skips[lvl]
             elif kind == "head":
@@ -410,11 +424,14 @@ class Model:
                 out, stats, sqerr = ops.head_fwd(cur1, w, b, x, target, self._ws, loss_kind=loss_kind, eps=eps)
                 if keep:
                     tape.append(("head", cur1))
+                if self.audit is not None:
+                    self.audit.append(("fwd_head", "residual_rgb", cur1, x, target, out, stats))
                 return out, stats, sqerr, tape
         raise AssertionError("plan without head")
 
     def _backward(self, tape: List[tuple], x: torch.Tensor, target: torch.Tensor, grad_scale: float):
         ws = self._ws
+        audit = self.audit
         dskips: Dict[int, torch.Tensor] = {}
         d = None
         while tape:
@@ -426,8 +443,11 @@ class Model:
                                  self.grad("residual_rgb/kernel").view(self.head, 3), self.grad("residual_rgb/bias"),
                                  grad_scale, ws, loss_kind=self.loss.kind, eps=self.loss.eps)
                 self._done("residual_rgb/kernel")
+                if audit is not None:
+                    audit.append(("bwd_head", "residual_rgb", rec[1], x, target, grad_scale, d))
             elif kind == "cla":
                 _, cs, x1, x2, z, mean, rstd, lvl = rec
+                d_in = d
                 dz = ops.layernorm_relu_bwd(d, z, mean, rstd, self.param(cs.ln + "/gamma"), self.param(cs.ln + "/beta"),
                                             self.grad(cs.ln + "/gamma"), self.grad(cs.ln + "/beta"),
                                             self.grad(cs.name + "/bias"), ws)
@@ -436,23 +456,37 @@ class Model:
                 else:
                     ops.conv3x3_wgrad(x1, x2, dz, self.grad(cs.name + "/kernel"), cs.cin, ws)
                 self._done(cs.name + "/kernel")
+                dsk = None
                 if not cs.need_dgrad:
                     d = None
                 elif x2 is not None:
-                    d, dskips[lvl] = ops.conv3x3_fwd(dz, None, self._packs[cs.name][1], None, cs.cin, split=x1.shape[-1])
+                    d, dsk = ops.conv3x3_fwd(dz, None, self._packs[cs.name][1], None, cs.cin, split=x1.shape[-1])
+                    dskips[lvl] = dsk
                 else:
                     d = ops.conv3x3_fwd(dz, None, self._packs[cs.name][1], None, self._cin_pad(cs))
+                if audit is not None:
+                    audit.append(("bwd_cla", cs.name, x1, x2, z, mean, rstd, d_in, dz, d, dsk))
             elif kind == "ca":
                 _, cs, xin, u = rec
+                d_in = d
                 dz = ops.relu_bwd(d, u, self.grad(cs.name + "/bias"), ws)
                 ops.conv3x3_wgrad(xin, None, dz, self.grad(cs.name + "/kernel"), cs.cin, ws)
                 self._done(cs.name + "/kernel")
                 d = ops.conv3x3_fwd(dz, None, self._packs[cs.name][1], None, cs.cin)
+                if audit is not None:
+                    audit.append(("bwd_ca", cs.name, xin, u, d_in, dz, d))
             elif kind == "up":
+                d_in = d
                 d = self.dec_up.resize_grad(d, rec[1], rec[2])
+                if audit is not None:
+                    audit.append(("bwd_resize", "dec_up", d_in, None, d))
             elif kind == "down":
                 _, lvl, h, w = rec
-                d = self.enc_down.resize_grad(d, h, w, out=dskips.pop(lvl))
+                d_in, acc = d, dskips.pop(lvl)
+                before = acc.clone() if audit is not None else None        # the skip gradient is accumulated into in place
+                d = self.enc_down.resize_grad(d, h, w, out=acc)
+                if audit is not None:
+                    audit.append(("bwd_resize", "enc_down", d_in, before, d))
 
     def _done(self, name: str):
         if self.grad_ready is not None:

@@ -269,7 +269,7 @@ def conv3x3_c3_wgrad(x: torch.Tensor, dz: torch.Tensor, dw_out: torch.Tensor, ws
     n, h, w, _ = x.shape
     lib = _lib.load()
     ws.ensure(lib.ad_conv3x3_c3_wgrad_ws_bytes(n, h, w))
-    with _timed("conv3x3_wgrad"):
+    with _timed("conv3x3_c3_wgrad", 2.0 * n * h * w * 27 * 64):
         check(lib.ad_conv3x3_c3_wgrad(_p(x), _p(dz), _p(dw_out), n, h, w, ws.ptr, ws.nbytes, AD_BF16, _stream()),
               "ad_conv3x3_c3_wgrad")
 
@@ -283,7 +283,8 @@ def conv3x3_wgrad(x1: torch.Tensor, x2: Optional[torch.Tensor], dz: torch.Tensor
     lib = _lib.load()
     need = lib.ad_conv3x3_wgrad_ws_bytes(n, h, w, c1 + c2, cout, dt(x1.dtype))
     ws.ensure(need)
-    with _timed("conv3x3_wgrad"):
+    with _timed("conv3x3_wgrad", 2.0 * n * h * w * 9 * (c1 + c2) * cout,
+                float(n * h * w * (c1 + c2 + cout) * x1.element_size())):
         check(lib.ad_conv3x3_wgrad(_p(x1), c1, _p(x2), c2, _p(dz), _p(dw_out), cin_real, n, h, w, cout,
                                    ws.ptr, ws.nbytes, dt(x1.dtype), _stream()), "ad_conv3x3_wgrad")
 

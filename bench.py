@@ -51,24 +51,49 @@ def synth_batch(rank, n, p, device):
     return torch.from_numpy(lr).to(device), torch.from_numpy(hr).to(device)
 
 
+def kernel_source_stamp():
+    """sha256 of the kernel sources a PMC measurement belongs to: a committed traffic figure is only quoted while the
+    kernels it was measured on are the ones in the tree."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "adaptive-depth-u-net-for-image-super-resolution-segmentation_amd", "csrc")
+    for name in ("conv.hip", "common.h"):
+        with open(os.path.join(csrc, name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(workload, dtype, batch):
-    """HBM bytes per launch of the conv3x3_fwd family from the committed rocprofv3 PMC passes (profiles/README.md);
-    None when the run is not the configuration those passes were taken on."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if (workload, dtype, batch) != ("K2p", "bf16", 64) or not os.path.exists(path):
+    """HBM bytes per launch of the conv3x3_fwd family from the committed rocprofv3 PMC passes (profiles/README.md).
+    PMC counters need their own rocprofv3 runs, so the figure is read from the newest profiles/r*_pmc_traffic.json; it is
+    None when that file was measured on another configuration or on other kernel sources (stale)."""
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if (workload, dtype, batch) != ("K2p", "bf16", 64) or not cands:
         return None
-    with open(path) as f:
-        return json.load(f)["families"]["conv3x3_fwd"]["hbm_bytes_per_launch"]
+    with open(cands[-1]) as f:
+        rec = json.load(f)
+    if rec.get("kernel_source_stamp") != kernel_source_stamp():
+        return None
+    return rec["families"]["conv3x3_fwd"]["hbm_bytes_per_launch"]
 
 
-def cpu_baseline(scale, depth, patch, budget_seconds=12.0):
-    """Oracle ("port") timed on the host cores: whole fp32 train steps of batch 1 until `budget_seconds` have passed."""
+def cpu_baseline(scale, depth, patch, workload):
+    """The CPU path timed beside the kernels on this box's host cores (rank 0, N = 1 only), ~35 s in total.
+
+    TensorFlow/Keras cannot run here, so the baseline is a port: `value` = whole train steps of the SAME
+    workload at batch 4 on the PyTorch-CPU stand-in (oracle/torch_standin.py: F.conv2d/oneDNN + layer_norm +
+    interpolate(antialias) + autograd, float32, all cores); next to it the reference's own CPU-runnable shapes K1 and R3
+    at the reference CLI's batch 4 and the NumPy oracle the parity tests use (batch 1)."""
     from oracle.sr_unet import SRUNetOracle
-    try:
-        from threadpoolctl import threadpool_info
-        cores = max([d.get("num_threads", 1) for d in threadpool_info()] or [os.cpu_count() or 1])
-    except Exception:
-        cores = os.cpu_count() or 1
+    from oracle.torch_standin import time_train_steps
+    ips, steps, dt, threads = time_train_steps(scale, depth, patch, 4, 10.0)
+    out = {"value": ips, "unit": "images/s", "cores": int(threads), "kind": "port",
+           "implementation": "PyTorch-CPU float32 stand-in for the TF/Keras CPU path (TF is not installable here)",
+           "sample": f"{steps} train step(s) of batch 4 of {workload} after one warm-up step ({dt:.1f} s)"}
+    for name, (sc, dp, pp) in (("K1", (0.5, 2, 128)), ("R3", (0.5, 3, 256))):
+        v, st, d, _ = time_train_steps(sc, dp, pp, 4, 6.0)
+        out[f"{name}_batch4_torch_cpu"] = {"value": v, "unit": "images/s", "sample": f"{st} train step(s), {d:.1f} s"}
     rng = np.random.default_rng(1234)
     m = SRUNetOracle(scale, depth, patch)
     params = m.init_params(rng, dtype=np.float32, head_uniform=0.05)
@@ -76,13 +101,49 @@ def cpu_baseline(scale, depth, patch, budget_seconds=12.0):
     hr = rng.random((1, patch, patch, 3), dtype=np.float32)
     lr = np.clip(hr + 0.05 * rng.standard_normal(hr.shape, dtype=np.float32), 0, 1).astype(np.float32)
     t0 = time.time()
-    budget_images = 0
-    while budget_images == 0 or time.time() - t0 < budget_seconds:
+    n = 0
+    while n == 0 or time.time() - t0 < 6.0:
         m.train_step(params, state, lr, hr, lr=1e-4)
-        budget_images += 1
-    dt = time.time() - t0
-    return {"value": budget_images / dt, "unit": "images/s", "cores": int(cores), "kind": "port",
-            "sample": f"{budget_images} train step(s) of batch 1 on the same model (NumPy float32 oracle, {dt:.1f} s)"}
+        n += 1
+    d = time.time() - t0
+    out["numpy_oracle"] = {"value": n / d, "unit": "images/s", "sample": f"{n} train step(s) of batch 1 of {workload}, float32, {d:.1f} s"}
+    return out
+
+
+def micro_kernel(device, iters=10):
+    """north_star's kernel target, measured in this process right after the timed region: ONE 3x3 convolution 64 -> 64
+    on 32 x 256 x 256 bf16 (SURVEY 8d row mu), forward / dgrad / wgrad each timed with HIP events on the launch stream
+    over `iters` back-to-back launches (after 3 warm-ups), and summed: 3 x 154.6 GFLOP over the three times."""
+    from adunet_amd import ops
+    n, hw, c = 32, 256, 64
+    g = torch.Generator(device="cpu").manual_seed(7)
+    x = (torch.rand((n, hw, hw, c), generator=g) * 2 - 1).to(device=device, dtype=torch.bfloat16)
+    dz = (torch.rand((n, hw, hw, c), generator=g) * 2 - 1).to(device=device, dtype=torch.bfloat16)
+    w = ((torch.rand((3, 3, c, c), generator=g) * 2 - 1) * 0.05).to(device)
+    bias = torch.zeros(c, device=device)
+    wf, wd = ops.conv3x3_pack(w, c, torch.bfloat16)
+    dw = torch.empty_like(w)
+    ws = ops.Workspace(device)
+    flops = 2.0 * n * hw * hw * 9 * c * c
+    jobs = {"fwd": lambda: ops.conv3x3_fwd(x, None, wf, bias, c),
+            "dgrad": lambda: ops.conv3x3_fwd(dz, None, wd, None, c),
+            "wgrad": lambda: ops.conv3x3_wgrad(x, None, dz, dw, c, ws)}
+    out, total_ms = {"shape": f"N={n}, {hw}x{hw}, {c}->{c}, bf16", "gflop_per_pass": flops / 1e9, "iters": iters}, 0.0
+    for name, fn in jobs.items():
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        total_ms += ms
+        out[name] = {"ms": ms, "tflops": flops / ms / 1e9, "frac": flops / ms / 1e9 / PEAK_BF16_TFLOPS}
+    out["fwd_dgrad_wgrad"] = {"ms": total_ms, "tflops": 3 * flops / total_ms / 1e9,
+                              "frac": 3 * flops / total_ms / 1e9 / PEAK_BF16_TFLOPS}
+    return out
 
 
 def launch_ranks(n: int) -> int:
@@ -109,6 +170,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch override")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-micro", action="store_true", help="skip the 64->64 @256x256 N=32 micro-kernel measurement")
     ap.add_argument("--breakdown", action="store_true", help="print the per-op-family time table to stderr")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
     args = ap.parse_args()
@@ -186,26 +248,55 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
 
+    exposed_ms = None
+    if use_dist:
+        # exposed gradient exchange: time the compute stream sits waiting for RCCL, measured over a few extra steps
+        model._dp.measure = True
+        probe = min(args.steps, 5)
+        for _ in range(probe):
+            step_fn(lr_img, hr_img)
+        torch.cuda.synchronize()
+        exposed_ms = model._dp.exposed_ms() / probe
+        model._dp.measure = False
+
     if rank == 0:
         fwd, first = conv_flops_per_image(model)
         f_step = 3.0 * fwd - first
         summ = timer.summary()
-        # dominant kernel family: the forward convs and the dgrads (same kernels on the rotated weight pack) that run
-        # WITHOUT the fused LayerNorm epilogue; the five fused launches are their own timer family.  FLOPs are the
-        # algorithmic ones: what the wrappers launched minus the zero-padded channels of the first conv (3 -> 32).
+        per_step = 1.0 / timed_steps
+        c3 = "conv3x3_c3_ln_relu_fwd" in summ       # bf16: the first conv has its own 3-channel kernels, nothing is padded
+        # the wrappers book what they launched; the first conv of the fp32 path is zero-padded 3 -> 16 channels and
+        # those padded FLOPs are not algorithmic work
+        pad_ratio = 0.0 if c3 else model._cin_pad(next(iter(model.convs.values()))) / 3.0 - 1.0
+        padded_first = first * pad_ratio * batch
+
+        def family(names, minus=0.0):
+            cnt = sum(summ.get(k, (0, 0.0))[0] for k in names)
+            ms = sum(summ.get(k, (0, 0.0))[1] for k in names) * per_step
+            fl = sum(timer.work(k) for k in names) * per_step - minus
+            return {"launches_per_step": cnt * per_step, "gflop_per_step": fl / 1e9, "ms_per_step": ms,
+                    "tflops": fl / ms / 1e9 if ms > 0 else None,
+                    "frac": fl / ms / 1e9 / PEAK_BF16_TFLOPS if ms > 0 else None}
+
+        fam = {
+            # forward convs and dgrads (the same kernels on the rotated pack) launched WITHOUT the fused LayerNorm epilogue
+            # (fp32 runs every Conv2D -> LayerNorm link as two launches, so the padded first conv is booked here)
+            "fwd_dgrad": family(["conv3x3_fwd"], padded_first if args.dtype == "f32" else 0.0),
+            # Conv2D -> LayerNorm -> ReLU in one launch (incl. the dedicated 3-channel first layer)
+            "fused_ln_fwd": family(["conv3x3_ln_relu_fwd", "conv3x3_c3_ln_relu_fwd"],
+                                   padded_first if args.dtype != "f32" else 0.0),
+            "wgrad": family(["conv3x3_wgrad", "conv3x3_c3_wgrad"], padded_first),
+        }
+        conv_ms = sum(f["ms_per_step"] for f in fam.values())
+        conv_gf = sum(f["gflop_per_step"] for f in fam.values())
+        total_ms = sum(v[1] for v in summ.values()) * per_step
         n_launch, ms = summ["conv3x3_fwd"]
-        padded_first = first * (model._cin_pad(next(iter(model.convs.values()))) / 3.0 - 1.0) * batch * timed_steps
-        if "conv3x3_c3_ln_relu_fwd" in summ:      # bf16: the first conv has its own 3-channel kernel, nothing was padded
-            padded_first = 0.0
-        flops_kernel = timer.work("conv3x3_fwd") - padded_first
-        achieved = flops_kernel / (ms * 1e-3) / 1e12
-        fused = summ.get("conv3x3_ln_relu_fwd", (0, 0.0))
-        total_ms = sum(v[1] for v in summ.values())
+        dom = fam["fwd_dgrad"]
         if args.breakdown:
-            print(f"{'op family':<22}{'launches/step':>14}{'ms/step':>10}{'share':>8}", file=sys.stderr)
+            print(f"{'op family':<26}{'launches/step':>14}{'ms/step':>10}{'share':>8}", file=sys.stderr)
             for k, (cnt, t_ms) in sorted(summ.items(), key=lambda kv: -kv[1][1]):
-                print(f"{k:<22}{cnt / timed_steps:>14.1f}{t_ms / timed_steps:>10.3f}{t_ms / total_ms:>8.1%}", file=sys.stderr)
-            print(f"{'(sum of op events)':<22}{'':>14}{total_ms / timed_steps:>10.3f}", file=sys.stderr)
+                print(f"{k:<26}{cnt * per_step:>14.1f}{t_ms * per_step:>10.3f}{t_ms * per_step / total_ms:>8.1%}", file=sys.stderr)
+            print(f"{'(sum of op events)':<26}{'':>14}{total_ms:>10.3f}", file=sys.stderr)
         img_s = batch * world * args.steps / elapsed
         line = {
             "metric": METRIC, "value": img_s, "unit": "images/s", "n_gpus": world, "steps": args.steps,
@@ -213,25 +304,34 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.workload}: SR U-Net scale {scale} depth {depth} patch {patch} train step",
                        "global_batch": batch * world, "per_gpu_batch": batch, "params": model.count_params(),
-                       "parallelism": f"dp{world}", "launch": "hipGraph replay" if graphed else "eager", "conv_gflop_per_image_step": f_step / 1e9,
-                       "model_tflops": img_s * f_step / 1e12, "final_loss": float(last_loss),
-                       "final_psnr": float(last_psnr)},
+                       "parallelism": f"dp{world}", "launch": "hipGraph replay" if graphed else "eager",
+                       "conv_gflop_per_image_step": f_step / 1e9, "model_tflops": img_s * f_step / world / 1e12,
+                       "final_loss": float(last_loss), "final_psnr": float(last_psnr)},
             "roofline": {"bound": "mfma",
                          "kernel": "forward-conv / dgrad family: conv3x3_fwd_wres_kernel, conv3x3_fwd_ws_kernel, "
                                    "conv3x3_fwd_kernel (+ splitk_finalize_kernel), launches without the fused "
                                    "LayerNorm epilogue",
-                         "fused_ln_launches_per_step": fused[0] / timed_steps, "fused_ln_ms_per_step": fused[1] / timed_steps,
-                         "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_BF16_TFLOPS,
+                         "achieved": dom["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": dom["frac"],
                          "traffic": pmc_traffic(args.workload, args.dtype, batch),
                          "algorithmic_bytes_per_launch": timer.nbytes("conv3x3_fwd") / n_launch,
-                         "launches_per_step": n_launch / timed_steps, "avg_launch_ms": ms / n_launch,
+                         "launches_per_step": n_launch * per_step, "avg_launch_ms": ms / n_launch,
+                         "gflop_per_launch": dom["gflop_per_step"] / (n_launch * per_step),
+                         # the whole truth next to the dominant family: SURVEY 8d's step-level figure (every HBM-bound op
+                         # included: images/s x conv FLOPs per image-step / peak, per GPU) and every conv kernel family
+                         "frac_step": img_s / world * f_step / 1e12 / PEAK_BF16_TFLOPS,
+                         "frac_all_conv_kernels": conv_gf / conv_ms / PEAK_BF16_TFLOPS if conv_ms > 0 else None,
+                         "families": fam,
+                         "non_conv_ms_per_step": total_ms - conv_ms,
                          "timing": ("HIP events around every launch of %d eager steps run right after the graph-replayed "
-                                    "timed region" % timed_steps) if graphed else "HIP events inside the timed region",
-                         "gflop_per_launch": flops_kernel / n_launch / 1e9},
+                                    "timed region" % timed_steps) if graphed else "HIP events inside the timed region"},
         }
+        if use_dist:
+            line["rccl_ranks"] = dist.get_world_size()
+            line["exposed_comm_ms_per_step"] = exposed_ms
+        if world == 1 and args.dtype == "bf16" and not args.no_micro:
+            line["micro"] = micro_kernel(device)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(scale, depth, patch)
+            line["cpu_baseline"] = cpu_baseline(scale, depth, patch, args.workload)
         print(json.dumps(line), flush=True)
     if use_dist:
         del step_fn, model            # graphs and side streams go before the communicator they reference

@@ -1,0 +1,227 @@
+"""Layer-wise ("teacher-forced") parity inside the full BASELINE configurations.
+
+End-to-end comparisons of a reduced-precision network have a noise floor that no oracle removes: one bf16 rounding
+that falls the other way (fp32 vs float64 accumulation order decides it for ~1 element in 10^4) changes the inputs of
+the next layer by one unit in the last place, which flips a few dozen roundings there, and after a handful of layers
+most stored values differ by one ulp (tools/diag_seg.py prints the cascade).  So the end-to-end tests bound the noise,
+and THIS file checks the arithmetic: the model records every tensor each step reads and writes (`Model.audit`), and
+each step is recomputed in float64 by the oracle's op ON THE PRODUCT'S OWN INPUTS.  Errors cannot compound, so the
+bounds are those of a single kernel:
+
+* tensors stored in bf16: |got - want| <= 2^-8 |want| + 3e-5 max|want|  (half an ulp of rounding, one ulp if the fp32
+  sum landed on the other side of a rounding boundary, plus fp32 accumulation error relative to the tensor's scale);
+* tensors stored in fp32 (fp32 path, statistics, parameter gradients): 1e-4 of the tensor's max magnitude
+  (parameter gradients are sums over up to 131 072 pixels accumulated in fp32);
+* ReLU / clip kinks: where a pre-activation is within 1e-5 of the kink fp32 rounding decides the side, and both
+  one-sided derivatives are valid: such pixels are left out of the element-wise comparison and the reductions are
+  allowed the difference between the two choices.
+
+This is the test that takes the 1x1x1024 bottleneck, split-K launches, 2-image / 16-image tiles, the wave-specialised
+kernels and the fused Conv->LayerNorm->ReLU launches of K2' (and R3's 128/64/32 pyramid) to the oracle inside the
+model they are benchmarked in.  Reference arithmetic: Super_resolution/code/train_adaptive_unet.py:200-287,308-334.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ops as ref
+
+pytestmark = pytest.mark.gpu
+
+KINK = 1e-5
+
+
+def f64(t):
+    return t.detach().float().cpu().numpy().astype(np.float64)
+
+
+def check_stored(got_t, want, what, store_bf16):
+    got = f64(got_t)
+    scale = np.abs(want).max() + 1e-30
+    tol = (2.0 ** -8 * np.abs(want) + 3e-5 * scale) if store_bf16 else np.full_like(want, 3e-5 * scale)
+    bad = np.abs(got - want) > tol
+    assert not bad.any(), (what, int(bad.sum()), float(np.abs(got - want).max() / scale))
+
+
+def check_f32(got, want, what, tol=1e-4, slack=None):
+    got = np.asarray(got, np.float64)
+    lim = tol * (np.abs(want).max() + 1e-30) + (0 if slack is None else slack)
+    err = np.abs(got - want)
+    assert (err <= lim).all(), (what, float((err / (np.abs(want).max() + 1e-30)).max()))
+
+
+def audit_sr_step(model, lr, hr):
+    """Runs forward + loss + backward with the audit on and recomputes every recorded step."""
+    from adunet_amd import _lib, ops
+    lib = _lib.load()
+    bf16 = model.dtype == torch.bfloat16
+    q = ref.bf16_round if bf16 else (lambda a: a)
+    W = {k: v.astype(np.float64) for k, v in model.get_weights().items()}
+    model.audit = []
+    out, loss, psnr, (tape, x, t) = model.forward_loss(lr, hr, keep=True)
+    model._backward(tape, x, t, 1.0 / x.numel())
+    torch.cuda.synchronize()
+    records, model.audit = model.audit, None
+    G = {k: v.astype(np.float64) for k, v in model.get_grads().items()}
+    n = lr.shape[0]
+    seen = set()
+
+    def conv_input(name, x1, x2):
+        cin = model.convs[name].cin
+        a = f64(x1)
+        if x1.dtype == torch.float32 and bf16:
+            a = q(a)                                           # the first-layer kernels stage the raw batch as bf16
+        a = a[..., :cin] if x2 is None else np.concatenate([a, f64(x2)], axis=-1)
+        assert a.shape[-1] == cin
+        return a
+
+    def is_fused(name, x1, x2):
+        cs = model.convs[name]
+        if not bf16:
+            return False
+        if x1.dtype == torch.float32:
+            return True                                        # dedicated 3-channel kernel: conv + LayerNorm in one
+        c1, c2 = x1.shape[-1], (x2.shape[-1] if x2 is not None else 0)
+        return bool(lib.ad_conv3x3_ln_relu_is_fused(n, cs.hw, cs.hw, c1, c2, cs.cout, ops.dt(model.dtype)))
+
+    for rec in records:
+        kind, name = rec[0], rec[1]
+        seen.add(kind)
+        if kind == "fwd_cla":
+            _, _, x1, x2, z, a, mean, rstd = rec
+            ln = model.convs[name].ln
+            want_z = ref.conv2d_same_fwd(conv_input(name, x1, x2), q(W[name + "/kernel"]), W[name + "/bias"])
+            check_stored(z, want_z, name + " z", bf16)
+            zin = want_z if is_fused(name, x1, x2) else f64(z)  # statistics: fp32 accumulators (one kernel) or stored z
+            y, (xhat, rs) = ref.layernorm_fwd(zin, W[ln + "/gamma"], W[ln + "/beta"])
+            check_f32(mean.cpu().numpy().reshape(zin.shape[:-1]), zin.mean(axis=-1), name + " mean", 1e-5,
+                      slack=1e-6 * np.abs(zin).max())
+            check_f32(rstd.cpu().numpy().reshape(zin.shape[:-1]), rs[..., 0], name + " rstd", 1e-4)
+            check_stored(a, ref.relu_fwd(y), name + " act", bf16)
+        elif kind == "fwd_resize":
+            _, _, xin, xout = rec
+            check_stored(xout, ref.resize_aa_fwd(f64(xin), xout.shape[1], xout.shape[2]), name + " fwd", bf16)
+        elif kind == "fwd_ca":
+            _, _, xin, u = rec
+            want = ref.relu_fwd(ref.conv2d_same_fwd(f64(xin), q(W[name + "/kernel"]), W[name + "/bias"]))
+            check_stored(u, want, name + " relu(conv)", bf16)
+        elif kind == "fwd_head":
+            _, _, xh, inp, target, o, stats = rec
+            r = ref.conv2d_same_fwd(f64(xh), W["residual_rgb/kernel"], W["residual_rgb/bias"])
+            want_out, pre = ref.clip_add_fwd(f64(inp), r)
+            check_f32(f64(o), want_out, "enhanced_rgb", 1e-5)
+            st = stats.cpu().numpy()
+            assert abs(st[2] - ref.charbonnier_fwd(f64(target), want_out)) < 1e-5 * st[2]
+            assert abs(st[1] - np.mean(ref.psnr_per_image(f64(target), want_out))) < 1e-3          # dB
+        elif kind == "bwd_head":
+            _, _, xh, inp, target, gscale, d = rec
+            r = ref.conv2d_same_fwd(f64(xh), W["residual_rgb/kernel"], W["residual_rgb/bias"])
+            want_out, pre = ref.clip_add_fwd(f64(inp), r)
+            assert abs(gscale * want_out.size - 1.0) < 1e-12
+            dr = ref.clip_add_bwd(ref.charbonnier_bwd(f64(target), want_out), pre)
+            edge = (np.abs(pre) < KINK) | (np.abs(pre - 1.0) < KINK)          # clip kinks: either side is valid
+            dxh, dw, db = ref.conv2d_same_bwd(f64(xh), W["residual_rgb/kernel"], dr)
+            ok = ~edge.any(axis=-1)
+            got = f64(d)
+            check_stored_masked(got, dxh, ok, "d head activations", bf16)
+            slack = np.abs(ref.charbonnier_bwd(f64(target), want_out) * edge).sum() * np.abs(f64(xh)).max()
+            check_f32(G["residual_rgb/kernel"], dw, "residual_rgb/kernel grad", slack=slack)
+            check_f32(G["residual_rgb/bias"], db, "residual_rgb/bias grad", slack=slack)
+        elif kind == "bwd_cla":
+            _, _, x1, x2, z, mean, rstd, d_in, dz, d, dsk = rec
+            ln = model.convs[name].ln
+            gam, bet = W[ln + "/gamma"], W[ln + "/beta"]
+            zs = f64(z)
+            mu = mean.cpu().numpy().astype(np.float64).reshape(zs.shape[:-1] + (1,))
+            rs = rstd.cpu().numpy().astype(np.float64).reshape(zs.shape[:-1] + (1,))
+            xhat = (zs - mu) * rs
+            y = xhat * gam + bet
+            din = f64(d_in)
+            res = [ref.layernorm_bwd(din * (y > thr), gam, (xhat, rs)) for thr in (0.0, KINK, -KINK)]
+            ok = ~(np.abs(y) <= KINK).any(axis=-1)             # pixels without an element on the ReLU kink
+            check_stored_masked(f64(dz), res[0][0], ok, name + " dz", bf16)
+            for j, pname in ((1, ln + "/gamma"), (2, ln + "/beta")):
+                check_f32(G[pname], res[0][j], pname + " grad", slack=np.abs(res[1][j] - res[2][j]))
+            # conv backward on the product's own dz
+            dzp = f64(dz)
+            xin = conv_input(name, x1, x2)
+            need_dx = d is not None
+            dx, dw, db = ref.conv2d_same_bwd(xin, q(W[name + "/kernel"]), dzp, need_dx=need_dx)
+            check_f32(G[name + "/kernel"], dw, name + "/kernel grad")
+            check_f32(G[name + "/bias"], db, name + "/bias grad")
+            if need_dx:
+                c1 = d.shape[-1] if dsk is not None else model.convs[name].cin
+                check_stored(d[..., :c1] if dsk is None else d, dx[..., :c1], name + " dgrad", bf16)
+                if dsk is not None:
+                    check_stored(dsk, dx[..., c1:], name + " dgrad (skip half)", bf16)
+        elif kind == "bwd_ca":
+            _, _, xin, u, d_in, dz, d = rec
+            want_dz = f64(d_in) * (f64(u) > 0)
+            assert np.array_equal(f64(dz), want_dz), name + " relu grad"
+            dx, dw, db = ref.conv2d_same_bwd(f64(xin), q(W[name + "/kernel"]), want_dz)
+            check_f32(G[name + "/kernel"], dw, name + "/kernel grad")
+            check_f32(G[name + "/bias"], db, name + "/bias grad")
+            check_stored(d, dx, name + " dgrad", bf16)
+        elif kind == "bwd_resize":
+            _, _, d_in, before, d = rec
+            want = ref.resize_aa_bwd(f64(d_in), d.shape[1], d.shape[2])
+            if before is not None:
+                want = want + f64(before)
+            check_stored(d, want, name + " bwd", bf16)
+    assert seen == {"fwd_cla", "fwd_resize", "fwd_ca", "fwd_head", "bwd_head", "bwd_cla", "bwd_ca", "bwd_resize"}
+    return len(records)
+
+
+def check_stored_masked(got, want, ok_pixels, what, store_bf16):
+    scale = np.abs(want).max() + 1e-30
+    tol = (2.0 ** -8 * np.abs(want) + 3e-5 * scale) if store_bf16 else np.full_like(want, 3e-5 * scale)
+    bad = (np.abs(got - want) > tol) & ok_pixels[..., None]
+    assert not bad.any(), (what, int(bad.sum()), float((np.abs(got - want) * ok_pixels[..., None]).max() / scale))
+    assert ok_pixels.mean() > 0.99, (what, "too many pixels on a kink", float(ok_pixels.mean()))
+
+
+def build(scale, depth, p, dtype, device):
+    from adunet_amd.model import Adam, build_losses_and_metrics, build_super_resolution_unet
+    model, _ = build_super_resolution_unet(scale, depth_override=depth, input_size=p, dtype=dtype, device=device)
+    loss, metrics = build_losses_and_metrics("charbonnier")
+    model.compile(optimizer=Adam(1e-3), loss=loss, metrics=metrics)
+    model._require_device()
+    model.set_weights(model.initial_weights(np.random.default_rng(1234), head_uniform=0.05))
+    return model
+
+
+def synth(rng, n, p):
+    hr = rng.random((n, p, p, 3), dtype=np.float32)
+    lr = np.clip(hr + 0.05 * rng.standard_normal(hr.shape).astype(np.float32), 0, 1).astype(np.float32)
+    return lr, hr
+
+
+CONFIGS = [
+    ("small-ragged", 0.6, 3, 40, 3),
+    ("K2p", 0.25, 4, 256, 2),        # BASELINE `metric` headline / config 2 (depth 4, x4): pyramid 256/64/16/4/1
+    ("R3", 0.5, 3, 256, 1),          # the reference's own Experiment-1 shape: 256/128/64/32
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("cfg", CONFIGS, ids=[c[0] for c in CONFIGS])
+def test_every_step_of_the_model_against_the_oracle(device, cfg, dtype):
+    _, scale, depth, p, n = cfg
+    model = build(scale, depth, p, dtype, device)
+    lr, hr = synth(np.random.default_rng(4321), n, p)
+    nrec = audit_sr_step(model, lr, hr)
+    # forward: 2 convs per block (2 depth + 2 blocks), depth up-convs, 2 depth resizes, head; backward: the same again
+    assert nrec == 2 * (2 * (2 * depth + 2) + depth + 2 * depth + 1)
+
+
+def test_audit_is_off_by_default_and_does_not_change_results(device):
+    model = build(0.5, 2, 32, torch.bfloat16, device)
+    lr, hr = synth(np.random.default_rng(1), 2, 32)
+    assert model.audit is None
+    out0, loss0, _, (tape, x, t) = model.forward_loss(lr, hr, keep=True)
+    model._backward(tape, x, t, 1.0 / x.numel())
+    g0 = model.G.clone()
+    model.audit = []
+    out1, loss1, _, (tape, x, t) = model.forward_loss(lr, hr, keep=True)
+    model._backward(tape, x, t, 1.0 / x.numel())
+    assert torch.equal(out0, out1) and torch.equal(g0, model.G) and len(model.audit) > 10

@@ -148,50 +148,30 @@ def test_tier2_ops_match_torch():
 
 
 def test_whole_model_gradients_by_torch_autograd():
-    """Independent check of the oracle's hand-written backward: rebuild the same network from torch ops."""
-    m = SRUNetOracle(0.6, 2, 20, base_channels=8, residual_head_channels=8)
+    """Independent check of the oracle's hand-written backward: the same network rebuilt from torch ops
+    (oracle/torch_standin.py, which is also bench.py's PyTorch-CPU baseline)."""
+    from oracle.torch_standin import TorchSRUNet
+    net = TorchSRUNet(0.6, 2, 20, base_channels=8, head_channels=8, dtype=torch.float64)
+    m = net.oracle
     params = m.init_params(np.random.default_rng(3), head_uniform=0.05)
     hr = RNG.random((2, 20, 20, 3))
     lr = np.clip(hr + 0.05 * RNG.standard_normal(hr.shape), 0, 1)
     want_loss, grads, out, _ = m.loss_and_grads(params, lr, hr)
-    P = {k: t(v) for k, v in params.items()}
-
-    def conv(x, name, k=3):
-        return F.conv2d(x, P[name + "/kernel"].permute(3, 2, 0, 1), P[name + "/bias"], padding=k // 2)
-
-    def ln(x, name):
-        y = F.layer_norm(x.permute(0, 2, 3, 1), (x.shape[1],), P[name + "/gamma"], P[name + "/beta"], eps=1e-3)
-        return y.permute(0, 3, 1, 2)
-
-    def rs(x, s):
-        return F.interpolate(x, size=(s, s), mode="bilinear", antialias=True, align_corners=False)
-
-    x = nchw(torch.tensor(lr))
-    inp = x
-    names = iter([k[:-7] for k in params if k.endswith("/kernel")])
-    lns = iter([k[:-6] for k in params if k.endswith("/gamma")])
-
-    def block(v):
-        v = F.relu(ln(conv(v, next(names)), next(lns)))
-        return F.relu(ln(conv(v, next(names)), next(lns)))
-
-    skips = []
-    for lvl in range(2):
-        x = block(x)
-        skips.append(x)
-        x = rs(x, m.sizes[lvl + 1])
-    x = block(x)
-    for lvl in (1, 0):
-        x = F.relu(conv(rs(x, m.sizes[lvl]), next(names)))
-        x = block(torch.cat([x, skips[lvl]], dim=1))
-    x = block(x)
-    o = torch.clamp(inp + conv(x, "residual_rgb", k=1), 0, 1).permute(0, 2, 3, 1)
-    loss = torch.sqrt((torch.tensor(hr) - o) ** 2 + 1e-6).mean()
+    net.set_params(params)
+    loss, o = net.loss(torch.tensor(lr), torch.tensor(hr))
     loss.backward()
     assert np.isclose(float(loss), want_loss, rtol=1e-5)        # resize tap weights are float32 in the oracle (as in TF)
+    assert np.abs(o.detach().numpy() - out).max() < 1e-6
     for k in params:
-        g = P[k].grad.numpy()
+        g = net.P[k].grad.numpy()
         assert np.abs(g - grads[k]).max() <= 2e-5 * max(np.abs(g).max(), 1e-12) + 1e-12, k
+    # ... and its Keras-form Adam step against the oracle's
+    state = {}
+    m.train_step(params, state, lr, hr, lr=1e-3)
+    net.set_params({k: v for k, v in m.init_params(np.random.default_rng(3), head_uniform=0.05).items()})
+    net.train_step(torch.tensor(lr), torch.tensor(hr), lr=1e-3)
+    for k in params:
+        assert np.abs(net.P[k].detach().numpy() - params[k]).max() < 2e-5, k
 
 
 def test_seg_loss_gradient_by_torch_autograd():
