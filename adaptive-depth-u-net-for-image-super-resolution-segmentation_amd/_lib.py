@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # ADUNET_LIB overrides the path (diagnostic / ablation builds of the same C ABI)
 LIB_PATH = os.environ.get("ADUNET_LIB") or os.path.join(_HERE, "csrc", "libadunet_hip.so")
 
-AD_F32, AD_BF16 = 0, 1
+AD_F32, AD_BF16, AD_F16 = 0, 1, 2
 EPI_NONE, EPI_RELU = 0, 1
 
 _vp, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
@@ -45,7 +45,7 @@ SIGNATURES = {
     "ad_resample": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "ad_head_ws_bytes": (_sz, [_i, _i]),
     "ad_head_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _f, _vp, _sz, _i, _vp]),
-    "ad_head_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _f, _f, _vp, _sz, _i, _vp]),
+    "ad_head_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _f, _f, _vp, _vp, _sz, _i, _vp]),
     "ad_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _f, _vp]),
     "ad_adam_alpha": (_f, [_f, _f, _f, _i]),
     "ad_adam_step_dev": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _f, _f, _f, _f, _vp]),
@@ -60,7 +60,10 @@ SIGNATURES = {
     "ad_pixel_shuffle2": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ad_seg_head_ws_bytes": (_sz, [_i, _i]),
     "ad_seg_head_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _sz, _i, _vp]),
-    "ad_seg_head_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _f, _f, _f, _vp, _sz, _i, _vp]),
+    "ad_seg_head_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _f, _f, _f, _vp, _vp, _sz, _i, _vp]),
+    "ad_loss_scale_check": (_i, [_vp, _i64, _vp, _vp]),
+    "ad_loss_scale_update": (_i, [_vp, _i, _vp]),
+    "ad_adam_step_scaled": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _f, _f, _f, _f, _vp, _vp]),
 }
 
 _lib = None

@@ -15,7 +15,7 @@ int ad_set_error(int code, const char* fmt, ...) {
 
 extern "C" int ad_version(void) { return 1; }
 extern "C" const char* ad_last_error(void) { return g_err; }
-extern "C" int ad_cin_granule(int dtype) { return dtype == AD_BF16 ? 32 : 16; }
+extern "C" int ad_cin_granule(int dtype) { return ad_is_half(dtype) ? 32 : 16; }
 
 template <typename TI, typename TO>
 __global__ void cast_kernel(const TI* __restrict__ x, TO* __restrict__ y, int64_t n) {
@@ -29,16 +29,10 @@ extern "C" int ad_cast(const void* x, int dtype_in, void* y, int dtype_out, int6
     hipStream_t s = (hipStream_t)stream;
     int blocks = (int)((count + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    if (dtype_in == AD_F32 && dtype_out == AD_BF16)
-        cast_kernel<float, bf16_t><<<blocks, 256, 0, s>>>((const float*)x, (bf16_t*)y, count);
-    else if (dtype_in == AD_BF16 && dtype_out == AD_F32)
-        cast_kernel<bf16_t, float><<<blocks, 256, 0, s>>>((const bf16_t*)x, (float*)y, count);
-    else if (dtype_in == AD_F32 && dtype_out == AD_F32)
-        cast_kernel<float, float><<<blocks, 256, 0, s>>>((const float*)x, (float*)y, count);
-    else if (dtype_in == AD_BF16 && dtype_out == AD_BF16)
-        cast_kernel<bf16_t, bf16_t><<<blocks, 256, 0, s>>>((const bf16_t*)x, (bf16_t*)y, count);
-    else
+    if (!ad_dtype_ok(dtype_in) || !ad_dtype_ok(dtype_out))
         return ad_set_error(AD_ERR_ARG, "ad_cast: bad dtype %d -> %d", dtype_in, dtype_out);
+    AD_DISPATCH_DTYPE(dtype_in, TI_,
+        AD_DISPATCH_DTYPE(dtype_out, TO_, cast_kernel<TI_, TO_><<<blocks, 256, 0, s>>>((const TI_*)x, (TO_*)y, count);))
     AD_LAUNCH_CHECK("ad_cast");
     return AD_OK;
 }
@@ -66,18 +60,14 @@ __global__ void pad_channels_kernel(const float* __restrict__ x, T* __restrict__
 }
 
 extern "C" int ad_pad_channels(const float* x, void* y, int64_t npix, int c, int cpad, int dtype, void* stream) {
-    AD_REQUIRE(c > 0 && cpad >= c && cpad % (dtype == AD_BF16 ? 8 : 4) == 0, "ad_pad_channels: c=%d cpad=%d", c, cpad);
+    AD_REQUIRE(ad_dtype_ok(dtype), "ad_pad_channels: bad dtype %d", dtype);
+    AD_REQUIRE(c > 0 && cpad >= c && cpad % (ad_is_half(dtype) ? 8 : 4) == 0, "ad_pad_channels: c=%d cpad=%d", c, cpad);
     if (npix <= 0) return AD_OK;
     hipStream_t s = (hipStream_t)stream;
-    int64_t total = npix * (cpad / (dtype == AD_BF16 ? 8 : 4));
+    int64_t total = npix * (cpad / (ad_is_half(dtype) ? 8 : 4));
     int blocks = (int)((total + 255) / 256);
     if (blocks > 8192) blocks = 8192;
-    if (dtype == AD_BF16)
-        pad_channels_kernel<bf16_t><<<blocks, 256, 0, s>>>(x, (bf16_t*)y, npix, c, cpad);
-    else if (dtype == AD_F32)
-        pad_channels_kernel<float><<<blocks, 256, 0, s>>>(x, (float*)y, npix, c, cpad);
-    else
-        return ad_set_error(AD_ERR_ARG, "ad_pad_channels: bad dtype %d", dtype);
+    AD_DISPATCH_DTYPE(dtype, T_, pad_channels_kernel<T_><<<blocks, 256, 0, s>>>(x, (T_*)y, npix, c, cpad);)
     AD_LAUNCH_CHECK("ad_pad_channels");
     return AD_OK;
 }

@@ -11,7 +11,36 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) short short4_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
+typedef _Float16 f16_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+
 int ad_set_error(int code, const char* fmt, ...);
+
+static inline bool ad_is_half(int dtype) { return dtype == AD_BF16 || dtype == AD_F16; }   // 16-bit storage types
+static inline bool ad_dtype_ok(int dtype) { return dtype == AD_F32 || dtype == AD_BF16 || dtype == AD_F16; }
+
+// The two 16-bit element types share every kernel; they differ in the vector types and in the MFMA instruction
+// (v_mfma_f32_16x16x32_bf16 / v_mfma_f32_16x16x32_f16), fp32 accumulation in both.
+template <typename E> struct Half16;
+template <> struct Half16<bf16_t> {
+    typedef bf16x8 v8;
+    typedef bf16x4 v4;
+    static __device__ __forceinline__ f32x4 mfma(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct Half16<f16_t> {
+    typedef f16x8 v8;
+    typedef f16x4 v4;
+    static __device__ __forceinline__ f32x4 mfma(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+
+// Runs `...` with T_ bound to the element type of `dtype` (validated by the caller).
+#define AD_DISPATCH_DTYPE(dtype, T_, ...)                           \
+    switch (dtype) {                                                \
+        case AD_BF16: { typedef bf16_t T_; __VA_ARGS__ } break;     \
+        case AD_F16: { typedef f16_t T_; __VA_ARGS__ } break;       \
+        default: { typedef float T_; __VA_ARGS__ } break;           \
+    }
 
 #define AD_REQUIRE(cond, ...)                                   \
     do {                                                        \
@@ -33,6 +62,10 @@ template <> struct ElemTraits<float> {
 template <> struct ElemTraits<bf16_t> {
     static constexpr int EPT = 8;
     static constexpr int DT = AD_BF16;
+};
+template <> struct ElemTraits<f16_t> {
+    static constexpr int EPT = 8;
+    static constexpr int DT = AD_F16;
 };
 
 // 16-byte vector of T, unpacked to / packed from fp32.
@@ -60,6 +93,24 @@ template <> struct Vec16<bf16_t> {
     __device__ __forceinline__ void from_f32(const float* f) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = (bf16_t)f[i];
+    }
+};
+
+template <> struct Vec16<f16_t> {
+    f16x8 v;
+    __device__ __forceinline__ void load(const void* p) { v = *reinterpret_cast<const f16x8*>(p); }
+    __device__ __forceinline__ void store(void* p) const { *reinterpret_cast<f16x8*>(p) = v; }
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (f16_t)0.0f;
+    }
+    __device__ __forceinline__ void to_f32(float* f) const {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] = (float)v[i];
+    }
+    __device__ __forceinline__ void from_f32(const float* f) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (f16_t)f[i];
     }
 };
 

@@ -77,8 +77,10 @@ static bool pick_geo(int n, int h, int w, Geo* g) {
 // m-tile mt) for one channel chunk.  HALO = false: the feature map is 1x1, only the centre tap exists.
 // bf16: the fragments of tap t+1 are read from LDS while the 16 MFMAs of tap t issue (two register sets,
 // selected by the compile-time parity of t), so LDS latency is hidden inside a single wave.
-struct PolBF16 {
-    typedef bf16_t T;
+template <typename E>
+struct Pol16 {
+    typedef E T;
+    typedef typename Half16<E>::v8 v8;
     static constexpr int CK = 32;   // channels per 64-byte chunk
     static constexpr int KV = 8;    // channels per 16 bytes
     static __device__ __forceinline__ int a_lane_off(int lane) { return (lane >> 4) * 16; }
@@ -86,16 +88,16 @@ struct PolBF16 {
     static __device__ __forceinline__ void mma_chunk(f32x4 (&acc)[MT][4], const char* xt, const int (&abase)[MT],
                                                      int row_bytes, const char* wt, int lane) {
         constexpr int NTAP = HALO ? 9 : 1;
-        bf16x8 wf[2][4], xf[2][MT];
+        v8 wf[2][4], xf[2][MT];
         const char* wl = wt + (((lane >> 4) * BN) + (lane & 15)) * 16;
 #define AD_LOAD_TAP(BUF, TAP)                                                                             \
     {                                                                                                     \
         const int tap_ = HALO ? (TAP) : 4;                                                                \
         const int toff_ = HALO ? ((TAP) / 3 - 1) * row_bytes + ((TAP) % 3 - 1) * PIXB : 0;                \
         _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                  \
-            wf[BUF][nt] = *reinterpret_cast<const bf16x8*>(wl + tap_ * (4 * BN * 16) + nt * 256);         \
+            wf[BUF][nt] = *reinterpret_cast<const v8*>(wl + tap_ * (4 * BN * 16) + nt * 256);         \
         _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                 \
-            xf[BUF][mt] = *reinterpret_cast<const bf16x8*>(xt + abase[mt] + toff_);                       \
+            xf[BUF][mt] = *reinterpret_cast<const v8*>(xt + abase[mt] + toff_);                       \
     }
         AD_LOAD_TAP(0, 0)
 #pragma unroll
@@ -105,7 +107,7 @@ struct PolBF16 {
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t & 1][nt], xf[t & 1][mt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = Half16<E>::mfma(wf[t & 1][nt], xf[t & 1][mt], acc[mt][nt]);
         }
 #undef AD_LOAD_TAP
     }
@@ -118,15 +120,15 @@ struct PolBF16 {
     template <typename Hook>
     static __device__ __forceinline__ void mma_chunk_rows(f32x4 (&acc)[4][4], const char* xt, int abase0, int row_bytes,
                                                           const char* wt, int lane, const Hook& hook) {
-        bf16x8 wf[2][4], xr[2][6];
+        v8 wf[2][4], xr[2][6];
         const char* wl = wt + (((lane >> 4) * BN) + (lane & 15)) * 16;
         const char* xl = xt + abase0 - row_bytes - PIXB;       // halo row -1, column -1 of m-tile 0
 #define AD_LOAD_W(BUF, TAP)                                                                               \
     _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                      \
-        wf[BUF][nt] = *reinterpret_cast<const bf16x8*>(wl + (TAP) * (4 * BN * 16) + nt * 256);
+        wf[BUF][nt] = *reinterpret_cast<const v8*>(wl + (TAP) * (4 * BN * 16) + nt * 256);
 #define AD_LOAD_R(BUF, DX)                                                                                \
     _Pragma("unroll") for (int r = 0; r < 6; ++r)                                                         \
-        xr[BUF][r] = *reinterpret_cast<const bf16x8*>(xl + r * row_bytes + (DX) * PIXB);
+        xr[BUF][r] = *reinterpret_cast<const v8*>(xl + r * row_bytes + (DX) * PIXB);
         AD_LOAD_R(0, 0)
         AD_LOAD_W(0, 0)
 #pragma unroll
@@ -141,13 +143,15 @@ struct PolBF16 {
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[st & 1][nt], xr[dx & 1][mt + dy], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = Half16<E>::mfma(wf[st & 1][nt], xr[dx & 1][mt + dy], acc[mt][nt]);
             hook(st);
         }
 #undef AD_LOAD_W
 #undef AD_LOAD_R
     }
 };
+typedef Pol16<bf16_t> PolBF16;
+typedef Pol16<f16_t> PolF16;
 
 struct PolF32 {
     typedef float T;
@@ -501,8 +505,9 @@ __global__ __launch_bounds__(FT, XS <= 6 ? 2 : 1) void conv3x3_fwd_kernel(ConvAr
                             for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
                         }
                         if constexpr (sizeof(T) == 2) {
-                            bf16x4 pk = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-                            *reinterpret_cast<bf16x4*>(dst + nt * 16) = pk;
+                            typedef typename Half16<T>::v4 h4;
+                            h4 pk = {(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
+                            *reinterpret_cast<h4*>(dst + nt * 16) = pk;
                         } else {
                             *reinterpret_cast<float4*>(dst + nt * 16) = make_float4(v[0], v[1], v[2], v[3]);
                         }
@@ -625,7 +630,7 @@ __device__ __forceinline__ WsOrder ws_order(int ntiles, int nblk) {
 // channels: 16-byte stores, two instructions per 128-byte NHWC row.  pend[0..7]: z (or relu(z), EPI 1) pieces
 // (mt, n-tile pair), pend[8..15]: activation pieces (EPI 2); pvo[mt]: byte offset of the piece, out of range past the
 // image edge.  mean / rstd are stored here (lane group 0).
-template <int EPI, typename RS>
+template <int EPI, typename E, typename RS>
 __device__ __forceinline__ void ws_pack_tile(const f32x4 (&acc)[4][4], const float* gb, float eps, int wave, int lane,
                                              int img_h, int img_w, int nn, int y0, int x0, int cy, const int (&soff)[4],
                                              RS rsm, RS rsr, u32x4 (&pend)[EPI == 2 ? 16 : 8], unsigned (&pvo)[4]) {
@@ -656,7 +661,7 @@ __device__ __forceinline__ void ws_pack_tile(const f32x4 (&acc)[4][4], const flo
         }
 #pragma unroll
         for (int np = 0; np < 2; ++np) {
-            union { bf16x4 h; u32x2 u; } pa, pb, qa, qb;
+            union { typename Half16<E>::v4 h; u32x2 u; } pa, pb, qa, qb;
             float4 ga, gb4, ba, bb;
             if (EPI == 2) {
                 ga = *reinterpret_cast<const float4*>(gb + (2 * np) * 16 + grp * 4);
@@ -673,12 +678,12 @@ __device__ __forceinline__ void ws_pack_tile(const f32x4 (&acc)[4][4], const flo
                     va = __builtin_amdgcn_fmed3f(va, 0.f, __builtin_inff());
                     vb = __builtin_amdgcn_fmed3f(vb, 0.f, __builtin_inff());
                 }
-                pa.h[q] = (bf16_t)va;
-                pb.h[q] = (bf16_t)vb;
+                pa.h[q] = (E)va;
+                pb.h[q] = (E)vb;
                 if (EPI == 2) {
                     const float ya = (va - mean) * rstd * gaa[q] + baa[q], yb = (vb - mean) * rstd * gba[q] + bba[q];
-                    qa.h[q] = (bf16_t)__builtin_amdgcn_fmed3f(ya, 0.f, __builtin_inff());
-                    qb.h[q] = (bf16_t)__builtin_amdgcn_fmed3f(yb, 0.f, __builtin_inff());
+                    qa.h[q] = (E)__builtin_amdgcn_fmed3f(ya, 0.f, __builtin_inff());
+                    qb.h[q] = (E)__builtin_amdgcn_fmed3f(yb, 0.f, __builtin_inff());
                 }
             }
             const u32x2 s0 = __builtin_amdgcn_permlane16_swap(pa.u[0], pb.u[0], false, false);
@@ -775,7 +780,7 @@ __device__ __forceinline__ void ws_mma_role(const ConvArgs& a, const char* xb0, 
             lds_barrier();
             P::mma_chunk_rows(acc, xb1, abase0, HWB, wt1, lane, [](int) {});
         }
-        ws_pack_tile<EPI>(acc, gb, a.ln_eps, wave, lane, a.h, a.w, nn, y0, x0, cy, soff, rsm, rsr, pend, pvo);
+        ws_pack_tile<EPI, typename P::T>(acc, gb, a.ln_eps, wave, lane, a.h, a.w, nn, y0, x0, cy, soff, rsm, rsr, pend, pvo);
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) WS_PEND_STORE(i, rsy);
@@ -1056,17 +1061,18 @@ struct WgradArgs {
 
 template <typename P> struct WgradPol;
 
-template <> struct WgradPol<PolBF16> {
+template <typename E> struct WgradPol<Pol16<E>> {
+    typedef typename Half16<E>::v8 v8;
     static constexpr int NACC = 2;   // n-tiles per wave (one m-tile of 16 input channels)
     static constexpr int DZS = BN * 2 + 32;   // 160 B: 8 consecutive pixels x 32 B tile the 256-B bank row
     static constexpr int DSLOTS = BN * 2 / 16;   // 16-byte dz slots per thread (one pixel row each)
-    static __device__ __forceinline__ bf16x8 tr_pair(const char* p0, const char* p1) {
+    static __device__ __forceinline__ v8 tr_pair(const char* p0, const char* p1) {
         typedef __attribute__((address_space(3))) short4_t* lds_p;
         short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p0));
         short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p1));
         typedef __attribute__((ext_vector_type(8))) short short8_t;
         short8_t r = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-        return __builtin_bit_cast(bf16x8, r);
+        return __builtin_bit_cast(v8, r);
     }
     // Per-lane LDS offsets of the 8 k-steps (tile independent): k index 8*grp + j of a k-step <-> pixel
     // ks*32 + 16*(j>>2) + 4*grp + (j&3), so each transposed read covers 8 consecutive pixels per 32-lane half
@@ -1097,8 +1103,8 @@ template <> struct WgradPol<PolBF16> {
         constexpr int NT = HALO ? 9 : 1;
         constexpr int NS = (TM / 32) * NT;     // stages = (k-step, tap)
         constexpr int NPRE = 4;
-        bf16x8 afr[NPRE];
-        bf16x8 bfr[2][NACC];
+        v8 afr[NPRE];
+        v8 bfr[2][NACC];
 #define AD_LOAD_A(S)                                                                                          \
     {                                                                                                         \
         constexpr int ks_ = (S) / NT, t_ = (S) % NT;                                                          \
@@ -1117,8 +1123,8 @@ template <> struct WgradPol<PolBF16> {
     // compile-time recursion over the stages keeps every fragment index a constant (no scratch arrays)
     template <bool HALO, int S>
     static __device__ __forceinline__ void ad_tile_stages(f32x4 (&acc)[9][NACC], const char* xt, const char* dzt,
-                                                          const Lane& l, int row_bytes, bf16x8 (&afr)[4],
-                                                          bf16x8 (&bfr)[2][NACC]) {
+                                                          const Lane& l, int row_bytes, v8 (&afr)[4],
+                                                          v8 (&bfr)[2][NACC]) {
         constexpr int NT = HALO ? 9 : 1;
         constexpr int NS = (TM / 32) * NT;
         constexpr int NPRE = 4;
@@ -1131,7 +1137,7 @@ template <> struct WgradPol<PolBF16> {
                     bfr[(ks + 1) & 1][j] = tr_pair(dzt + l.dz + (ks + 1) * 32 * DZS + j * 32,
                                                    dzt + l.dz + ((ks + 1) * 32 + 16) * DZS + j * 32);
             }
-            const bf16x8 a_cur = afr[S % NPRE];
+            const v8 a_cur = afr[S % NPRE];
             if constexpr (S + NPRE < NS) {
                 constexpr int ks2 = (S + NPRE) / NT, t2 = (S + NPRE) % NT;
                 const int toff2 = HALO ? (t2 / 3 - 1) * row_bytes + (t2 % 3 - 1) * PIXB : 0;
@@ -1139,7 +1145,7 @@ template <> struct WgradPol<PolBF16> {
             }
 #pragma unroll
             for (int j = 0; j < NACC; ++j)
-                acc[tap][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_cur, bfr[ks & 1][j], acc[tap][j], 0, 0, 0);
+                acc[tap][j] = Half16<E>::mfma(a_cur, bfr[ks & 1][j], acc[tap][j]);
             ad_tile_stages<HALO, S + 1>(acc, xt, dzt, l, row_bytes, afr, bfr);
         }
     }
@@ -1306,10 +1312,10 @@ constexpr int W2_DSL = 4;                        // dz slots per loader thread a
 // One half tile (4 k-steps) of K for one MFMA wave.  xh: this wave's 32-channel chunk of the half's halo buffer,
 // already offset to its 16 channels; dzh: the half's dz buffer.  Same k <-> pixel map and fragment ring as
 // WgradPol<PolBF16>::tile.
-template <int S>
+template <typename E, int S>
 __device__ __forceinline__ void w2_stages(f32x4 (&acc)[9][4], const char* xh, const char* dzh, const int (&xa)[4],
-                                          const int (&xb)[4], int dzo, bf16x8 (&afr)[4], bf16x8 (&bfr)[2][4]) {
-    typedef WgradPol<PolBF16> WP;
+                                          const int (&xb)[4], int dzo, typename Half16<E>::v8 (&afr)[4], typename Half16<E>::v8 (&bfr)[2][4]) {
+    typedef WgradPol<Pol16<E>> WP;
     constexpr int NS = 4 * 9, NPRE = 4, RB = 18 * PIXB;
     if constexpr (S < NS) {
         constexpr int ks = S / 9, t = S % 9;
@@ -1319,7 +1325,7 @@ __device__ __forceinline__ void w2_stages(f32x4 (&acc)[9][4], const char* xh, co
                 bfr[(ks + 1) & 1][j] = WP::tr_pair(dzh + dzo + (ks + 1) * 32 * W2_DZS + j * 32,
                                                    dzh + dzo + ((ks + 1) * 32 + 16) * W2_DZS + j * 32);
         }
-        const bf16x8 a_cur = afr[S % NPRE];
+        const typename Half16<E>::v8 a_cur = afr[S % NPRE];
         if constexpr (S + NPRE < NS) {
             constexpr int ks2 = (S + NPRE) / 9, t2 = (S + NPRE) % 9;
             constexpr int toff2 = (t2 / 3 - 1) * RB + (t2 % 3 - 1) * PIXB;
@@ -1327,16 +1333,17 @@ __device__ __forceinline__ void w2_stages(f32x4 (&acc)[9][4], const char* xh, co
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_cur, bfr[ks & 1][j], acc[t][j], 0, 0, 0);
-        w2_stages<S + 1>(acc, xh, dzh, xa, xb, dzo, afr, bfr);
+            acc[t][j] = Half16<E>::mfma(a_cur, bfr[ks & 1][j], acc[t][j]);
+        w2_stages<E, S + 1>(acc, xh, dzh, xa, xb, dzo, afr, bfr);
     }
 }
 
+template <typename E>
 __device__ __forceinline__ void w2_half(f32x4 (&acc)[9][4], const char* xh, const char* dzh, const int (&xa)[4],
                                         const int (&xb)[4], int dzo) {
-    typedef WgradPol<PolBF16> WP;
+    typedef WgradPol<Pol16<E>> WP;
     constexpr int RB = 18 * PIXB;
-    bf16x8 afr[4], bfr[2][4];
+    typename Half16<E>::v8 afr[4], bfr[2][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
         bfr[0][j] = WP::tr_pair(dzh + dzo + j * 32, dzh + dzo + 16 * W2_DZS + j * 32);
@@ -1345,11 +1352,12 @@ __device__ __forceinline__ void w2_half(f32x4 (&acc)[9][4], const char* xh, cons
         const int toff = (t / 3 - 1) * RB + (t % 3 - 1) * PIXB;
         afr[t] = WP::tr_pair(xh + xa[0] + toff, xh + xb[0] + toff);
     }
-    w2_stages<0>(acc, xh, dzh, xa, xb, dzo, afr, bfr);
+    w2_stages<E, 0>(acc, xh, dzh, xa, xb, dzo, afr, bfr);
 }
 
 // grid: x = K split, y = 64-input-channel block, z = 64-output-channel block
 // ws slab layout: [split][cib][cob][tap][64][64] fp32
+template <typename E>
 __global__ __launch_bounds__(W2_T, 1) void conv3x3_wgrad_ws_kernel(WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Geo& g = a.g;      // geometry is (1, 16, 16)
@@ -1486,9 +1494,9 @@ __global__ __launch_bounds__(W2_T, 1) void conv3x3_wgrad_ws_kernel(WgradArgs a) 
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int tile = t_begin; tile < t_end; ++tile) {
             lds_barrier();                           // B0
-            w2_half(acc, smem + xw, smem + 4 * W2_XB, xa, xb, dzo);
+            w2_half<E>(acc, smem + xw, smem + 4 * W2_XB, xa, xb, dzo);
             lds_barrier();                           // B1
-            w2_half(acc, smem + 2 * W2_XB + xw, smem + 4 * W2_XB + W2_DZB, xa, xb, dzo);
+            w2_half<E>(acc, smem + 2 * W2_XB + xw, smem + 4 * W2_XB + W2_DZB, xa, xb, dzo);
         }
         float* slab = a.ws + ((size_t)(split * a.ncib + cib) * a.ncob + cob) * (9 * 64 * BN);
 #pragma unroll
@@ -1547,7 +1555,7 @@ __device__ __forceinline__ C3Halo c3_halo_setup(int tid) {
 #define C3_STORE_HALO(V, BUF)                                                                             \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                         \
         if (tid + C3_T * i < C3_HALO)                                                                     \
-            reinterpret_cast<bf16_t*>(BUF)[tid + C3_T * i] = (bf16_t)__builtin_bit_cast(float, V[i]);
+            reinterpret_cast<E*>(BUF)[tid + C3_T * i] = (E)__builtin_bit_cast(float, V[i]);
 #define C3_TILE(T)                                                                                        \
     const int t_ = (T) < a.ntiles ? (T) : a.ntiles - 1;      /* past the end: re-fetch, loads stay unconditional */ \
     const int r_ = t_ / a.tiles_x;                                                                        \
@@ -1555,7 +1563,9 @@ __device__ __forceinline__ C3Halo c3_halo_setup(int tid) {
     const int nn = r_ / a.tiles_y;                                                                        \
     const int y0 = (r_ - nn * a.tiles_y) << 4;
 
+template <typename E>
 __global__ __launch_bounds__(C3_T, 2) void conv3x3_c3_fwd_kernel(C3Args a) {
+    typedef typename Half16<E>::v8 v8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* hb0 = smem;
     char* hb1 = smem + C3_HB;
@@ -1566,13 +1576,13 @@ __global__ __launch_bounds__(C3_T, 2) void conv3x3_c3_fwd_kernel(C3Args a) {
         gb[tid] = a.gamma[tid]; gb[64 + tid] = a.beta[tid]; gb[128 + tid] = a.bias ? a.bias[tid] : 0.f;
     }
     // weight fragments (MFMA operand A): row = output channel nt*16 + (lane & 15), k = 8 grp .. 8 grp + 7
-    bf16x8 wf[4];
+    v8 wf[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int k = 8 * grp + j;
-            wf[nt][j] = (bf16_t)(k < 27 ? a.w[k * 64 + nt * 16 + (lane & 15)] : 0.f);
+            wf[nt][j] = (E)(k < 27 ? a.w[k * 64 + nt * 16 + (lane & 15)] : 0.f);
         }
     // patch gather: K index k of pixel (row, col) sits at halo element (row * 18 + col) * 3 + k + 45 * (k / 9)
     int koff[8];
@@ -1616,17 +1626,17 @@ __global__ __launch_bounds__(C3_T, 2) void conv3x3_c3_fwd_kernel(C3Args a) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             const char* pb = hb + (((wave * 4 + mt) * 18 + (lane & 15)) * 3) * 2;
-            bf16x8 xf;
+            v8 xf;
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                xf[j] = koff[j] >= 0 ? *reinterpret_cast<const bf16_t*>(pb + koff[j]) : (bf16_t)0.f;
+                xf[j] = koff[j] >= 0 ? *reinterpret_cast<const E*>(pb + koff[j]) : (E)0.f;
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf, acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = Half16<E>::mfma(wf[nt], xf, acc[mt][nt]);
         }
         u32x4 pend[16];
         unsigned pvo[4];
-        ws_pack_tile<2>(acc, gb, a.eps, wave, lane, a.h, a.w_img, nn, y0, x0, 64, soff, rsm, rsr, pend, pvo);
+        ws_pack_tile<2, E>(acc, gb, a.eps, wave, lane, a.h, a.w_img, nn, y0, x0, 64, soff, rsm, rsr, pend, pvo);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             __builtin_amdgcn_raw_buffer_store_b128(pend[i], rsz, pvo[i >> 1], (i & 1) * 64, 0);
@@ -1640,8 +1650,10 @@ __global__ __launch_bounds__(C3_T, 2) void conv3x3_c3_fwd_kernel(C3Args a) {
 // Wave w owns output channels 16 w .. 16 w + 15 and both 16-row halves of k; per k-step (32 pixels) the dz fragment
 // is one transposed-read pair (layout and k <-> pixel map of WgradPol<PolBF16>) and the patch fragments are gathered
 // from the bf16 halo.  LDS: two halo buffers + one dz tile (256 pixels x 160 B); dz and the next halo wait in registers.
+template <typename E>
 __global__ __launch_bounds__(C3_T, 2) void conv3x3_c3_wgrad_kernel(C3Args a) {
-    typedef WgradPol<PolBF16> WP;
+    typedef typename Half16<E>::v8 v8;
+    typedef WgradPol<Pol16<E>> WP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* hb0 = smem;
     char* hb1 = smem + C3_HB;
@@ -1695,15 +1707,15 @@ __global__ __launch_bounds__(C3_T, 2) void conv3x3_c3_wgrad_kernel(C3Args a) {
         }
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
-            const bf16x8 bfr = WP::tr_pair(dzt + dzo + ks * 32 * WP::DZS, dzt + dzo + (ks * 32 + 16) * WP::DZS);
+            const v8 bfr = WP::tr_pair(dzt + dzo + ks * 32 * WP::DZS, dzt + dzo + (ks * 32 + 16) * WP::DZS);
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
-                bf16x8 afr;
+                v8 afr;
                 const char* pb = hb + (2 * ks * 18 * 3) * 2 + (moff[mt] >= 0 ? moff[mt] : 0);
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
-                    afr[j] = moff[mt] >= 0 ? *reinterpret_cast<const bf16_t*>(pb + joff[j]) : (bf16_t)0.f;
-                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr, acc[mt], 0, 0, 0);
+                    afr[j] = moff[mt] >= 0 ? *reinterpret_cast<const E*>(pb + joff[j]) : (E)0.f;
+                acc[mt] = Half16<E>::mfma(afr, bfr, acc[mt]);
             }
         }
         lds_barrier();                              // the dz tile is single buffered
@@ -1975,9 +1987,9 @@ static void plan_wgrad(int n, int h, int w, int c1, int c2, int cout, int dtype,
     p->ntiles = p->g.tiles_x * p->g.tiles_y * p->g.tiles_i;
     p->ncob = cout / BN;
     const long long widest = (long long)n * h * w * (c1 > c2 ? (c1 > cout ? c1 : cout) : (c2 > cout ? c2 : cout)) * 2;
-    p->specialised = dtype == AD_BF16 && p->g.lti == 0 && p->g.lth == 4 && p->g.ltw == 4 && cin % 64 == 0 &&
+    p->specialised = ad_is_half(dtype) && p->g.lti == 0 && p->g.lth == 4 && p->g.ltw == 4 && cin % 64 == 0 &&
                      c1 % 32 == 0 && widest <= WR_MAX_BYTES && p->ntiles >= 4 * NUM_CU / ((cin / 64) * p->ncob);
-    p->ck = p->specialised ? 64 : dtype == AD_BF16 ? PolBF16::CK : PolF32::CK;
+    p->ck = p->specialised ? 64 : ad_is_half(dtype) ? PolBF16::CK : PolF32::CK;
     p->ncib = cin / p->ck;
     int want = ((p->specialised ? 1 : 2) * NUM_CU) / (p->ncib * p->ncob);   // workgroups per CU in total
     if (want < 1) want = 1;
@@ -2009,8 +2021,8 @@ int launch_wgrad(WgradArgs a, const WgradPlan& p, hipStream_t s) {
     if constexpr (sizeof(typename P::T) == 2) {
         if (p.specialised) {
             static bool attr2 = false;
-            if (!attr2) { allow_big_lds(conv3x3_wgrad_ws_kernel); attr2 = true; }
-            conv3x3_wgrad_ws_kernel<<<grid, W2_T, W2_LDS, s>>>(a);
+            if (!attr2) { allow_big_lds(conv3x3_wgrad_ws_kernel<typename P::T>); attr2 = true; }
+            conv3x3_wgrad_ws_kernel<typename P::T><<<grid, W2_T, W2_LDS, s>>>(a);
             AD_LAUNCH_CHECK("conv3x3_wgrad_ws");
             return AD_OK;
         }
@@ -2028,6 +2040,12 @@ int launch_wgrad(WgradArgs a, const WgradPlan& p, hipStream_t s) {
     return AD_OK;
 }
 
+static int launch_fwd_dtype(int dtype, const ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t s) {
+    if (dtype == AD_BF16) return launch_fwd_runs<PolBF16>(a, ws, ws_bytes, s);
+    if (dtype == AD_F16) return launch_fwd_runs<PolF16>(a, ws, ws_bytes, s);
+    return launch_fwd_runs<PolF32>(a, ws, ws_bytes, s);
+}
+
 }  // namespace
 
 static unsigned long long* g_dbg = nullptr;
@@ -2037,7 +2055,7 @@ extern "C" void ad_dbg_set_stamp_buffer(void* p) { g_dbg = (unsigned long long*)
 
 extern "C" int ad_conv3x3_pack(const float* w_hwio, int cin, int cout, int cin_pad, void* w_fwd, void* w_dgrad,
                                int dtype, void* stream) {
-    AD_REQUIRE(dtype == AD_BF16 || dtype == AD_F32, "ad_conv3x3_pack: bad dtype %d", dtype);
+    AD_REQUIRE(ad_dtype_ok(dtype), "ad_conv3x3_pack: bad dtype %d", dtype);
     const int gran = ad_cin_granule(dtype);
     AD_REQUIRE(cin > 0 && cout > 0 && cin_pad >= cin && cin_pad % gran == 0,
                "ad_conv3x3_pack: cin=%d cin_pad=%d must be a multiple of %d", cin, cin_pad, gran);
@@ -2047,10 +2065,7 @@ extern "C" int ad_conv3x3_pack(const float* w_hwio, int cin, int cout, int cin_p
     int total = 9 * cin_pad * cout;
     int blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    if (dtype == AD_BF16)
-        pack_kernel<bf16_t><<<blocks, 256, 0, s>>>(w_hwio, cin, cout, cin_pad, (bf16_t*)w_fwd, (bf16_t*)w_dgrad);
-    else
-        pack_kernel<float><<<blocks, 256, 0, s>>>(w_hwio, cin, cout, cin_pad, (float*)w_fwd, (float*)w_dgrad);
+    AD_DISPATCH_DTYPE(dtype, T_, pack_kernel<T_><<<blocks, 256, 0, s>>>(w_hwio, cin, cout, cin_pad, (T_*)w_fwd, (T_*)w_dgrad);)
     AD_LAUNCH_CHECK("ad_conv3x3_pack");
     return AD_OK;
 }
@@ -2060,13 +2075,10 @@ extern "C" size_t ad_conv3x3_pack_job_bytes(void) { return sizeof(PackJob); }
 extern "C" int ad_conv3x3_pack_quantum(void) { return PACK_Q; }
 
 extern "C" int ad_conv3x3_pack_batch(const void* jobs_dev, int njobs, int nblocks, int dtype, void* stream) {
-    AD_REQUIRE(dtype == AD_BF16 || dtype == AD_F32, "ad_conv3x3_pack_batch: bad dtype %d", dtype);
+    AD_REQUIRE(ad_dtype_ok(dtype), "ad_conv3x3_pack_batch: bad dtype %d", dtype);
     AD_REQUIRE(jobs_dev != nullptr && njobs > 0 && njobs <= 64 && nblocks > 0,
                "ad_conv3x3_pack_batch: bad job table (%d jobs, %d blocks)", njobs, nblocks);
-    if (dtype == AD_BF16)
-        pack_batch_kernel<bf16_t><<<nblocks, 256, 0, (hipStream_t)stream>>>((const PackJob*)jobs_dev, njobs);
-    else
-        pack_batch_kernel<float><<<nblocks, 256, 0, (hipStream_t)stream>>>((const PackJob*)jobs_dev, njobs);
+    AD_DISPATCH_DTYPE(dtype, T_, pack_batch_kernel<T_><<<nblocks, 256, 0, (hipStream_t)stream>>>((const PackJob*)jobs_dev, njobs);)
     AD_LAUNCH_CHECK("ad_conv3x3_pack_batch");
     return AD_OK;
 }
@@ -2074,7 +2086,7 @@ extern "C" int ad_conv3x3_pack_batch(const void* jobs_dev, int njobs, int nblock
 extern "C" int ad_conv3x3_fwd(const void* x1, int c1, const void* x2, int c2, const void* w_packed, const float* bias,
                               void* y1, int cy1, void* y2, int n, int h, int w, int cout, int epilogue, void* ws,
                               size_t ws_bytes, int dtype, void* stream) {
-    AD_REQUIRE(dtype == AD_BF16 || dtype == AD_F32, "ad_conv3x3_fwd: bad dtype %d", dtype);
+    AD_REQUIRE(ad_dtype_ok(dtype), "ad_conv3x3_fwd: bad dtype %d", dtype);
     const int gran = ad_cin_granule(dtype);
     AD_REQUIRE(n > 0 && h > 0 && w > 0, "ad_conv3x3_fwd: bad shape n=%d h=%d w=%d", n, h, w);
     AD_REQUIRE((long)n * h * w < (1L << 31), "ad_conv3x3_fwd: more than 2^31 pixels");
@@ -2095,14 +2107,14 @@ extern "C" int ad_conv3x3_fwd(const void* x1, int c1, const void* x2, int c2, co
     pick_geo(n, h, w, &a.g);
     a.ntiles = a.g.tiles_x * a.g.tiles_y * a.g.tiles_i;
     hipStream_t s = (hipStream_t)stream;
-    return dtype == AD_BF16 ? launch_fwd_runs<PolBF16>(a, ws, ws_bytes, s) : launch_fwd_runs<PolF32>(a, ws, ws_bytes, s);
+    return launch_fwd_dtype(dtype, a, ws, ws_bytes, s);
 }
 
 extern "C" int ad_layernorm_relu_fwd(const void* z, const float* gamma, const float* beta, void* y, float* mean,
                                      float* rstd, int64_t npix, int c, float eps, int relu, int dtype, void* stream);
 
 extern "C" int ad_conv3x3_ln_relu_is_fused(int n, int h, int w, int c1, int c2, int cout, int dtype) {
-    if (dtype != AD_BF16 || n <= 0 || h <= 0 || w <= 0 || c1 <= 0 || c2 < 0 || cout <= 0 || cout % BN) return 0;
+    if (!ad_is_half(dtype) || n <= 0 || h <= 0 || w <= 0 || c1 <= 0 || c2 < 0 || cout <= 0 || cout % BN) return 0;
     const int chunk = images_per_launch(n, h, w, c1, c2, cout, true, false);
     return fwd_ws_kind(chunk, h, w, c1, c2, cout, true) != 0;
 }
@@ -2111,7 +2123,7 @@ extern "C" int ad_conv3x3_ln_relu_fwd(const void* x1, int c1, const void* x2, in
                                       const float* bias, const float* gamma, const float* beta, float eps, void* z,
                                       void* act, float* mean, float* rstd, int n, int h, int w, int cout, void* ws,
                                       size_t ws_bytes, int dtype, void* stream) {
-    AD_REQUIRE(dtype == AD_BF16 || dtype == AD_F32, "ad_conv3x3_ln_relu_fwd: bad dtype %d", dtype);
+    AD_REQUIRE(ad_dtype_ok(dtype), "ad_conv3x3_ln_relu_fwd: bad dtype %d", dtype);
     AD_REQUIRE(gamma && beta && z && act && mean && rstd, "ad_conv3x3_ln_relu_fwd: NULL LayerNorm operand");
     const int gran = ad_cin_granule(dtype);
     AD_REQUIRE(n > 0 && h > 0 && w > 0 && (long)n * h * w < (1L << 31), "ad_conv3x3_ln_relu_fwd: bad shape n=%d h=%d w=%d", n, h, w);
@@ -2130,10 +2142,10 @@ extern "C" int ad_conv3x3_ln_relu_fwd(const void* x1, int c1, const void* x2, in
     pick_geo(n, h, w, &a.g);
     a.ntiles = a.g.tiles_x * a.g.tiles_y * a.g.tiles_i;
     hipStream_t s = (hipStream_t)stream;
-    int rc = dtype == AD_BF16 ? launch_fwd_runs<PolBF16>(a, ws, ws_bytes, s) : launch_fwd_runs<PolF32>(a, ws, ws_bytes, s);
+    int rc = launch_fwd_dtype(dtype, a, ws, ws_bytes, s);
     if (rc != AD_ERR_UNFUSED) return rc;
     a.epilogue = AD_EPI_NONE;
-    rc = dtype == AD_BF16 ? launch_fwd_runs<PolBF16>(a, ws, ws_bytes, s) : launch_fwd_runs<PolF32>(a, ws, ws_bytes, s);
+    rc = launch_fwd_dtype(dtype, a, ws, ws_bytes, s);
     if (rc) return rc;
     return ad_layernorm_relu_fwd(z, gamma, beta, act, mean, rstd, (int64_t)n * h * w, cout, eps, 1, dtype, stream);
 }
@@ -2143,7 +2155,7 @@ extern "C" size_t ad_conv3x3_fwd_ws_bytes(int n, int h, int w, int cin, int cout
     Geo g;
     pick_geo(n, h, w, &g);
     const int nitems = g.tiles_x * g.tiles_y * g.tiles_i * (cout / BN);
-    const int ks = pick_ksplit(nitems, cin / (dtype == AD_BF16 ? PolBF16::CK : PolF32::CK));
+    const int ks = pick_ksplit(nitems, cin / (ad_is_half(dtype) ? PolBF16::CK : PolF32::CK));
     return ks > 1 ? (size_t)ks * n * h * w * cout * sizeof(float) : 0;
 }
 
@@ -2159,19 +2171,20 @@ static bool c3_plan(int n, int h, int w, C3Args* a, int* grid) {
 
 extern "C" int ad_conv3x3_c3_supported(int n, int h, int w, int cout, int dtype) {
     C3Args a; int grid;
-    return dtype == AD_BF16 && cout == 64 && c3_plan(n, h, w, &a, &grid);
+    return ad_is_half(dtype) && cout == 64 && c3_plan(n, h, w, &a, &grid);
 }
 
 extern "C" int ad_conv3x3_c3_ln_relu_fwd(const float* x, const float* w_hwio, const float* bias, const float* gamma,
                                          const float* beta, float eps, void* z, void* act, float* mean, float* rstd,
                                          int n, int h, int w, int dtype, void* stream) {
-    AD_REQUIRE(dtype == AD_BF16, "ad_conv3x3_c3_ln_relu_fwd: bf16 only (dtype %d)", dtype);
+    AD_REQUIRE(ad_is_half(dtype), "ad_conv3x3_c3_ln_relu_fwd: 16-bit storage types only (dtype %d)", dtype);
     AD_REQUIRE(x && w_hwio && gamma && beta && z && act && mean && rstd, "ad_conv3x3_c3_ln_relu_fwd: NULL operand");
     C3Args a; int grid;
     AD_REQUIRE(c3_plan(n, h, w, &a, &grid), "ad_conv3x3_c3_ln_relu_fwd: unsupported shape n=%d h=%d w=%d", n, h, w);
     a.x = x; a.w = w_hwio; a.bias = bias; a.gamma = gamma; a.beta = beta; a.eps = eps;
     a.z = (char*)z; a.act = (char*)act; a.mean = mean; a.rstd = rstd; a.dz = nullptr; a.ws = nullptr;
-    conv3x3_c3_fwd_kernel<<<grid, C3_T, 2 * C3_HB + 3 * BN * 4, (hipStream_t)stream>>>(a);
+    if (dtype == AD_BF16) conv3x3_c3_fwd_kernel<bf16_t><<<grid, C3_T, 2 * C3_HB + 3 * BN * 4, (hipStream_t)stream>>>(a);
+    else conv3x3_c3_fwd_kernel<f16_t><<<grid, C3_T, 2 * C3_HB + 3 * BN * 4, (hipStream_t)stream>>>(a);
     AD_LAUNCH_CHECK("ad_conv3x3_c3_ln_relu_fwd");
     return AD_OK;
 }
@@ -2184,7 +2197,7 @@ extern "C" size_t ad_conv3x3_c3_wgrad_ws_bytes(int n, int h, int w) {
 
 extern "C" int ad_conv3x3_c3_wgrad(const float* x, const void* dz, float* dw_hwio, int n, int h, int w, void* ws,
                                    size_t ws_bytes, int dtype, void* stream) {
-    AD_REQUIRE(dtype == AD_BF16, "ad_conv3x3_c3_wgrad: bf16 only (dtype %d)", dtype);
+    AD_REQUIRE(ad_is_half(dtype), "ad_conv3x3_c3_wgrad: 16-bit storage types only (dtype %d)", dtype);
     AD_REQUIRE(x && dz && dw_hwio, "ad_conv3x3_c3_wgrad: NULL operand");
     C3Args a; int grid;
     AD_REQUIRE(c3_plan(n, h, w, &a, &grid), "ad_conv3x3_c3_wgrad: unsupported shape n=%d h=%d w=%d", n, h, w);
@@ -2194,7 +2207,8 @@ extern "C" int ad_conv3x3_c3_wgrad(const float* x, const void* dz, float* dw_hwi
     a.x = x; a.w = nullptr; a.bias = a.gamma = a.beta = nullptr; a.eps = 0.f;
     a.z = a.act = nullptr; a.mean = a.rstd = nullptr; a.dz = (const char*)dz; a.ws = (float*)ws;
     hipStream_t s = (hipStream_t)stream;
-    conv3x3_c3_wgrad_kernel<<<grid, C3_T, 2 * C3_HB + TM * WgradPol<PolBF16>::DZS, s>>>(a);
+    if (dtype == AD_BF16) conv3x3_c3_wgrad_kernel<bf16_t><<<grid, C3_T, 2 * C3_HB + TM * WgradPol<PolBF16>::DZS, s>>>(a);
+    else conv3x3_c3_wgrad_kernel<f16_t><<<grid, C3_T, 2 * C3_HB + TM * WgradPol<PolF16>::DZS, s>>>(a);
     AD_LAUNCH_CHECK("ad_conv3x3_c3_wgrad");
     // slabs [grid][27][64] -> dw_hwio [3][3][3][64]: the generic slab reduce with 3-channel input blocks
     wgrad_reduce_kernel<<<(27 * 64 + 63) / 64, 256, 0, s>>>((const float*)ws, dw_hwio, grid, 1, 1, 3, 3, 64);
@@ -2207,7 +2221,7 @@ extern "C" size_t ad_conv3x3_wgrad_ws_bytes(int n, int h, int w, int cin, int co
     if (n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0 || cout % BN) return 0;
     plan_wgrad(n, h, w, cin, 0, cout, dtype, &p);     // the split of cin does not change the slab size
     size_t need = p.ws_bytes;
-    const int chunk = dtype == AD_BF16 ? images_per_launch(n, h, w, cin, 0, cout, false, true) : n;
+    const int chunk = ad_is_half(dtype) ? images_per_launch(n, h, w, cin, 0, cout, false, true) : n;
     if (chunk < n) {                                  // image runs of a >= 2 GiB batch plan their own slabs
         plan_wgrad(chunk, h, w, cin, 0, cout, dtype, &p);
         if (p.ws_bytes > need) need = p.ws_bytes;
@@ -2220,7 +2234,7 @@ extern "C" size_t ad_conv3x3_wgrad_ws_bytes(int n, int h, int w, int cin, int co
 extern "C" int ad_conv3x3_wgrad(const void* x1, int c1, const void* x2, int c2, const void* dz, float* dw_hwio,
                                 int cin_real, int n, int h, int w, int cout, void* ws, size_t ws_bytes, int dtype,
                                 void* stream) {
-    AD_REQUIRE(dtype == AD_BF16 || dtype == AD_F32, "ad_conv3x3_wgrad: bad dtype %d", dtype);
+    AD_REQUIRE(ad_dtype_ok(dtype), "ad_conv3x3_wgrad: bad dtype %d", dtype);
     const int gran = ad_cin_granule(dtype);
     AD_REQUIRE(n > 0 && h > 0 && w > 0, "ad_conv3x3_wgrad: bad shape");
     AD_REQUIRE((long)n * h * w < (1L << 31), "ad_conv3x3_wgrad: more than 2^31 pixels");
@@ -2230,9 +2244,9 @@ extern "C" int ad_conv3x3_wgrad(const void* x1, int c1, const void* x2, int c2, 
     const int cin = c1 + c2;
     AD_REQUIRE(cin_real > 0 && cin_real <= cin, "ad_conv3x3_wgrad: cin_real=%d", cin_real);
     // batches whose tensors reach 2 GiB: runs of `chunk` images, the first run writes dw, the others add to it
-    const int chunk = dtype == AD_BF16 ? images_per_launch(n, h, w, c1, c2, cout, false, true) : n;
+    const int chunk = ad_is_half(dtype) ? images_per_launch(n, h, w, c1, c2, cout, false, true) : n;
     hipStream_t s = (hipStream_t)stream;
-    const size_t tsz = dtype == AD_BF16 ? 2 : 4;
+    const size_t tsz = ad_is_half(dtype) ? 2 : 4;
     for (int i0 = 0; i0 < n; i0 += chunk) {
         const int nr = n - i0 < chunk ? n - i0 : chunk;
         const size_t pix0 = (size_t)i0 * h * w;
@@ -2248,7 +2262,8 @@ extern "C" int ad_conv3x3_wgrad(const void* x1, int c1, const void* x2, int c2, 
         a.g = p.g;
         const bool direct = p.nsplit == 1 && !p.specialised && chunk >= n;
         a.dw = direct ? dw_hwio : nullptr; a.cin_real = cin_real;
-        int rc = dtype == AD_BF16 ? launch_wgrad<PolBF16>(a, p, s) : launch_wgrad<PolF32>(a, p, s);
+        int rc = dtype == AD_BF16 ? launch_wgrad<PolBF16>(a, p, s)
+                 : dtype == AD_F16 ? launch_wgrad<PolF16>(a, p, s) : launch_wgrad<PolF32>(a, p, s);
         if (rc || direct) return rc;
         int total = 9 * cin_real * cout;
         wgrad_reduce_kernel<<<(total + 63) / 64, 256, 0, s>>>((const float*)ws, dw_hwio, p.nsplit, p.ncib, p.ncob, p.ck,

@@ -108,11 +108,12 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ xh,
                                                        const float* __restrict__ b, const float* __restrict__ inp,
                                                        const float* __restrict__ target, T* __restrict__ dxh,
                                                        float* __restrict__ part, int64_t ppi, int ch, int loss_kind,
-                                                       float eps, float gscale) {
+                                                       float eps, float gscale_host, const float* __restrict__ loss_scale) {
     constexpr int EPT = ElemTraits<T>::EPT;
     constexpr int PPB = 256 / G;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = reinterpret_cast<float*>(smem);  // [PPB][ch*3+3]
+    const float gscale = loss_scale ? gscale_host * loss_scale[0] : gscale_host;   // dynamic loss scale (fp16), device resident
     const int ncol = ch * 3 + 3;
     const int tid = threadIdx.x, gl = tid % G, gp = tid / G;
     const int img = blockIdx.y;
@@ -227,11 +228,11 @@ extern "C" size_t ad_head_ws_bytes(int n, int ch) {
 extern "C" int ad_head_fwd(const void* xh, const float* w, const float* b, const float* inp, const float* target,
                            float* out, float* stats, float* sqerr, int n, int64_t pix_per_img, int ch, int loss_kind,
                            float eps, void* ws, size_t ws_bytes, int dtype, void* stream) {
-    AD_REQUIRE(dtype == AD_BF16 || dtype == AD_F32, "ad_head_fwd: bad dtype %d", dtype);
+    AD_REQUIRE(ad_dtype_ok(dtype), "ad_head_fwd: bad dtype %d", dtype);
     AD_REQUIRE(n > 0 && pix_per_img > 0, "ad_head_fwd: bad shape");
     AD_REQUIRE(loss_kind == 0 || loss_kind == 1, "ad_head_fwd: loss_kind=%d", loss_kind);
     int g;
-    AD_REQUIRE(head_group(ch, dtype == AD_BF16 ? 8 : 4, &g), "ad_head_fwd: unsupported ch=%d", ch);
+    AD_REQUIRE(head_group(ch, ad_is_half(dtype) ? 8 : 4, &g), "ad_head_fwd: unsupported ch=%d", ch);
     const int bpi = head_bpi(pix_per_img, g);
     float* part = nullptr;
     if (target) {
@@ -241,13 +242,9 @@ extern "C" int ad_head_fwd(const void* xh, const float* w, const float* b, const
     }
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(bpi, n);
-    if (dtype == AD_BF16) {
-        HEAD_DISPATCH(head_fwd_kernel<bf16_t, G_><<<grid, 256, 0, s>>>((const bf16_t*)xh, w, b, inp, target, out, part,
-                                                                       pix_per_img, ch, loss_kind, eps);)
-    } else {
-        HEAD_DISPATCH(head_fwd_kernel<float, G_><<<grid, 256, 0, s>>>((const float*)xh, w, b, inp, target, out, part,
-                                                                      pix_per_img, ch, loss_kind, eps);)
-    }
+    AD_DISPATCH_DTYPE(dtype, T_,
+        HEAD_DISPATCH(head_fwd_kernel<T_, G_><<<grid, 256, 0, s>>>((const T_*)xh, w, b, inp, target, out, part, pix_per_img, ch,
+                                                                   loss_kind, eps);))
     AD_LAUNCH_CHECK("ad_head_fwd");
     if (target) {
         head_stats_kernel<<<1, 256, 0, s>>>(part, n, bpi, stats, sqerr, (float)pix_per_img * 3.f);
@@ -258,12 +255,12 @@ extern "C" int ad_head_fwd(const void* xh, const float* w, const float* b, const
 
 extern "C" int ad_head_bwd(const void* xh, const float* w, const float* b, const float* inp, const float* target,
                            void* dxh, float* dw, float* db, int n, int64_t pix_per_img, int ch, int loss_kind, float eps,
-                           float grad_scale, void* ws, size_t ws_bytes, int dtype, void* stream) {
-    AD_REQUIRE(dtype == AD_BF16 || dtype == AD_F32, "ad_head_bwd: bad dtype %d", dtype);
+                           float grad_scale, const float* loss_scale, void* ws, size_t ws_bytes, int dtype, void* stream) {
+    AD_REQUIRE(ad_dtype_ok(dtype), "ad_head_bwd: bad dtype %d", dtype);
     AD_REQUIRE(n > 0 && pix_per_img > 0 && target, "ad_head_bwd: bad shape / missing target");
     AD_REQUIRE(loss_kind == 0 || loss_kind == 1, "ad_head_bwd: loss_kind=%d", loss_kind);
     int g;
-    AD_REQUIRE(head_group(ch, dtype == AD_BF16 ? 8 : 4, &g), "ad_head_bwd: unsupported ch=%d", ch);
+    AD_REQUIRE(head_group(ch, ad_is_half(dtype) ? 8 : 4, &g), "ad_head_bwd: unsupported ch=%d", ch);
     const int bpi = head_bpi(pix_per_img, g);
     const int ncol = ch * 3 + 3;
     size_t need = (size_t)n * bpi * ncol * sizeof(float);
@@ -271,15 +268,9 @@ extern "C" int ad_head_bwd(const void* xh, const float* w, const float* b, const
     size_t lds = (size_t)(256 / g) * ncol * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(bpi, n);
-    if (dtype == AD_BF16) {
-        HEAD_DISPATCH(head_bwd_kernel<bf16_t, G_><<<grid, 256, lds, s>>>((const bf16_t*)xh, w, b, inp, target, (bf16_t*)dxh,
-                                                                         (float*)ws, pix_per_img, ch, loss_kind, eps,
-                                                                         grad_scale);)
-    } else {
-        HEAD_DISPATCH(head_bwd_kernel<float, G_><<<grid, 256, lds, s>>>((const float*)xh, w, b, inp, target, (float*)dxh,
-                                                                        (float*)ws, pix_per_img, ch, loss_kind, eps,
-                                                                        grad_scale);)
-    }
+    AD_DISPATCH_DTYPE(dtype, T_,
+        HEAD_DISPATCH(head_bwd_kernel<T_, G_><<<grid, 256, lds, s>>>((const T_*)xh, w, b, inp, target, (T_*)dxh, (float*)ws,
+                                                                     pix_per_img, ch, loss_kind, eps, grad_scale, loss_scale);))
     AD_LAUNCH_CHECK("ad_head_bwd");
     rows_reduce_kernel<<<(ncol + 3) / 4, 256, 0, s>>>((const float*)ws, n * bpi, ncol, dw, ch * 3, db);
     AD_LAUNCH_CHECK("head rows_reduce");

@@ -282,9 +282,9 @@ extern "C" int ad_layernorm_relu_fwd(const void* z, const float* gamma, const fl
                                      float* rstd, int64_t npix, int c, float eps, int relu, int dtype, void* stream) {
     if (npix <= 0) return AD_OK;
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == AD_BF16) return ln_fwd_launch<bf16_t>(z, gamma, beta, y, mean, rstd, npix, c, eps, relu, s);
-    if (dtype == AD_F32) return ln_fwd_launch<float>(z, gamma, beta, y, mean, rstd, npix, c, eps, relu, s);
-    return ad_set_error(AD_ERR_ARG, "ad_layernorm_relu_fwd: bad dtype %d", dtype);
+    AD_REQUIRE(ad_dtype_ok(dtype), "ad_layernorm_relu_fwd: bad dtype %d", dtype);
+    AD_DISPATCH_DTYPE(dtype, T_, return ln_fwd_launch<T_>(z, gamma, beta, y, mean, rstd, npix, c, eps, relu, s);)
+    return AD_OK;
 }
 
 extern "C" size_t ad_layernorm_bwd_ws_bytes(int64_t npix, int c) {
@@ -298,22 +298,19 @@ extern "C" int ad_layernorm_relu_bwd(const void* dy, const void* z, const float*
                                      void* stream) {
     AD_REQUIRE(npix > 0, "ad_layernorm_relu_bwd: npix=%ld", (long)npix);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == AD_BF16)
-        return relu ? ln_bwd_launch<bf16_t, 0>(dy, z, mean, rstd, gamma, beta, dz, dgamma, dbeta, dbias, npix, c, ws, ws_bytes, s)
-                    : ln_bwd_launch<bf16_t, 1>(dy, z, mean, rstd, gamma, beta, dz, dgamma, dbeta, dbias, npix, c, ws, ws_bytes, s);
-    if (dtype == AD_F32)
-        return relu ? ln_bwd_launch<float, 0>(dy, z, mean, rstd, gamma, beta, dz, dgamma, dbeta, dbias, npix, c, ws, ws_bytes, s)
-                    : ln_bwd_launch<float, 1>(dy, z, mean, rstd, gamma, beta, dz, dgamma, dbeta, dbias, npix, c, ws, ws_bytes, s);
-    return ad_set_error(AD_ERR_ARG, "ad_layernorm_relu_bwd: bad dtype %d", dtype);
+    AD_REQUIRE(ad_dtype_ok(dtype), "ad_layernorm_relu_bwd: bad dtype %d", dtype);
+    AD_DISPATCH_DTYPE(dtype, T_,
+        return relu ? ln_bwd_launch<T_, 0>(dy, z, mean, rstd, gamma, beta, dz, dgamma, dbeta, dbias, npix, c, ws, ws_bytes, s)
+                    : ln_bwd_launch<T_, 1>(dy, z, mean, rstd, gamma, beta, dz, dgamma, dbeta, dbias, npix, c, ws, ws_bytes, s);)
+    return AD_OK;
 }
 
 extern "C" int ad_relu_bwd(const void* dy, const void* y, void* dz, float* dbias, int64_t npix, int c, void* ws,
                            size_t ws_bytes, int dtype, void* stream) {
     AD_REQUIRE(npix > 0, "ad_relu_bwd: npix=%ld", (long)npix);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == AD_BF16)
-        return ln_bwd_launch<bf16_t, 2>(dy, y, nullptr, nullptr, nullptr, nullptr, dz, nullptr, nullptr, dbias, npix, c, ws, ws_bytes, s);
-    if (dtype == AD_F32)
-        return ln_bwd_launch<float, 2>(dy, y, nullptr, nullptr, nullptr, nullptr, dz, nullptr, nullptr, dbias, npix, c, ws, ws_bytes, s);
-    return ad_set_error(AD_ERR_ARG, "ad_relu_bwd: bad dtype %d", dtype);
+    AD_REQUIRE(ad_dtype_ok(dtype), "ad_relu_bwd: bad dtype %d", dtype);
+    AD_DISPATCH_DTYPE(dtype, T_,
+        return ln_bwd_launch<T_, 2>(dy, y, nullptr, nullptr, nullptr, nullptr, dz, nullptr, nullptr, dbias, npix, c, ws, ws_bytes, s);)
+    return AD_OK;
 }

@@ -165,9 +165,9 @@ void launch_march(const void* x, void* y, const int* sy, const float* wy, int ky
 extern "C" int ad_resample(const void* x, void* y, const int* sy, const float* wy, int ky, const int* sx,
                            const float* wx, int kx, int n, int h, int w, int oh, int ow, int c, int accumulate,
                            int dtype, void* stream) {
-    AD_REQUIRE(dtype == AD_BF16 || dtype == AD_F32, "ad_resample: bad dtype %d", dtype);
+    AD_REQUIRE(ad_dtype_ok(dtype), "ad_resample: bad dtype %d", dtype);
     AD_REQUIRE(n > 0 && h > 0 && w > 0 && oh > 0 && ow > 0 && ky > 0 && kx > 0, "ad_resample: bad shape");
-    const int ept = dtype == AD_BF16 ? 8 : 4;
+    const int ept = ad_is_half(dtype) ? 8 : 4;
     AD_REQUIRE(c > 0 && c % ept == 0, "ad_resample: c=%d must be a multiple of %d", c, ept);
     AD_REQUIRE(oh <= 65535 && n <= 65535, "ad_resample: oh=%d n=%d exceed the grid limits", oh, n);
     hipStream_t s = (hipStream_t)stream;
@@ -175,20 +175,15 @@ extern "C" int ad_resample(const void* x, void* y, const int* sy, const float* w
         // R output rows per thread: 4 where there are rows enough to keep every CU busy, else 1 (bottleneck maps)
         const bool r4 = (long)oh * n >= 4096;
 #define AD_RS(T, R) launch_march<T, R>(x, y, sy, wy, ky, sx, wx, kx, n, h, w, oh, ow, c, accumulate, s)
-        if (dtype == AD_BF16) { if (r4) AD_RS(bf16_t, 4); else AD_RS(bf16_t, 1); }
-        else { if (r4) AD_RS(float, 4); else AD_RS(float, 1); }
+        AD_DISPATCH_DTYPE(dtype, T_, if (r4) AD_RS(T_, 4); else AD_RS(T_, 1);)
 #undef AD_RS
         AD_LAUNCH_CHECK("ad_resample");
         return AD_OK;
     }
     const int row_items = ow * (c / ept);
     dim3 grid((row_items + 255) / 256, oh, n);
-    if (dtype == AD_BF16)
-        resample_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)x, (bf16_t*)y, sy, wy, ky, sx, wx, kx, h, w, oh, ow, c,
-                                                      accumulate);
-    else
-        resample_kernel<float><<<grid, 256, 0, s>>>((const float*)x, (float*)y, sy, wy, ky, sx, wx, kx, h, w, oh, ow, c,
-                                                     accumulate);
+    AD_DISPATCH_DTYPE(dtype, T_, resample_kernel<T_><<<grid, 256, 0, s>>>((const T_*)x, (T_*)y, sy, wy, ky, sx, wx, kx, h, w, oh, ow,
+                                                                        c, accumulate);)
     AD_LAUNCH_CHECK("ad_resample");
     return AD_OK;
 }

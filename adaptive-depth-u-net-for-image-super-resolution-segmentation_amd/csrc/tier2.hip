@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256) void seg_head_bwd_kernel(const T* __restrict__
                                                            const float* __restrict__ target, const float* __restrict__ prob,
                                                            const float* __restrict__ sums, T* __restrict__ dxh,
                                                            float* __restrict__ part, int64_t ppi, int ch, int n, float wb,
-                                                           float wd, float smooth) {
+                                                           float wd, float smooth, const float* __restrict__ loss_scale) {
     constexpr int EPT = ElemTraits<T>::EPT;
     constexpr int PPB = 256 / G;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -391,6 +391,7 @@ __global__ __launch_bounds__(256) void seg_head_bwd_kernel(const T* __restrict__
     const float inter = sums[img * 3 + 1], uni = sums[img * 3 + 2];
     const float den = uni + smooth;
     const float inv_cnt = 1.0f / ((float)n * (float)ppi);
+    const float lscale = loss_scale ? loss_scale[0] : 1.f;        // dynamic loss scale (fp16), device resident
     for (int64_t q = (int64_t)blockIdx.x * PPB + gp; q < ppi; q += (int64_t)gridDim.x * PPB) {
         const int64_t pix = (int64_t)img * ppi + q;
         const float p = prob[pix], y = target[pix];
@@ -402,7 +403,7 @@ __global__ __launch_bounds__(256) void seg_head_bwd_kernel(const T* __restrict__
             const float ddice = (2.f * y * den - (2.f * inter + smooth)) / (den * den);
             dp += -wd * ddice / (float)n;
         }
-        const float g = dp * p * (1.f - p);
+        const float g = dp * p * (1.f - p) * lscale;
         Vec16<T> ld, st;
         float x[EPT], dx[EPT];
         ld.load(xh + pix * ch + gl * EPT);
@@ -504,20 +505,18 @@ extern "C" int ad_batchnorm_relu_fwd_train(const void* z, const float* gamma, co
                                            float* save_rstd, float* save_var, float* moving_mean, float* moving_var,
                                            float momentum, int64_t npix, int c, float eps, int relu, void* ws,
                                            size_t ws_bytes, int dtype, void* stream) {
-    AD_REQUIRE(dtype == AD_BF16 || dtype == AD_F32, "ad_batchnorm_relu_fwd_train: bad dtype %d", dtype);
-    const int ept = dtype == AD_BF16 ? 8 : 4;
+    AD_REQUIRE(ad_dtype_ok(dtype), "ad_batchnorm_relu_fwd_train: bad dtype %d", dtype);
+    const int ept = ad_is_half(dtype) ? 8 : 4;
     AD_REQUIRE(npix > 0 && chan_ok(c, ept), "ad_batchnorm_relu_fwd_train: unsupported npix=%ld c=%d", (long)npix, c);
     if (!ws || ws_bytes < ad_batchnorm_ws_bytes(c)) return ad_set_error(AD_ERR_WS, "ad_batchnorm: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     const int cs = slice_channels(c, ept);
     for (int c0 = 0; c0 < c; c0 += cs) {
-        const int rc = dtype == AD_BF16
-            ? bn_fwd_train<bf16_t>((const bf16_t*)z + c0, gamma + c0, beta + c0, (bf16_t*)y + c0, save_mean + c0, save_rstd + c0,
-                                   save_var + c0, moving_mean ? moving_mean + c0 : nullptr, moving_var ? moving_var + c0 : nullptr,
-                                   momentum, npix, cs, c, eps, relu, (float*)ws, s)
-            : bn_fwd_train<float>((const float*)z + c0, gamma + c0, beta + c0, (float*)y + c0, save_mean + c0, save_rstd + c0,
+        int rc = AD_OK;
+        AD_DISPATCH_DTYPE(dtype, T_,
+            rc = bn_fwd_train<T_>((const T_*)z + c0, gamma + c0, beta + c0, (T_*)y + c0, save_mean + c0, save_rstd + c0,
                                   save_var + c0, moving_mean ? moving_mean + c0 : nullptr, moving_var ? moving_var + c0 : nullptr,
-                                  momentum, npix, cs, c, eps, relu, (float*)ws, s);
+                                  momentum, npix, cs, c, eps, relu, (float*)ws, s);)
         if (rc) return rc;
     }
     return AD_OK;
@@ -526,20 +525,16 @@ extern "C" int ad_batchnorm_relu_fwd_train(const void* z, const float* gamma, co
 extern "C" int ad_batchnorm_relu_fwd_infer(const void* z, const float* gamma, const float* beta, const float* moving_mean,
                                            const float* moving_var, void* y, float* rstd_tmp, int64_t npix, int c, float eps,
                                            int relu, int dtype, void* stream) {
-    AD_REQUIRE(dtype == AD_BF16 || dtype == AD_F32, "ad_batchnorm_relu_fwd_infer: bad dtype %d", dtype);
-    const int ept = dtype == AD_BF16 ? 8 : 4;
+    AD_REQUIRE(ad_dtype_ok(dtype), "ad_batchnorm_relu_fwd_infer: bad dtype %d", dtype);
+    const int ept = ad_is_half(dtype) ? 8 : 4;
     AD_REQUIRE(npix > 0 && chan_ok(c, ept), "ad_batchnorm_relu_fwd_infer: unsupported npix=%ld c=%d", (long)npix, c);
     hipStream_t s = (hipStream_t)stream;
     bn_finalize_kernel<<<(c + 255) / 256, 256, 0, s>>>(moving_mean, moving_var, rstd_tmp, nullptr, nullptr, 0.f, eps, c);
     const int cs = slice_channels(c, ept);
     const int blocks = ew_blocks(npix * (cs / ept));
     for (int c0 = 0; c0 < c; c0 += cs) {
-        if (dtype == AD_BF16)
-            bn_apply_kernel<bf16_t><<<blocks, 256, 0, s>>>((const bf16_t*)z + c0, moving_mean + c0, rstd_tmp + c0, gamma + c0,
-                                                           beta + c0, (bf16_t*)y + c0, npix, cs, relu, c);
-        else
-            bn_apply_kernel<float><<<blocks, 256, 0, s>>>((const float*)z + c0, moving_mean + c0, rstd_tmp + c0, gamma + c0,
-                                                          beta + c0, (float*)y + c0, npix, cs, relu, c);
+        AD_DISPATCH_DTYPE(dtype, T_, bn_apply_kernel<T_><<<blocks, 256, 0, s>>>((const T_*)z + c0, moving_mean + c0, rstd_tmp + c0,
+                                                                              gamma + c0, beta + c0, (T_*)y + c0, npix, cs, relu, c);)
     }
     AD_LAUNCH_CHECK("ad_batchnorm_relu_fwd_infer");
     return AD_OK;
@@ -548,34 +543,33 @@ extern "C" int ad_batchnorm_relu_fwd_infer(const void* z, const float* gamma, co
 extern "C" int ad_batchnorm_relu_bwd(const void* dy, const void* z, const float* save_mean, const float* save_rstd,
                                      const float* gamma, const float* beta, void* dz, float* dgamma, float* dbeta,
                                      int64_t npix, int c, int relu, void* ws, size_t ws_bytes, int dtype, void* stream) {
-    AD_REQUIRE(dtype == AD_BF16 || dtype == AD_F32, "ad_batchnorm_relu_bwd: bad dtype %d", dtype);
-    const int ept = dtype == AD_BF16 ? 8 : 4;
+    AD_REQUIRE(ad_dtype_ok(dtype), "ad_batchnorm_relu_bwd: bad dtype %d", dtype);
+    const int ept = ad_is_half(dtype) ? 8 : 4;
     AD_REQUIRE(npix > 0 && chan_ok(c, ept), "ad_batchnorm_relu_bwd: unsupported npix=%ld c=%d", (long)npix, c);
     if (!ws || ws_bytes < ad_batchnorm_ws_bytes(c)) return ad_set_error(AD_ERR_WS, "ad_batchnorm: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     const int cs = slice_channels(c, ept);
     for (int c0 = 0; c0 < c; c0 += cs) {
-        const int rc = dtype == AD_BF16
-            ? bn_bwd<bf16_t>((const bf16_t*)dy + c0, (const bf16_t*)z + c0, save_mean + c0, save_rstd + c0, gamma + c0, beta + c0,
-                             (bf16_t*)dz + c0, dgamma + c0, dbeta + c0, npix, cs, c, relu, (float*)ws, s)
-            : bn_bwd<float>((const float*)dy + c0, (const float*)z + c0, save_mean + c0, save_rstd + c0, gamma + c0, beta + c0,
-                            (float*)dz + c0, dgamma + c0, dbeta + c0, npix, cs, c, relu, (float*)ws, s);
+        int rc = AD_OK;
+        AD_DISPATCH_DTYPE(dtype, T_,
+            rc = bn_bwd<T_>((const T_*)dy + c0, (const T_*)z + c0, save_mean + c0, save_rstd + c0, gamma + c0, beta + c0,
+                            (T_*)dz + c0, dgamma + c0, dbeta + c0, npix, cs, c, relu, (float*)ws, s);)
         if (rc) return rc;
     }
     return AD_OK;
 }
 
 extern "C" int ad_colsum(const void* x, float* out, int64_t npix, int c, void* ws, size_t ws_bytes, int dtype, void* stream) {
-    AD_REQUIRE(dtype == AD_BF16 || dtype == AD_F32, "ad_colsum: bad dtype %d", dtype);
-    const int ept = dtype == AD_BF16 ? 8 : 4;
+    AD_REQUIRE(ad_dtype_ok(dtype), "ad_colsum: bad dtype %d", dtype);
+    const int ept = ad_is_half(dtype) ? 8 : 4;
     AD_REQUIRE(npix > 0 && chan_ok(c, ept), "ad_colsum: unsupported npix=%ld c=%d", (long)npix, c);
     if (!ws || ws_bytes < ad_batchnorm_ws_bytes(c)) return ad_set_error(AD_ERR_WS, "ad_colsum: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     const int cs = slice_channels(c, ept);
     for (int c0 = 0; c0 < c; c0 += cs) {
         int nb = 0;
-        int rc = dtype == AD_BF16 ? colstats<bf16_t>((const bf16_t*)x + c0, nullptr, (float*)ws, npix, cs, c, s, &nb)
-                                  : colstats<float>((const float*)x + c0, nullptr, (float*)ws, npix, cs, c, s, &nb);
+        int rc = AD_OK;
+        AD_DISPATCH_DTYPE(dtype, T_, rc = colstats<T_>((const T_*)x + c0, nullptr, (float*)ws, npix, cs, c, s, &nb);)
         if (rc) return rc;
         colstats_finish_kernel<<<(2 * cs + 3) / 4, 256, 0, s>>>((const float*)ws, nb, cs, 1.f, 0.f, nullptr, out + c0, nullptr);
     }
@@ -584,42 +578,36 @@ extern "C" int ad_colsum(const void* x, float* out, int64_t npix, int c, void* w
 }
 
 extern "C" int ad_maxpool2_fwd(const void* x, void* y, int n, int h, int w, int c, int dtype, void* stream) {
-    AD_REQUIRE(dtype == AD_BF16 || dtype == AD_F32, "ad_maxpool2_fwd: bad dtype %d", dtype);
-    const int ept = dtype == AD_BF16 ? 8 : 4;
+    AD_REQUIRE(ad_dtype_ok(dtype), "ad_maxpool2_fwd: bad dtype %d", dtype);
+    const int ept = ad_is_half(dtype) ? 8 : 4;
     AD_REQUIRE(n > 0 && h >= 2 && w >= 2 && c > 0 && c % ept == 0, "ad_maxpool2_fwd: bad shape");
     hipStream_t s = (hipStream_t)stream;
     const int blocks = ew_blocks((int64_t)n * (h / 2) * (w / 2) * (c / ept));
-    if (dtype == AD_BF16) maxpool2_fwd_kernel<bf16_t><<<blocks, 256, 0, s>>>((const bf16_t*)x, (bf16_t*)y, n, h, w, c);
-    else maxpool2_fwd_kernel<float><<<blocks, 256, 0, s>>>((const float*)x, (float*)y, n, h, w, c);
+    AD_DISPATCH_DTYPE(dtype, T_, maxpool2_fwd_kernel<T_><<<blocks, 256, 0, s>>>((const T_*)x, (T_*)y, n, h, w, c);)
     AD_LAUNCH_CHECK("ad_maxpool2_fwd");
     return AD_OK;
 }
 
 extern "C" int ad_maxpool2_bwd(const void* dy, const void* x, void* dx, int n, int h, int w, int c, int dtype, void* stream) {
-    AD_REQUIRE(dtype == AD_BF16 || dtype == AD_F32, "ad_maxpool2_bwd: bad dtype %d", dtype);
-    const int ept = dtype == AD_BF16 ? 8 : 4;
+    AD_REQUIRE(ad_dtype_ok(dtype), "ad_maxpool2_bwd: bad dtype %d", dtype);
+    const int ept = ad_is_half(dtype) ? 8 : 4;
     AD_REQUIRE(n > 0 && h >= 2 && w >= 2 && c > 0 && c % ept == 0, "ad_maxpool2_bwd: bad shape");
     hipStream_t s = (hipStream_t)stream;
     const int blocks = ew_blocks((int64_t)n * h * w * (c / ept));
-    if (dtype == AD_BF16) maxpool2_bwd_kernel<bf16_t><<<blocks, 256, 0, s>>>((const bf16_t*)dy, (const bf16_t*)x, (bf16_t*)dx, n, h, w, c);
-    else maxpool2_bwd_kernel<float><<<blocks, 256, 0, s>>>((const float*)dy, (const float*)x, (float*)dx, n, h, w, c);
+    AD_DISPATCH_DTYPE(dtype, T_, maxpool2_bwd_kernel<T_><<<blocks, 256, 0, s>>>((const T_*)dy, (const T_*)x, (T_*)dx, n, h, w, c);)
     AD_LAUNCH_CHECK("ad_maxpool2_bwd");
     return AD_OK;
 }
 
 extern "C" int ad_pixel_shuffle2(const void* x, void* y, int n, int h, int w, int c, int to_space, int dtype, void* stream) {
-    AD_REQUIRE(dtype == AD_BF16 || dtype == AD_F32, "ad_pixel_shuffle2: bad dtype %d", dtype);
-    const int ept = dtype == AD_BF16 ? 8 : 4;
+    AD_REQUIRE(ad_dtype_ok(dtype), "ad_pixel_shuffle2: bad dtype %d", dtype);
+    const int ept = ad_is_half(dtype) ? 8 : 4;
     AD_REQUIRE(n > 0 && h > 0 && w > 0 && c > 0 && c % ept == 0, "ad_pixel_shuffle2: bad shape");
     hipStream_t s = (hipStream_t)stream;
     const int blocks = ew_blocks((int64_t)n * h * w * 4 * (c / ept));
-    if (dtype == AD_BF16) {
-        if (to_space) shuffle2_kernel<bf16_t, true><<<blocks, 256, 0, s>>>((const bf16_t*)x, (bf16_t*)y, n, h, w, c);
-        else shuffle2_kernel<bf16_t, false><<<blocks, 256, 0, s>>>((const bf16_t*)x, (bf16_t*)y, n, h, w, c);
-    } else {
-        if (to_space) shuffle2_kernel<float, true><<<blocks, 256, 0, s>>>((const float*)x, (float*)y, n, h, w, c);
-        else shuffle2_kernel<float, false><<<blocks, 256, 0, s>>>((const float*)x, (float*)y, n, h, w, c);
-    }
+    AD_DISPATCH_DTYPE(dtype, T_,
+        if (to_space) shuffle2_kernel<T_, true><<<blocks, 256, 0, s>>>((const T_*)x, (T_*)y, n, h, w, c);
+        else shuffle2_kernel<T_, false><<<blocks, 256, 0, s>>>((const T_*)x, (T_*)y, n, h, w, c);)
     AD_LAUNCH_CHECK("ad_pixel_shuffle2");
     return AD_OK;
 }
@@ -651,9 +639,9 @@ extern "C" size_t ad_seg_head_ws_bytes(int n, int ch) { return (size_t)n * 64 * 
 
 extern "C" int ad_seg_head_fwd(const void* xh, const float* w, const float* b, const float* target, float* prob, float* sums,
                                int n, int64_t pix_per_img, int ch, void* ws, size_t ws_bytes, int dtype, void* stream) {
-    AD_REQUIRE(dtype == AD_BF16 || dtype == AD_F32, "ad_seg_head_fwd: bad dtype %d", dtype);
+    AD_REQUIRE(ad_dtype_ok(dtype), "ad_seg_head_fwd: bad dtype %d", dtype);
     int g;
-    AD_REQUIRE(n > 0 && pix_per_img > 0 && seg_group(ch, dtype == AD_BF16 ? 8 : 4, &g), "ad_seg_head_fwd: unsupported shape ch=%d", ch);
+    AD_REQUIRE(n > 0 && pix_per_img > 0 && seg_group(ch, ad_is_half(dtype) ? 8 : 4, &g), "ad_seg_head_fwd: unsupported shape ch=%d", ch);
     const int bpi = seg_bpi(pix_per_img, g);
     float* part = nullptr;
     if (target) {
@@ -662,8 +650,8 @@ extern "C" int ad_seg_head_fwd(const void* xh, const float* w, const float* b, c
     }
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(bpi, n);
-    if (dtype == AD_BF16) { SEG_DISPATCH(seg_head_fwd_kernel<bf16_t, G_><<<grid, 256, 0, s>>>((const bf16_t*)xh, w, b, target, prob, part, pix_per_img, ch);) }
-    else { SEG_DISPATCH(seg_head_fwd_kernel<float, G_><<<grid, 256, 0, s>>>((const float*)xh, w, b, target, prob, part, pix_per_img, ch);) }
+    AD_DISPATCH_DTYPE(dtype, T_,
+        SEG_DISPATCH(seg_head_fwd_kernel<T_, G_><<<grid, 256, 0, s>>>((const T_*)xh, w, b, target, prob, part, pix_per_img, ch);))
     AD_LAUNCH_CHECK("ad_seg_head_fwd");
     if (target) {
         seg_sums_kernel<<<(n * 3 + 255) / 256, 256, 0, s>>>(part, n, bpi, sums);
@@ -674,18 +662,20 @@ extern "C" int ad_seg_head_fwd(const void* xh, const float* w, const float* b, c
 
 extern "C" int ad_seg_head_bwd(const void* xh, const float* w, const float* target, const float* prob, const float* sums,
                                void* dxh, float* dw, float* db, int n, int64_t pix_per_img, int ch, float bce_weight,
-                               float dice_weight, float smooth, void* ws, size_t ws_bytes, int dtype, void* stream) {
-    AD_REQUIRE(dtype == AD_BF16 || dtype == AD_F32, "ad_seg_head_bwd: bad dtype %d", dtype);
+                               float dice_weight, float smooth, const float* loss_scale, void* ws, size_t ws_bytes, int dtype,
+                               void* stream) {
+    AD_REQUIRE(ad_dtype_ok(dtype), "ad_seg_head_bwd: bad dtype %d", dtype);
     int g;
-    AD_REQUIRE(n > 0 && pix_per_img > 0 && seg_group(ch, dtype == AD_BF16 ? 8 : 4, &g), "ad_seg_head_bwd: unsupported shape ch=%d", ch);
+    AD_REQUIRE(n > 0 && pix_per_img > 0 && seg_group(ch, ad_is_half(dtype) ? 8 : 4, &g), "ad_seg_head_bwd: unsupported shape ch=%d", ch);
     const int bpi = seg_bpi(pix_per_img, g);
     const int ncol = ch + 1;
     if (!ws || ws_bytes < (size_t)n * bpi * ncol * sizeof(float)) return ad_set_error(AD_ERR_WS, "ad_seg_head_bwd: workspace too small");
     size_t lds = (size_t)(256 / g) * ncol * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(bpi, n);
-    if (dtype == AD_BF16) { SEG_DISPATCH(seg_head_bwd_kernel<bf16_t, G_><<<grid, 256, lds, s>>>((const bf16_t*)xh, w, target, prob, sums, (bf16_t*)dxh, (float*)ws, pix_per_img, ch, n, bce_weight, dice_weight, smooth);) }
-    else { SEG_DISPATCH(seg_head_bwd_kernel<float, G_><<<grid, 256, lds, s>>>((const float*)xh, w, target, prob, sums, (float*)dxh, (float*)ws, pix_per_img, ch, n, bce_weight, dice_weight, smooth);) }
+    AD_DISPATCH_DTYPE(dtype, T_,
+        SEG_DISPATCH(seg_head_bwd_kernel<T_, G_><<<grid, 256, lds, s>>>((const T_*)xh, w, target, prob, sums, (T_*)dxh, (float*)ws,
+                                                                        pix_per_img, ch, n, bce_weight, dice_weight, smooth, loss_scale);))
     AD_LAUNCH_CHECK("ad_seg_head_bwd");
     rows_sum_kernel<<<(ncol + 255) / 256, 256, 0, s>>>((const float*)ws, n * bpi, ncol, dw, ch, db);
     AD_LAUNCH_CHECK("seg rows_sum");

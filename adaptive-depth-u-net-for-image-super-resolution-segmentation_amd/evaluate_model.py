@@ -136,7 +136,7 @@ def parse_args(argv=None) -> argparse.Namespace:
     p.add_argument("--skip-per-image", action="store_true")
     p.add_argument("--dtype", choices=["float32", "bfloat16", "float16"], default=None,
                    help="compute dtype (default: the one recorded in the checkpoint, else float32)")
-    p.add_argument("--mixed-precision", action="store_true", help="shorthand for --dtype bfloat16")
+    p.add_argument("--mixed-precision", action="store_true", help="shorthand for --dtype float16 (the reference's policy)")
     return p.parse_args(argv)
 
 
@@ -155,7 +155,7 @@ def main(argv=None) -> None:
     import torch
     dtype = {"float32": torch.float32, "bfloat16": torch.bfloat16, "float16": torch.float16, None: None}[args.dtype]
     if dtype is None and args.mixed_precision:
-        dtype = torch.bfloat16
+        dtype = torch.float16
     model = load_checkpoint_model(args.model_path.expanduser(), args.scale, args.patch_size, args.depth_override, dtype=dtype)
     shave = infer_eval_shave(args.scale, args.eval_shave)
     summary, per_patch = evaluate(model, eval_ds, eval_shave=shave)

@@ -77,6 +77,62 @@ class Adam:
         return float(lr(step)) if callable(lr) else float(lr)
 
 
+class LossScaleOptimizer:
+    """tf.keras.mixed_precision.LossScaleOptimizer(inner, dynamic=True): what Keras wraps the optimizer in under the
+    reference's mixed_float16 policy (Super_resolution/code/train_adaptive_unet.py:471-477).  Initial scale 2**15; a step
+    whose gradients contain inf / NaN is skipped and halves the scale; `dynamic_growth_steps` (2000) consecutive finite
+    steps double it; the inner optimizer's iteration count advances on applied steps only.
+
+    The scaler state lives in device memory (include/adunet.h, ad_loss_scale_*): the backward pass, the finiteness
+    check, the (possibly skipped) Adam update and the scale update run without a host round trip, so the step can be
+    replayed from a hipGraph.  The host-side attributes are read back on demand (`sync()`)."""
+
+    def __init__(self, inner_optimizer: Adam, initial_scale: float = 2.0 ** 15, dynamic_growth_steps: int = 2000):
+        self.inner_optimizer = inner_optimizer
+        self.initial_scale = float(initial_scale)
+        self.dynamic_growth_steps = int(dynamic_growth_steps)
+        self.state: Optional[torch.Tensor] = None      # device float32[8], see ad_loss_scale_check
+        self.lr_dev: Optional[torch.Tensor] = None
+        self.calls = 0                                 # train steps issued (applied + skipped)
+
+    # the Adam hyper-parameters of the wrapped optimizer
+    learning_rate = property(lambda self: self.inner_optimizer.learning_rate)
+    beta_1 = property(lambda self: self.inner_optimizer.beta_1)
+    beta_2 = property(lambda self: self.inner_optimizer.beta_2)
+    epsilon = property(lambda self: self.inner_optimizer.epsilon)
+
+    def lr_at(self, step: int) -> float:
+        return self.inner_optimizer.lr_at(step)
+
+    def ensure(self, device):
+        if self.state is None:
+            host = torch.zeros(8, dtype=torch.float32)
+            host[0], host[1] = self.initial_scale, 1.0 / self.initial_scale
+            host[4] = float(self.inner_optimizer.iterations)
+            self.state = host.to(device)
+            self.lr_dev = torch.zeros(1, dtype=torch.float32, device=device)
+
+    def sync(self) -> Dict[str, float]:
+        """Read the scaler back (one device -> host copy): dynamic scale, applied and skipped step counts."""
+        st = self.state.cpu().tolist() if self.state is not None else [self.initial_scale, 0, 0, 0, self.inner_optimizer.iterations, 0]
+        self.inner_optimizer.iterations = int(st[4])
+        return {"loss_scale": st[0], "good_steps": int(st[2]), "applied": int(st[4]), "skipped": int(st[5])}
+
+    @property
+    def loss_scale(self) -> float:
+        return self.sync()["loss_scale"]
+
+    @property
+    def iterations(self) -> int:
+        return self.sync()["applied"]
+
+    @iterations.setter
+    def iterations(self, value: int):
+        self.inner_optimizer.iterations = int(value)
+        if self.state is not None:
+            self.state[4] = float(value)
+
+
 class History:
     def __init__(self):
         self.epoch: List[int] = []
@@ -383,7 +439,8 @@ class Model:
                     if c3 and cs is first:
                         z, a, mean, rstd = ops.conv3x3_c3_ln_relu_fwd(cur1, self.param(cs.name + "/kernel"),
                                                                       self.param(cs.name + "/bias"),
-                                                                      self.param(cs.ln + "/gamma"), self.param(cs.ln + "/beta"))
+                                                                      self.param(cs.ln + "/gamma"), self.param(cs.ln + "/beta"),
+                                                                      dtype=self.dtype)
                     else:
                         z, a, mean, rstd = ops.conv3x3_ln_relu_fwd(cur1, cur2, self._packs[cs.name][0],
                                                                    self.param(cs.name + "/bias"), self.param(cs.ln + "/gamma"),
@@ -432,6 +489,7 @@ class Model:
     def _backward(self, tape: List[tuple], x: torch.Tensor, target: torch.Tensor, grad_scale: float):
         ws = self._ws
         audit = self.audit
+        sc = self._scaler() if self.optimizer is not None else None
         dskips: Dict[int, torch.Tensor] = {}
         d = None
         while tape:
@@ -441,7 +499,8 @@ class Model:
                 w = self.param("residual_rgb/kernel").view(self.head, 3)
                 d = ops.head_bwd(rec[1], w, self.param("residual_rgb/bias"), x, target,
                                  self.grad("residual_rgb/kernel").view(self.head, 3), self.grad("residual_rgb/bias"),
-                                 grad_scale, ws, loss_kind=self.loss.kind, eps=self.loss.eps)
+                                 grad_scale, ws, loss_kind=self.loss.kind, eps=self.loss.eps,
+                                 loss_scale=sc.state if sc is not None else None)
                 self._done("residual_rgb/kernel")
                 if audit is not None:
                     audit.append(("bwd_head", "residual_rgb", rec[1], x, target, grad_scale, d))
@@ -465,7 +524,8 @@ class Model:
                 else:
                     d = ops.conv3x3_fwd(dz, None, self._packs[cs.name][1], None, self._cin_pad(cs))
                 if audit is not None:
-                    audit.append(("bwd_cla", cs.name, x1, x2, z, mean, rstd, d_in, dz, d, dsk))
+                    # (the skip half is accumulated into in place later on: record a copy)
+                    audit.append(("bwd_cla", cs.name, x1, x2, z, mean, rstd, d_in, dz, d, dsk.clone() if dsk is not None else None))
             elif kind == "ca":
                 _, cs, xin, u = rec
                 d_in = d
@@ -511,9 +571,52 @@ class Model:
             metrics = metrics if metrics is not None else default_metrics
         if loss is None or not hasattr(loss, "kind"):
             raise ValueError("loss must come from build_losses_and_metrics ('charbonnier' or 'l1')")
-        self.optimizer = optimizer if optimizer is not None else Adam()
+        self.optimizer = self._wrap_optimizer(optimizer if optimizer is not None else Adam())
         self.loss = loss
         self.metrics_names = ["loss"] + [getattr(m, "__name__", str(m)) for m in (metrics or [])]
+
+    def _wrap_optimizer(self, optimizer):
+        """Under a float16 policy Keras' compile() wraps the optimizer in a dynamic LossScaleOptimizer; so does this."""
+        if self.dtype == torch.float16 and not isinstance(optimizer, LossScaleOptimizer):
+            return LossScaleOptimizer(optimizer)
+        return optimizer
+
+    def _scaler(self) -> Optional[LossScaleOptimizer]:
+        opt = self.optimizer
+        if isinstance(opt, LossScaleOptimizer):
+            opt.ensure(self.device)
+            return opt
+        return None
+
+    def _apply_gradients(self, gscale: float, alpha_dev: Optional[torch.Tensor] = None):
+        """Optimizer application shared by the eager and the graph-captured step.  With a LossScaleOptimizer:
+        finiteness check -> Adam (skipped on overflow, gradients unscaled) -> scale update, all on the device."""
+        opt = self.optimizer
+        sc = self._scaler()
+        if sc is not None:
+            ops.loss_scale_check(self.G, sc.state)
+            ops.adam_step_scaled(self.P, self.G, self.M, self.V, sc.lr_dev, sc.state, b1=opt.beta_1, b2=opt.beta_2,
+                                 eps=opt.epsilon, gscale=gscale)
+            ops.loss_scale_update(sc.state, sc.dynamic_growth_steps)
+        elif alpha_dev is not None:
+            ops.adam_step_dev(self.P, self.G, self.M, self.V, alpha_dev, b1=opt.beta_1, b2=opt.beta_2, eps=opt.epsilon,
+                              gscale=gscale)
+        else:
+            ops.adam_step(self.P, self.G, self.M, self.V, opt.iterations, lr=opt.lr_at(opt.iterations - 1),
+                          b1=opt.beta_1, b2=opt.beta_2, eps=opt.epsilon, gscale=gscale)
+        self._repack()
+
+    def _begin_step(self, alpha_dev: Optional[torch.Tensor] = None):
+        """Host-side bookkeeping before a step: advance the step count and publish the step size / learning rate."""
+        opt = self.optimizer
+        sc = self._scaler()
+        if sc is not None:
+            sc.calls += 1
+            sc.lr_dev.fill_(opt.lr_at(sc.calls - 1))     # (a schedule sees issued steps; skipped ones are not re-read)
+        else:
+            opt.iterations += 1
+            if alpha_dev is not None:
+                alpha_dev.fill_(ops.adam_alpha(opt.lr_at(opt.iterations - 1), opt.beta_1, opt.beta_2, opt.iterations))
 
     def forward_loss(self, lr_img, hr_img, keep: bool = False):
         """Forward + fused loss.  Returns (out, loss_mean [device scalar], psnr_mean [device scalar], tape)."""
@@ -535,11 +638,8 @@ class Model:
         count = float(x.numel())
         self._backward(tape, x, t, 1.0 / count)
         gscale = self.grad_sync(self) if self.grad_sync is not None else 1.0
-        opt = self.optimizer
-        opt.iterations += 1
-        ops.adam_step(self.P, self.G, self.M, self.V, opt.iterations, lr=opt.lr_at(opt.iterations - 1),
-                      b1=opt.beta_1, b2=opt.beta_2, eps=opt.epsilon, gscale=gscale)
-        self._repack()
+        self._begin_step()
+        self._apply_gradients(gscale)
         return loss, psnr
 
     def test_on_batch(self, lr_img, hr_img):
@@ -621,18 +721,18 @@ class Model:
                         segs[-1] = (segs[-1][0], segs[-1][1], True)
                 else:
                     self.grad_sync(self)
-            ops.adam_step_dev(self.P, self.G, self.M, self.V, alpha_dev, b1=opt.beta_1, b2=opt.beta_2, eps=opt.epsilon,
-                              gscale=gscale)
-            self._repack()
+            self._apply_gradients(gscale, alpha_dev)
             return outputs
 
         def set_alpha():
-            opt.iterations += 1
-            alpha_dev.fill_(ops.adam_alpha(opt.lr_at(opt.iterations - 1), opt.beta_1, opt.beta_2, opt.iterations))
+            self._begin_step(alpha_dev)
 
         extra = self._graph_extra_state()        # e.g. BatchNorm moving statistics (subclasses)
-        saved_state = ((self.P.clone(), self.M.clone(), self.V.clone(), opt.iterations, [t.clone() for t in extra])
-                       if capture_only else None)
+        sc = self._scaler()
+        if sc is not None:
+            extra = list(extra) + [sc.state]         # the scaler is part of what a capture-only warm-up must put back
+        saved_state = ((self.P.clone(), self.M.clone(), self.V.clone(), (opt.iterations if sc is None else sc.calls),
+                        [t.clone() for t in extra]) if capture_only else None)
         side = torch.cuda.Stream(device=self.device)       # warm-up on a side stream, as torch's capture recipe asks
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -669,7 +769,10 @@ class Model:
 
         if capture_only:
             self.P.copy_(saved_state[0]); self.M.copy_(saved_state[1]); self.V.copy_(saved_state[2])
-            opt.iterations = saved_state[3]
+            if sc is None:
+                opt.iterations = saved_state[3]
+            else:
+                sc.calls = saved_state[3]
             for t, saved in zip(extra, saved_state[4]):
                 t.copy_(saved)
             self._repack()

@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import AD_BF16, AD_F32, EPI_NONE, EPI_RELU, check
+from ._lib import AD_BF16, AD_F16, AD_F32, EPI_NONE, EPI_RELU, check
 
 LN_EPS = 1e-3          # Keras LayerNormalization default (train_adaptive_unet.py:203)
 CHARBONNIER_EPS = 1e-3  # train_adaptive_unet.py:314
@@ -24,6 +24,8 @@ def dt(t: torch.dtype) -> int:
         return AD_BF16
     if t == torch.float32:
         return AD_F32
+    if t == torch.float16:
+        return AD_F16
     raise ValueError(f"unsupported activation dtype {t}")
 
 
@@ -250,16 +252,16 @@ def conv3x3_c3_supported(x: torch.Tensor, cout: int, dtype: torch.dtype) -> bool
 
 
 def conv3x3_c3_ln_relu_fwd(x: torch.Tensor, w_hwio: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.Tensor,
-                           beta: torch.Tensor, eps: float = LN_EPS):
-    """First conv_block step on the raw [N,H,W,3] fp32 input: returns (z, act, mean, rstd) in bf16 / fp32."""
+                           beta: torch.Tensor, eps: float = LN_EPS, dtype: torch.dtype = torch.bfloat16):
+    """First conv_block step on the raw [N,H,W,3] fp32 input: returns (z, act, mean, rstd), z / act in `dtype` (bf16 / fp16)."""
     n, h, w, _ = x.shape
-    z = torch.empty((n, h, w, 64), dtype=torch.bfloat16, device=x.device)
+    z = torch.empty((n, h, w, 64), dtype=dtype, device=x.device)
     act = torch.empty_like(z)
     mean = torch.empty(n * h * w, dtype=torch.float32, device=x.device)
     rstd = torch.empty(n * h * w, dtype=torch.float32, device=x.device)
     with _timed("conv3x3_c3_ln_relu_fwd", 2.0 * n * h * w * 27 * 64):
         check(_lib.load().ad_conv3x3_c3_ln_relu_fwd(_p(x), _p(w_hwio), _p(bias), _p(gamma), _p(beta), eps, _p(z), _p(act),
-                                                    _p(mean), _p(rstd), n, h, w, AD_BF16, _stream()),
+                                                    _p(mean), _p(rstd), n, h, w, dt(dtype), _stream()),
               "ad_conv3x3_c3_ln_relu_fwd")
     return z, act, mean, rstd
 
@@ -270,7 +272,7 @@ def conv3x3_c3_wgrad(x: torch.Tensor, dz: torch.Tensor, dw_out: torch.Tensor, ws
     lib = _lib.load()
     ws.ensure(lib.ad_conv3x3_c3_wgrad_ws_bytes(n, h, w))
     with _timed("conv3x3_c3_wgrad", 2.0 * n * h * w * 27 * 64):
-        check(lib.ad_conv3x3_c3_wgrad(_p(x), _p(dz), _p(dw_out), n, h, w, ws.ptr, ws.nbytes, AD_BF16, _stream()),
+        check(lib.ad_conv3x3_c3_wgrad(_p(x), _p(dz), _p(dw_out), n, h, w, ws.ptr, ws.nbytes, dt(dz.dtype), _stream()),
               "ad_conv3x3_c3_wgrad")
 
 
@@ -367,14 +369,15 @@ def head_fwd(xh, w, b, inp, target, ws: Workspace, loss_kind: int = 0, eps: floa
 
 
 def head_bwd(xh, w, b, inp, target, dw, db, grad_scale: float, ws: Workspace, loss_kind: int = 0,
-             eps: float = CHARBONNIER_EPS):
+             eps: float = CHARBONNIER_EPS, loss_scale: Optional[torch.Tensor] = None):
+    """loss_scale: the device-resident scaler state of a LossScaleOptimizer (its first float multiplies the gradient)."""
     n, h, wd, ch = xh.shape
     dxh = torch.empty_like(xh)
     lib = _lib.load()
     ws.ensure(lib.ad_head_ws_bytes(n, ch))
     with _timed("head_bwd"):
         check(lib.ad_head_bwd(_p(xh), _p(w), _p(b), _p(inp), _p(target), _p(dxh), _p(dw), _p(db), n, h * wd, ch, loss_kind,
-                              eps, grad_scale, ws.ptr, ws.nbytes, dt(xh.dtype), _stream()), "ad_head_bwd")
+                              eps, grad_scale, _p(loss_scale), ws.ptr, ws.nbytes, dt(xh.dtype), _stream()), "ad_head_bwd")
     return dxh
 
 
@@ -393,6 +396,24 @@ def adam_step_dev(p, g, m, v, alpha_dev: torch.Tensor, b1=0.9, b2=0.999, eps=1e-
     with _timed("adam_step"):
         check(_lib.load().ad_adam_step_dev(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(alpha_dev), b1, b2, eps, gscale,
                                            _stream()), "ad_adam_step_dev")
+
+
+def loss_scale_check(g: torch.Tensor, state: torch.Tensor):
+    """Sets state[3] when the flat gradient buffer holds an inf / NaN (Keras LossScaleOptimizer's finiteness test)."""
+    with _timed("loss_scale"):
+        check(_lib.load().ad_loss_scale_check(_p(g), g.numel(), _p(state), _stream()), "ad_loss_scale_check")
+
+
+def loss_scale_update(state: torch.Tensor, growth_steps: int):
+    with _timed("loss_scale"):
+        check(_lib.load().ad_loss_scale_update(_p(state), growth_steps, _stream()), "ad_loss_scale_update")
+
+
+def adam_step_scaled(p, g, m, v, lr_dev: torch.Tensor, state: torch.Tensor, b1=0.9, b2=0.999, eps=1e-7, gscale: float = 1.0):
+    """Adam under a device-resident loss scaler: skipped on overflow, gradients unscaled, applied-step bias correction."""
+    with _timed("adam_step"):
+        check(_lib.load().ad_adam_step_scaled(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(lr_dev), b1, b2, eps, gscale,
+                                              _p(state), _stream()), "ad_adam_step_scaled")
 
 
 def cast(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
@@ -537,13 +558,13 @@ def seg_head_fwd(xh, w, b, target, ws: Workspace):
 
 
 def seg_head_bwd(xh, w, target, prob, sums, dw, db, bce_weight: float, dice_weight: float, ws: Workspace,
-                 smooth: float = 1e-6):
+                 smooth: float = 1e-6, loss_scale: Optional[torch.Tensor] = None):
     n, h, wd, ch = xh.shape
     dxh = torch.empty_like(xh)
     lib = _lib.load()
     ws.ensure(lib.ad_seg_head_ws_bytes(n, ch))
     with _timed("seg_head_bwd"):
         check(lib.ad_seg_head_bwd(_p(xh), _p(w), _p(target), _p(prob), _p(sums), _p(dxh), _p(dw), _p(db), n, h * wd, ch,
-                                  bce_weight, dice_weight, smooth, ws.ptr, ws.nbytes, dt(xh.dtype), _stream()),
+                                  bce_weight, dice_weight, smooth, _p(loss_scale), ws.ptr, ws.nbytes, dt(xh.dtype), _stream()),
               "ad_seg_head_bwd")
     return dxh

@@ -117,6 +117,7 @@ class SegModel(Model):
         self.metrics_names = ["loss", "dice", "iou"]
         self.stop_training = False
         self.grad_sync = self.grad_ready = None
+        self.audit = None                 # parity instrumentation, see Model.audit
         self._up_tabs = {}
 
     # ------------------------------------------------------------------ graph
@@ -263,6 +264,8 @@ class SegModel(Model):
                                                            g, b, cs.cout)
             if keep:
                 tape.append(("cna", cs, nn, x1, x2, z, mean, rstd))
+            if self.audit is not None:
+                self.audit.append(("fwd_cna", cs.name, x1, x2, z, a, mean, rstd, training))
             x1, x2 = a, None
         return x1
 
@@ -274,18 +277,27 @@ class SegModel(Model):
             skips.append(x)
             if keep:
                 tape.append(("pool", x, lvl))
-            x = ops.maxpool2_fwd(x)
+            pooled = ops.maxpool2_fwd(x)
+            if self.audit is not None:
+                self.audit.append(("fwd_pool", f"pool{lvl}", x, pooled))
+            x = pooled
         x = self._block_fwd(self.blocks[self.depth], x, None, training, tape, keep)
         for i, lvl in enumerate(reversed(range(self.depth))):
             t = self.ups[i]
             if t is not None:
                 if keep:
                     tape.append(("convT", t, x))
-                x = ops.conv_transpose2x2s2_fwd(x, self._tpacks[t][0], self.param(t + "/bias"), skips[lvl].shape[-1])
+                y = ops.conv_transpose2x2s2_fwd(x, self._tpacks[t][0], self.param(t + "/bias"), skips[lvl].shape[-1])
+                if self.audit is not None:
+                    self.audit.append(("fwd_convT", t, x, y))
+                x = y
             else:
                 if keep:
                     tape.append(("up2", x.shape[1]))
-                x = ops.resample(x, self._up_tables(x.shape[1], False))
+                y = ops.resample(x, self._up_tables(x.shape[1], False))
+                if self.audit is not None:
+                    self.audit.append(("fwd_up2", f"up{lvl}", x, y))
+                x = y
             if keep:
                 tape.append(("concat", lvl))
             x = self._block_fwd(self.blocks[self.depth + 1 + i], x, skips[lvl], training, tape, keep)
@@ -293,10 +305,14 @@ class SegModel(Model):
         prob, sums = ops.seg_head_fwd(x, w, self.param(self.head_name + "/bias"), mask, self._ws)
         if keep:
             tape.append(("head", x, prob, sums))
+        if self.audit is not None:
+            self.audit.append(("fwd_head", self.head_name, x, mask, prob, sums))
         return prob, sums, tape
 
     def _backward_seg(self, tape, mask):
         ws = self._ws
+        audit = self.audit
+        sc = self._scaler() if self.optimizer is not None else None
         dskips: Dict[int, torch.Tensor] = {}
         pending_skip = None
         d = None
@@ -307,10 +323,14 @@ class SegModel(Model):
                 _, xh, prob, sums = rec
                 d = ops.seg_head_bwd(xh, self.param(self.head_name + "/kernel").view(self.head_channels), mask, prob, sums,
                                      self.grad(self.head_name + "/kernel").view(self.head_channels),
-                                     self.grad(self.head_name + "/bias"), self.loss.bce_weight, self.loss.dice_weight, ws)
+                                     self.grad(self.head_name + "/bias"), self.loss.bce_weight, self.loss.dice_weight, ws,
+                                     loss_scale=sc.state if sc is not None else None)
                 self._done(self.head_name + "/kernel")
+                if audit is not None:
+                    audit.append(("bwd_head", self.head_name, xh, mask, prob, d))
             elif kind == "cna":
                 _, cs, nn, x1, x2, z, mean, rstd = rec
+                d_in = d
                 g, b = self.param(nn + "/gamma"), self.param(nn + "/beta")
                 if self.norm == "bn":
                     dz = ops.batchnorm_relu_bwd(d, z, mean, rstd, g, b, self.grad(nn + "/gamma"), self.grad(nn + "/beta"), ws)
@@ -320,24 +340,38 @@ class SegModel(Model):
                                                 self.grad(cs.name + "/bias"), ws)
                 ops.conv3x3_wgrad(x1, x2, dz, self.grad(cs.name + "/kernel"), cs.cin, ws)
                 self._done(cs.name + "/kernel")
+                dsk = None
                 if not cs.need_dgrad:
                     d = None
                 elif x2 is not None:
                     d, pending_skip = ops.conv3x3_fwd(dz, None, self._packs[cs.name][1], None, cs.cin, split=x1.shape[-1])
+                    dsk = pending_skip
                 else:
                     d = ops.conv3x3_fwd(dz, None, self._packs[cs.name][1], None, self._cin_pad(cs))
+                if audit is not None:
+                    audit.append(("bwd_cna", cs.name, x1, x2, z, mean, rstd, d_in, dz, d, dsk))
             elif kind == "concat":
                 dskips[rec[1]] = pending_skip
             elif kind == "up2":
+                d_in = d
                 d = ops.resample(d, self._up_tables(rec[1], True))
+                if audit is not None:
+                    audit.append(("bwd_up2", "up", d_in, d))
             elif kind == "convT":
                 _, t, xin = rec
+                d_in = d
                 d = ops.conv_transpose2x2s2_bwd(xin, d, self._tpacks[t][1], self.grad(t + "/kernel"), self.grad(t + "/bias"), ws)
                 self._done(t + "/kernel")
+                if audit is not None:
+                    audit.append(("bwd_convT", t, xin, d_in, d))
             elif kind == "pool":
                 _, xin, lvl = rec
+                d_in = d
                 dp = ops.maxpool2_bwd(d, xin)
-                d = ops.resample(dskips.pop(lvl), self._identity_tables(xin.shape[1]), out=dp, accumulate=True)
+                skip_grad = dskips.pop(lvl)
+                d = ops.resample(skip_grad, self._identity_tables(xin.shape[1]), out=dp, accumulate=True)
+                if audit is not None:
+                    audit.append(("bwd_pool", f"pool{lvl}", xin, d_in, skip_grad, d))
 
     def _identity_tables(self, h: int):
         """1-tap identity map: lets ad_resample add the skip gradient into the pooling gradient in place."""
@@ -365,7 +399,7 @@ class SegModel(Model):
             raise ValueError("jit_compile=True is not supported (the reference disables XLA as well)")
         if loss is None or not hasattr(loss, "bce_weight"):
             raise ValueError("loss must come from make_hybrid_ce_dice_loss / make_bce_dice_loss / binary_crossentropy")
-        self.optimizer = optimizer if optimizer is not None else Adam()
+        self.optimizer = self._wrap_optimizer(optimizer if optimizer is not None else Adam())
         self.loss = loss
         self.metrics_names = ["loss", "dice", "iou"]
 
@@ -384,11 +418,8 @@ class SegModel(Model):
         prob, sums, tape = self._forward_seg(x, m, training=True, keep=True)
         self._backward_seg(tape, m)
         gscale = self.grad_sync(self) if self.grad_sync is not None else 1.0
-        opt = self.optimizer
-        opt.iterations += 1
-        ops.adam_step(self.P, self.G, self.M, self.V, opt.iterations, lr=opt.lr_at(opt.iterations - 1),
-                      b1=opt.beta_1, b2=opt.beta_2, eps=opt.epsilon, gscale=gscale)
-        self._repack()
+        self._begin_step()
+        self._apply_gradients(gscale)
         return self._metrics_from(sums, float(m.numel()))
 
     # ---- graph-replayed train step (Model.make_graphed_train_step / fit): same hooks, segmentation flavour

@@ -68,7 +68,9 @@ def train(args: argparse.Namespace):
         raise ValueError("Training dataset produced zero patches. Check patches_per_image or dataset splits.")
 
     import torch
-    dtype = torch.bfloat16 if args.mixed_precision else torch.float32     # reference: mixed_float16 on GPU (:471-477)
+    # --mixed_precision = the reference's mixed_float16 policy (:471-477): fp16 storage, fp32 variables, dynamic loss
+    # scaling (compile() wraps Adam in a LossScaleOptimizer).  --bf16 is this build's throughput policy (no scaling needed).
+    dtype = torch.bfloat16 if args.bf16 else torch.float16 if args.mixed_precision else torch.float32
     model, info = build_super_resolution_unet(args.scale, DEFAULT_BASE_CHANNELS, DEFAULT_RESIDUAL_HEAD_CHANNELS,
                                               depth_override=args.depth_override, input_size=patch_size,
                                               max_depth=args.max_depth, dtype=dtype, seed=args.seed)
@@ -147,7 +149,8 @@ def parse_args(argv=None) -> argparse.Namespace:
     p.add_argument("--eval_shave", type=int, default=None)
     p.add_argument("--depth_override", type=int, default=None)
     p.add_argument("--max_depth", type=int, default=7)
-    p.add_argument("--mixed_precision", action="store_true", help="bf16 activations (the reference uses mixed_float16)")
+    p.add_argument("--mixed_precision", action="store_true", help="mixed_float16 policy with dynamic loss scaling, as the reference")
+    p.add_argument("--bf16", action="store_true", help="bf16 activations (MI355X throughput policy; not a reference flag)")
     p.add_argument("--model_dir", type=str, default="models")
     p.add_argument("--log_dir", type=str, default="logs")
     p.add_argument("--run_name", type=str, default=None)

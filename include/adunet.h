@@ -10,7 +10,8 @@
  * Conventions
  *  - All tensor pointers are DEVICE pointers owned by the caller, NHWC, dense.
  *  - `dtype` selects the activation element type: AD_F32 (parity path) or
- *    AD_BF16 (throughput path; fp32 accumulation, fp32 statistics).
+ *    AD_BF16 (throughput path; fp32 accumulation, fp32 statistics) or AD_F16 (the same kernels on IEEE
+ *    half storage: the reference's mixed_float16 policy).
  *    Parameters, gradients, statistics and reduction outputs are always fp32.
  *  - `stream` is a hipStream_t passed as void*; every call is asynchronous on it.
  *  - No allocation, no synchronisation, no hidden state: scratch memory is passed
@@ -32,6 +33,8 @@ extern "C" {
 
 #define AD_F32 0
 #define AD_BF16 1
+#define AD_F16 2             /* IEEE half storage, fp32 accumulation: the reference's mixed_float16 policy
+                                (Super_resolution/code/train_adaptive_unet.py:471-477); needs loss scaling (ad_loss_scale_*) */
 
 #define AD_OK 0
 #define AD_ERR_ARG (-1)      /* bad shape / unsupported configuration */
@@ -193,6 +196,7 @@ int ad_head_fwd(const void* xh, const float* w, const float* b, const float* inp
 int ad_head_bwd(const void* xh, const float* w, const float* b, const float* inp,
                 const float* target, void* dxh, float* dw, float* db,
                 int n, int64_t pix_per_img, int ch, int loss_kind, float eps, float grad_scale,
+                const float* loss_scale /* NULL, or device float: g is multiplied by loss_scale[0] (ad_loss_scale_*) */,
                 void* ws, size_t ws_bytes, int dtype, void* stream);
 
 /* -------------------------------------------------------------- optimizer -- */
@@ -244,6 +248,7 @@ int ad_seg_head_fwd(const void* xh, const float* w, const float* b, const float*
 int ad_seg_head_bwd(const void* xh, const float* w, const float* target, const float* prob, const float* sums,
                     void* dxh, float* dw, float* db, int n, int64_t pix_per_img, int ch,
                     float bce_weight, float dice_weight, float smooth,
+                    const float* loss_scale /* NULL or device float, as ad_head_bwd */,
                     void* ws, size_t ws_bytes, int dtype, void* stream);
 
 /* Same update with the step-dependent factor alpha = lr*sqrt(1-b2^t)/(1-b1^t) read from DEVICE memory, so that a
@@ -252,6 +257,22 @@ int ad_seg_head_bwd(const void* xh, const float* w, const float* target, const f
 float ad_adam_alpha(float lr, float b1, float b2, int step);
 int ad_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t count, const float* alpha_dev,
                      float b1, float b2, float eps, float gscale, void* stream);
+
+/* Dynamic loss scaling for AD_F16 (Keras LossScaleOptimizer under the reference's mixed_float16 policy,
+ * Super_resolution/code/train_adaptive_unet.py:471-477; Segmenation/code/train_adaptive_unet.py:471-476): the loss
+ * gradient is multiplied by `scale` before the backward pass (ad_head_bwd / ad_seg_head_bwd read it from device memory),
+ * the optimizer divides it out, a step whose gradients contain inf / NaN is skipped and halves the scale, and
+ * `growth_steps` consecutive finite steps double it.  state (device, 8 floats, initialised by the host to
+ * {scale, 1/scale, 0, 0, 0, 0, 0, 0}): [0] scale, [1] 1/scale, [2] finite steps since the last change, [3] overflow
+ * flag of the current step, [4] optimizer applications so far, [5] skipped steps so far.  One step is
+ *   backward -> ad_loss_scale_check(G) -> ad_adam_step_scaled -> ad_loss_scale_update
+ * with no host round trip, so the whole sequence can sit in a hipGraph. */
+int ad_loss_scale_check(const float* grads, int64_t count, float* state, void* stream);
+int ad_loss_scale_update(float* state, int growth_steps, void* stream);
+/* Keras-form Adam as ad_adam_step_dev, but: nothing happens when state[3] != 0; gradients are multiplied by
+ * gscale * state[1]; the bias-correction step index is state[4] + 1 (applied updates); lr_dev[0] = learning rate. */
+int ad_adam_step_scaled(float* p, const float* g, float* m, float* v, int64_t count, const float* lr_dev,
+                        float b1, float b2, float eps, float gscale, const float* state, void* stream);
 
 /* -------------------------------------------------------------- utilities -- */
 

@@ -194,8 +194,9 @@ class SRUNetOracle:
                 x = q(ops.resize_aa_fwd(x, step[2], step[2]))
             elif kind == "upconv":
                 conv = step[1]
-                a = q(ops.relu_fwd(ops.conv2d_same_fwd(x, q(params[conv + "/kernel"]), params[conv + "/bias"])))
-                tape.append(("ca", conv, x, a))
+                zpre = ops.conv2d_same_fwd(x, q(params[conv + "/kernel"]), params[conv + "/bias"])
+                a = q(ops.relu_fwd(zpre))
+                tape.append(("ca", conv, x, a, zpre))
                 x = a
             elif kind == "concat":
                 skip = skips[step[1]]
@@ -211,7 +212,10 @@ class SRUNetOracle:
         self._storage = st
         return x
 
-    def backward(self, params, dout):
+    def backward(self, params, dout, kink: float = 0.0):
+        """kink: shifts every ReLU / clip decision by that amount (0 = the reference's masks).  Where a pre-activation
+        sits within float32 rounding of a kink, a float32 implementation may land on either side and both one-sided
+        derivatives are valid; backward(+d) and backward(-d) bracket what such flips can do to each gradient."""
         q = self._storage.q
         grads = {}
         dskips = [None] * self._nskips
@@ -220,7 +224,7 @@ class SRUNetOracle:
             kind = rec[0]
             if kind == "head":
                 _, xh, pre = rec
-                dr = ops.clip_add_bwd(d, pre)
+                dr = ops.clip_add_bwd(d, pre) if kink == 0.0 else d * ((pre >= kink) & (pre <= 1.0 - kink))
                 d, dw, db = ops.conv2d_same_bwd(xh, params["residual_rgb/kernel"], dr)
                 d = q(d)
                 grads["residual_rgb/kernel"], grads["residual_rgb/bias"] = dw, db
@@ -228,7 +232,7 @@ class SRUNetOracle:
                 _, conv, ln, xin, (zs, mu, rstd), a = rec
                 # LayerNorm + ReLU backward from what was saved: stored z, mean, rstd (the ReLU mask is re-derived)
                 xhat = (zs - mu) * rstd
-                dy = d * (xhat * params[ln + "/gamma"] + params[ln + "/beta"] > 0)
+                dy = d * (xhat * params[ln + "/gamma"] + params[ln + "/beta"] > kink)
                 dz, dg, dbeta = ops.layernorm_bwd(dy, params[ln + "/gamma"], (xhat, rstd))
                 dz = q(dz)
                 grads[ln + "/gamma"], grads[ln + "/beta"] = dg, dbeta
@@ -237,8 +241,8 @@ class SRUNetOracle:
                 d = q(d) if need_dx else None
                 grads[conv + "/kernel"], grads[conv + "/bias"] = dw, db
             elif kind == "ca":
-                _, conv, xin, a = rec
-                dz = ops.relu_bwd(d, a)
+                _, conv, xin, a, zpre = rec
+                dz = ops.relu_bwd(d, a) if kink == 0.0 else d * (zpre > kink)
                 d, dw, db = ops.conv2d_same_bwd(xin, q(params[conv + "/kernel"]), dz)
                 d = q(d)
                 grads[conv + "/kernel"], grads[conv + "/bias"] = dw, db
@@ -264,13 +268,37 @@ class SRUNetOracle:
         else:
             raise ValueError(f"Unknown loss '{loss}'. Expected one of: 'charbonnier', 'l1', 'combined'.")
         grads = self.backward(params, dout)
+        self._dout = dout
         psnr = float(np.mean(ops.psnr_per_image(hr_img, out)))
         return float(val), grads, out, psnr
 
+    def kink_slack(self, params, delta: float = 1e-5):
+        """After loss_and_grads: per-tensor bound on what ReLU / clip decisions within `delta` of their kink can change,
+        max|g(+delta) - g(-delta)| (zero when no pre-activation is that close)."""
+        hi = self.backward(params, self._dout, kink=delta)
+        lo = self.backward(params, self._dout, kink=-delta)
+        return {k: float(np.abs(hi[k] - lo[k]).max()) for k in hi}
+
     def train_step(self, params, opt_state, lr_img, hr_img, lr=1e-4, loss: str = "charbonnier",
-                   storage: "Storage | None" = None):
-        """One Keras train step (forward, loss, backward, Keras-form Adam). Mutates params/state."""
-        val, grads, out, psnr = self.loss_and_grads(params, lr_img, hr_img, loss, storage=storage)
+                   storage: "Storage | None" = None, scaler=None):
+        """One Keras train step (forward, loss, backward, Keras-form Adam). Mutates params/state.
+        scaler: an oracle.loss_scale.DynamicLossScale (the mixed_float16 policy): the loss gradient is multiplied by the
+        scale before the backward pass, a non-finite step is skipped, the update uses the unscaled gradients."""
+        if scaler is not None:
+            out = self.forward(params, lr_img, storage=storage)
+            val = ops.charbonnier_fwd(hr_img, out) if loss == "charbonnier" else ops.l1_fwd(hr_img, out)
+            dout = ops.charbonnier_bwd(hr_img, out) if loss == "charbonnier" else ops.l1_bwd(hr_img, out)
+            # the product forms (1 / count) * scale in float32 and multiplies the loss derivative by it
+            gs = float(np.float32(np.float32(1.0 / dout.size) * np.float32(scaler.scale)))
+            with np.errstate(all="ignore"):
+                scaled = self.backward(params, dout * dout.size * gs)
+            psnr = float(np.mean(ops.psnr_per_image(hr_img, out)))
+            inv = float(np.float32(1.0) / np.float32(scaler.scale))
+            if not scaler.update(scaled):
+                return float(val), psnr
+            grads = {k: v * inv for k, v in scaled.items()}
+        else:
+            val, grads, out, psnr = self.loss_and_grads(params, lr_img, hr_img, loss, storage=storage)
         opt_state["step"] = opt_state.get("step", 0) + 1
         for name in params:
             m = opt_state.setdefault("m/" + name, np.zeros_like(params[name]))

@@ -24,7 +24,7 @@ def test_train_then_evaluate(device, tmp_path):
     _pngs(hr, 10)
     argv = ["--scale", "0.5", "--high_res_dir", str(hr), "--patch_size", "32", "--depth_override", "1", "--batch_size", "4",
             "--epochs", "2", "--patches_per_image", "2", "--learning_rate", "1e-3", "--model_dir", str(tmp_path / "models"),
-            "--log_dir", str(tmp_path / "logs"), "--run_name", "t", "--mixed_precision", "--shuffle_buffer", "8"]
+            "--log_dir", str(tmp_path / "logs"), "--run_name", "t", "--bf16", "--shuffle_buffer", "8"]
     history, final = T.train(T.parse_args(argv))
     assert history.epoch == [0, 1] and "val_loss" in history.history
     run = tmp_path / "logs" / "t"
@@ -77,4 +77,6 @@ def test_fp32_checkpoint_is_evaluated_in_fp32(device, tmp_path):
     assert abs(got - want.psnr_mean) < 1e-3
     evaluate_model.main(common + ["--run-name", "mp", "--mixed-precision"])
     cfg = json.loads((tmp_path / "eval" / "mp" / "config.json").read_text())
-    assert cfg["compute_dtype"] == "bfloat16"
+    assert cfg["compute_dtype"] == "float16"
+    evaluate_model.main(common + ["--run-name", "bf", "--dtype", "bfloat16"])
+    assert json.loads((tmp_path / "eval" / "bf" / "config.json").read_text())["compute_dtype"] == "bfloat16"

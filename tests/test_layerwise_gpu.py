@@ -177,7 +177,7 @@ def check_stored_masked(got, want, ok_pixels, what, store_bf16):
     tol = (2.0 ** -8 * np.abs(want) + 3e-5 * scale) if store_bf16 else np.full_like(want, 3e-5 * scale)
     bad = (np.abs(got - want) > tol) & ok_pixels[..., None]
     assert not bad.any(), (what, int(bad.sum()), float((np.abs(got - want) * ok_pixels[..., None]).max() / scale))
-    assert ok_pixels.mean() > 0.99, (what, "too many pixels on a kink", float(ok_pixels.mean()))
+    assert (~ok_pixels).sum() <= max(8, 0.01 * ok_pixels.size), (what, "too many pixels on a kink", int((~ok_pixels).sum()))
 
 
 def build(scale, depth, p, dtype, device):
@@ -225,3 +225,156 @@ def test_audit_is_off_by_default_and_does_not_change_results(device):
     out1, loss1, _, (tape, x, t) = model.forward_loss(lr, hr, keep=True)
     model._backward(tape, x, t, 1.0 / x.numel())
     assert torch.equal(out0, out1) and torch.equal(g0, model.G) and len(model.audit) > 10
+
+
+# ----------------------------------------------------------------------------- segmentation models (tier 2, K3)
+def audit_seg_step(S, model, img, mask, bce_w=0.4, dice_w=0.6):
+    """Same idea for build_adaptive_depth_unet / build_unet (Segmenation/code/train_adaptive_unet.py:325-362,
+    unet_vinillia.py:42-91): BatchNorm statistics and backward, MaxPool, bilinear x2, Conv2DTranspose, sigmoid head."""
+    from adunet_amd import _lib, ops
+    lib = _lib.load()
+    bf16 = model.dtype == torch.bfloat16
+    q = ref.bf16_round if bf16 else (lambda a: a)
+    W = {k: v.astype(np.float64) for k, v in model.get_weights().items()}
+    model.audit = []
+    x, m = model._to_dev(img), model._to_dev_mask(mask)
+    prob, sums, tape = model._forward_seg(x, m, training=True, keep=True)
+    model._backward_seg(tape, m)
+    torch.cuda.synchronize()
+    records, model.audit = model.audit, None
+    G = {k: v.astype(np.float64) for k, v in model.get_grads().items()}
+    n = img.shape[0]
+    bn = model.norm == "bn"
+    seen = set()
+
+    def conv_input(name, x1, x2):
+        cin = model.convs[name].cin
+        a = f64(x1)
+        a = a[..., :cin] if x2 is None else np.concatenate([a, f64(x2)], axis=-1)
+        assert a.shape[-1] == cin
+        return a
+
+    for rec in records:
+        kind, name = rec[0], rec[1]
+        seen.add(kind)
+        if kind == "fwd_cna":
+            _, _, x1, x2, z, a, mean, rstd, training = rec
+            nn = model.convs[name].ln
+            want_z = ref.conv2d_same_fwd(conv_input(name, x1, x2), q(W[name + "/kernel"]), W[name + "/bias"])
+            check_stored(z, want_z, name + " z", bf16)
+            if bn:
+                y, (xhat, rs), mu, var = ref.batchnorm_train_fwd(f64(z), W[nn + "/gamma"], W[nn + "/beta"])
+                check_f32(mean.cpu().numpy(), mu, name + " batch mean", 1e-5, slack=1e-6 * np.abs(f64(z)).max())
+                check_f32(rstd.cpu().numpy(), rs, name + " batch rstd", 1e-4)
+            else:
+                c1, c2 = x1.shape[-1], (x2.shape[-1] if x2 is not None else 0)
+                fused = bf16 and bool(lib.ad_conv3x3_ln_relu_is_fused(n, z.shape[1], z.shape[2], c1, c2, z.shape[3], ops.dt(model.dtype)))
+                y, _ = ref.layernorm_fwd(want_z if fused else f64(z), W[nn + "/gamma"], W[nn + "/beta"])
+            check_stored(a, ref.relu_fwd(y), name + " act", bf16)
+        elif kind == "fwd_pool":
+            assert np.array_equal(f64(rec[3]), ref.maxpool2_fwd(f64(rec[2]))), name
+        elif kind == "fwd_up2":
+            check_stored(rec[3], ref.upsample2_bilinear_fwd(f64(rec[2])), name + " bilinear x2", bf16)
+        elif kind == "fwd_convT":
+            want = ref.conv_transpose2x2s2_fwd(f64(rec[2]), q(W[name + "/kernel"]), W[name + "/bias"])
+            check_stored(rec[3], want, name + " fwd", bf16)
+        elif kind == "fwd_head":
+            _, _, xh, msk, p, sm = rec
+            logit = ref.conv2d_same_fwd(f64(xh), W[name + "/kernel"], W[name + "/bias"])
+            check_f32(f64(p), ref.sigmoid(logit), "probabilities", 1e-5)
+            loss, dice, iou = model._metrics_from(sm, float(msk.numel()))
+            want_loss, _ = ref.seg_loss_fwd_bwd(f64(msk), ref.sigmoid(logit), bce_w, dice_w)
+            assert abs(float(loss) - want_loss) < 1e-4 * want_loss
+            assert abs(float(dice) - ref.dice_coefficient(f64(msk), ref.sigmoid(logit))) < 1e-5
+            assert abs(float(iou) - ref.iou_score(f64(msk), ref.sigmoid(logit))) < 1e-5
+        elif kind == "bwd_head":
+            _, _, xh, msk, p, d = rec
+            pp = f64(p)                                             # the product's own probabilities
+            _, dp = ref.seg_loss_fwd_bwd(f64(msk), pp, bce_w, dice_w)
+            dxh, dw, db = ref.conv2d_same_bwd(f64(xh), W[name + "/kernel"], dp * pp * (1 - pp))
+            check_stored(d, dxh, "d head activations", bf16)
+            check_f32(G[name + "/kernel"], dw, name + "/kernel grad")
+            check_f32(G[name + "/bias"], db, name + "/bias grad")
+        elif kind == "bwd_cna":
+            _, _, x1, x2, z, mean, rstd, d_in, dz, d, dsk = rec
+            nn = model.convs[name].ln
+            gam, bet = W[nn + "/gamma"], W[nn + "/beta"]
+            zs = f64(z)
+            shp = (1, 1, 1, -1) if bn else zs.shape[:-1] + (1,)
+            mu = mean.cpu().numpy().astype(np.float64).reshape(shp)
+            rs = rstd.cpu().numpy().astype(np.float64).reshape(shp)
+            xhat = (zs - mu) * rs
+            y = xhat * gam + bet
+            din = f64(d_in)
+            bwd = ref.batchnorm_train_bwd if bn else ref.layernorm_bwd
+            cache = (xhat, rs.reshape(-1) if bn else rs)
+            res = [bwd(din * (y > thr), gam, cache) for thr in (0.0, KINK, -KINK)]
+            kink = np.abs(y) <= KINK
+            if bn:       # a flipped element moves its whole channel's batch sums: allow the bracket on the affected channels
+                slack_dz = np.abs(res[1][0] - res[2][0]).max(axis=(0, 1, 2), keepdims=True) * 2
+                ok = ~kink
+                got, want = f64(dz), res[0][0]
+                scale = np.abs(want).max() + 1e-30
+                tol = (2.0 ** -8 * np.abs(want) + 3e-5 * scale if bf16 else 3e-5 * scale) + slack_dz
+                assert not ((np.abs(got - want) > tol) & ok).any(), name + " dz"
+            else:
+                check_stored_masked(f64(dz), res[0][0], ~kink.any(axis=-1), name + " dz", bf16)
+            for j, pname in ((1, nn + "/gamma"), (2, nn + "/beta")):
+                check_f32(G[pname], res[0][j], pname + " grad", slack=np.abs(res[1][j] - res[2][j]))
+            dzp = f64(dz)
+            need_dx = d is not None
+            dx, dw, db = ref.conv2d_same_bwd(conv_input(name, x1, x2), q(W[name + "/kernel"]), dzp, need_dx=need_dx)
+            check_f32(G[name + "/kernel"], dw, name + "/kernel grad")
+            # behind BatchNorm sum(dz) is zero in exact arithmetic: allow the fp32 summation error of the terms
+            check_f32(G[name + "/bias"], db, name + "/bias grad", slack=2e-6 * np.abs(dzp).sum(axis=(0, 1, 2)))
+            if need_dx:
+                c1 = d.shape[-1] if dsk is not None else model.convs[name].cin
+                check_stored(d[..., :c1] if dsk is None else d, dx[..., :c1], name + " dgrad", bf16)
+                if dsk is not None:
+                    check_stored(dsk, dx[..., c1:], name + " dgrad (skip half)", bf16)
+        elif kind == "bwd_up2":
+            _, _, d_in, d = rec
+            check_stored(d, ref.resize_aa_bwd(f64(d_in), d.shape[1], d.shape[2]), "bilinear x2 bwd", bf16)
+        elif kind == "bwd_convT":
+            _, _, xin, d_in, d = rec
+            dx, dw, db = ref.conv_transpose2x2s2_bwd(f64(xin), q(W[name + "/kernel"]), f64(d_in))
+            check_stored(d, dx, name + " dgrad", bf16)
+            check_f32(G[name + "/kernel"], dw, name + "/kernel grad")
+            check_f32(G[name + "/bias"], db, name + "/bias grad")
+        elif kind == "bwd_pool":
+            _, _, xin, d_in, skip_grad, d = rec
+            check_stored(d, ref.maxpool2_bwd(f64(d_in), f64(xin)) + f64(skip_grad), name + " bwd", bf16)
+    want_kinds = {"fwd_cna", "fwd_pool", "fwd_head", "bwd_head", "bwd_cna", "bwd_pool"} | (
+        {"fwd_up2", "bwd_up2"} if model.up == "bilinear" else {"fwd_convT", "bwd_convT"})
+    assert seen == want_kinds, seen ^ want_kinds
+
+
+SEG_CONFIGS = [
+    # name, builder kind, input size, depth, batch
+    ("bn-small", "bn", 32, 2, 3),
+    ("ln-convT-small", "ln", 32, 2, 3),
+    ("K3", "bn", 256, 5, 2),          # BASELINE config 3 as the reference expresses it: build_adaptive_depth_unet(256, 64, 5)
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("cfg", SEG_CONFIGS, ids=[c[0] for c in SEG_CONFIGS])
+def test_every_step_of_the_segmentation_models_against_the_oracle(device, cfg, dtype):
+    from adunet_amd import seg_model as S
+    _, kind, p, depth, batch = cfg
+    model = (S.build_adaptive_depth_unet(p, 64, depth, dtype=dtype, device=device, seed=5) if kind == "bn"
+             else S.build_unet(p, 1, 64, depth, dtype=dtype, device=device, seed=5))
+    proto = S.PROTOCOLS["A"]
+    model.compile(optimizer=S.build_optimizer(proto, steps_per_epoch=10, epochs=2), loss=proto.loss_builder())
+    model._require_device()
+    rng = np.random.default_rng(11)
+    w = model.get_weights()
+    for k in w:                                   # non-trivial gamma / beta / biases so every term of the backward is live
+        if k.endswith("/gamma"):
+            w[k] = rng.uniform(0.8, 1.2, w[k].shape).astype(np.float32)
+        elif k.endswith("/beta") or k.endswith("/bias"):
+            w[k] = rng.uniform(-0.1, 0.1, w[k].shape).astype(np.float32)
+    model.set_weights(w)
+    img = rng.random((batch, p, p, 3), dtype=np.float32)
+    mask = (rng.random((batch, p, p, 1)) < 0.35).astype(np.float32)
+    audit_seg_step(S, model, img, mask)
