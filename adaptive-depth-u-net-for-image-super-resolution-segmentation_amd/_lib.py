@@ -24,6 +24,7 @@ SIGNATURES = {
     "ad_cin_granule": (_i, [_i]),
     "ad_pad_channels": (_i, [_vp, _vp, _i64, _i, _i, _i, _vp]),
     "ad_conv3x3_pack": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp]),
+    "ad_conv3x3_pack_elems": (_sz, [_i, _i, _i]),
     "ad_conv3x3_pack_job_bytes": (_sz, []),
     "ad_conv3x3_pack_quantum": (_i, []),
     "ad_conv3x3_pack_batch": (_i, [_vp, _i, _i, _i, _vp]),

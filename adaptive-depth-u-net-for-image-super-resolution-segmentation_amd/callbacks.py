@@ -71,3 +71,36 @@ class CSVLogger(Callback):
             fh.write(",".join(keys) + "\n")
             for r in self.rows:
                 fh.write(",".join(str(r.get(k, "")) for k in keys) + "\n")
+
+
+class BackupAndRestore(Callback):
+    """tf.keras.callbacks.BackupAndRestore(backup_dir) (train_adaptive_unet.py:615): after every epoch the whole training
+    state (weights, non-trainable statistics, Adam moments, iteration count, loss scaler, epoch index) goes to
+    `backup_dir`; a later fit() with the same directory continues after the last finished epoch; the backup is deleted
+    when training ends normally.  The dataset position is not part of the state (as in Keras)."""
+
+    def __init__(self, backup_dir):
+        self.dir = Path(backup_dir)
+        self.file = self.dir / "backup.safetensors"
+        self.meta = self.dir / "backup.json"
+
+    def restore(self, model) -> int:
+        """Called by fit() before the first epoch; returns the epoch to start from (0 without a backup)."""
+        import json
+        if not (self.file.exists() and self.meta.exists()):
+            return 0
+        model.load_weights(self.file, restore_optimizer=True)
+        return int(json.loads(self.meta.read_text())["epochs_done"])
+
+    def on_epoch_end(self, epoch, logs):
+        import json
+        self.dir.mkdir(parents=True, exist_ok=True)
+        tmp = self.dir / "backup.tmp.safetensors"
+        self.model.save_weights(tmp, include_optimizer=True)
+        tmp.replace(self.file)                                   # atomic: a crash mid-write keeps the previous backup
+        self.meta.write_text(json.dumps({"epochs_done": epoch + 1}))
+
+    def on_train_end(self, logs):
+        for f in (self.file, self.meta):
+            if f.exists():
+                f.unlink()

@@ -284,7 +284,8 @@ struct ConvArgs {
     const char* x1; const char* x2; int c1, c2;
     const char* wp; const float* bias;
     char* y1; char* y2; int cy1;
-    int n, h, w, cout, epilogue;
+    int n, h, w, cout, epilogue;   // cout: output channels rounded up to whole 64-channel blocks (weight pack / block maths)
+    int cout_real;                 // channels that exist in y1 (+ y2); a ragged last block stores only those
     int ntiles;
     int ksplit;                // > 1: the channel chunks of an item are split over ksplit workgroups (tiny maps)
     float* slab;               // split-K partial sums [ksplit][n*h*w][cout] fp32
@@ -358,7 +359,7 @@ __global__ __launch_bounds__(FT, XS <= 6 ? 2 : 1) void conv3x3_fwd_kernel(ConvAr
         const char* src_ = first_ ? a.x1 : a.x2;                                                      \
         const int rb_ = (first_ ? a.c1 : a.c2) * TSZ;                                                 \
         const int ob_ = (first_ ? c0_ : c0_ - a.c1) * TSZ;                                            \
-        if ((FIRST) && a.bias) bq = a.bias[(NB) * BN + (tid & 63)];                                   \
+        if ((FIRST) && a.bias) bq = (NB) * BN + (tid & 63) < a.cout_real ? a.bias[(NB) * BN + (tid & 63)] : 0.f; \
         if constexpr (XS > 0) x0 = load_halo_slot((GT), src_, rb_, ob_, tid + 0 * FT);                                  \
         if constexpr (XS > 1) x1 = load_halo_slot((GT), src_, rb_, ob_, tid + 1 * FT);                                  \
         if constexpr (XS > 2) x2 = load_halo_slot((GT), src_, rb_, ob_, tid + 2 * FT);                                  \
@@ -471,9 +472,8 @@ __global__ __launch_bounds__(FT, XS <= 6 ? 2 : 1) void conv3x3_fwd_kernel(ConvAr
         // of pixel (lane & 15) of every m-tile; the four lane groups of a wave complete 32/64-byte row pieces.
         // No LDS round trip and no barrier: barrier B already fenced the staging buffers.
         {
-            char* yp; int cy, coff;
-            if (nb * BN < a.cy1) { yp = a.y1; cy = a.cy1; coff = nb * BN; }
-            else { yp = a.y2; cy = a.cout - a.cy1; coff = nb * BN - a.cy1; }
+            // the block's four 16-channel n-tiles each go to y1 (channels below cy1) or y2, or nowhere (padding of a
+            // ragged last block): the output split and the channel count need only be multiples of 16
             const float* bl = bias_lds + (cur ? BN : 0);
             float4 bv[4];
 #pragma unroll
@@ -495,9 +495,13 @@ __global__ __launch_bounds__(FT, XS <= 6 ? 2 : 1) void conv3x3_fwd_kernel(ConvAr
                             make_float4(acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]);
                 } else if (nn < a.n && y < a.h && x < a.w) {
                     const size_t gp = ((size_t)nn * a.h + y) * a.w + x;
-                    T* dst = reinterpret_cast<T*>(yp) + gp * cy + coff + (lane >> 4) * 4;
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt) {
+                        const int cg = nb * BN + nt * 16;                       // first channel of this n-tile
+                        if (cg >= a.cout_real) continue;
+                        T* dst = (cg < a.cy1 ? reinterpret_cast<T*>(a.y1) + gp * a.cy1 + cg
+                                             : reinterpret_cast<T*>(a.y2) + gp * (a.cout_real - a.cy1) + (cg - a.cy1)) +
+                                 (lane >> 4) * 4;
                         float v[4] = {acc[mt][nt][0] + bv[nt].x, acc[mt][nt][1] + bv[nt].y, acc[mt][nt][2] + bv[nt].z,
                                       acc[mt][nt][3] + bv[nt].w};
                         if (a.epilogue == AD_EPI_RELU) {
@@ -507,9 +511,9 @@ __global__ __launch_bounds__(FT, XS <= 6 ? 2 : 1) void conv3x3_fwd_kernel(ConvAr
                         if constexpr (sizeof(T) == 2) {
                             typedef typename Half16<T>::v4 h4;
                             h4 pk = {(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
-                            *reinterpret_cast<h4*>(dst + nt * 16) = pk;
+                            *reinterpret_cast<h4*>(dst) = pk;
                         } else {
-                            *reinterpret_cast<float4*>(dst + nt * 16) = make_float4(v[0], v[1], v[2], v[3]);
+                            *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
                         }
                     }
                 }
@@ -531,19 +535,20 @@ __global__ __launch_bounds__(FT, XS <= 6 ? 2 : 1) void conv3x3_fwd_kernel(ConvAr
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_finalize_kernel(const float* __restrict__ slab, const float* __restrict__ bias,
                                                               T* __restrict__ y1, T* __restrict__ y2, int cy1, int64_t npix,
-                                                              int cout, int ksplit, int relu) {
+                                                              int cout, int ksplit, int relu, int cout_real) {
     const int vecs = cout / 4;
     const int64_t total = npix * vecs;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int64_t p = i / vecs;
         const int co = (int)(i - p * vecs) * 4;
+        if (co >= cout_real) continue;             // padding of a ragged last 64-channel block
         float4 s = bias ? *reinterpret_cast<const float4*>(bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
         for (int k = 0; k < ksplit; ++k) {
             const float4 v = *reinterpret_cast<const float4*>(slab + ((size_t)k * npix + p) * cout + co);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
         if (relu) { s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f); }
-        T* dst = co < cy1 ? y1 + p * cy1 + co : y2 + p * (cout - cy1) + (co - cy1);
+        T* dst = co < cy1 ? y1 + p * cy1 + co : y2 + p * (cout_real - cy1) + (co - cy1);
         dst[0] = (T)s.x; dst[1] = (T)s.y; dst[2] = (T)s.z; dst[3] = (T)s.w;
     }
 }
@@ -728,7 +733,7 @@ __device__ __forceinline__ void ws_mma_role(const ConvArgs& a, const char* xb0, 
     }
     char* yp; int cy, coff;
     if (nb * BN < a.cy1) { yp = a.y1; cy = a.cy1; coff = nb * BN; }
-    else { yp = a.y2; cy = a.cout - a.cy1; coff = nb * BN - a.cy1; }
+    else { yp = a.y2; cy = a.cout_real - a.cy1; coff = nb * BN - a.cy1; }
     const auto rsy = wave_uniform_rsrc(yp, npix * cy * TSZ);
     const auto rsa = wave_uniform_rsrc(EPI == 2 ? a.a_out : yp, npix * cy * TSZ);
     const auto rsm = wave_uniform_rsrc(EPI == 2 ? (const void*)a.ln_mean : (const void*)yp, npix * 4);
@@ -1229,6 +1234,8 @@ __global__ __launch_bounds__(256, XS <= 6 ? 2 : 1) void conv3x3_wgrad_kernel(Wgr
 
     uint4 xr[XS];
     uint4 dr[WP::DSLOTS];
+    // 16-byte dz parts of this output block that exist in a row (8 / 16 of them unless the last block is ragged)
+    const int dz_parts = min(BN, a.cout - cob * BN) * TSZ / 16;
 #define WG_ISSUE(GT)                                                                                           \
     do {                                                                                                       \
         load_halo<XS, 256>(xr, (GT), src, row_bytes, off_bytes, tid);                                          \
@@ -1236,8 +1243,9 @@ __global__ __launch_bounds__(256, XS <= 6 ? 2 : 1) void conv3x3_wgrad_kernel(Wgr
             const int s_ = tid + 256 * i;                                                                      \
             const int gp_ = (GT)[dz_hb[i]];                                                                    \
             const int idx_ = gp_ >= 0 ? gp_ : ~gp_;                                                            \
+            const int part_ = s_ % WP::DSLOTS < dz_parts ? s_ % WP::DSLOTS : 0;   /* past the row: re-read part 0 */ \
             dr[i] = *reinterpret_cast<const uint4*>(                                                           \
-                a.dz + ((size_t)idx_ * a.cout + cob * BN) * TSZ + (s_ % WP::DSLOTS) * 16);                     \
+                a.dz + ((size_t)idx_ * a.cout + cob * BN) * TSZ + part_ * 16);                                 \
         }                                                                                                      \
     } while (0)
 
@@ -1256,7 +1264,7 @@ __global__ __launch_bounds__(256, XS <= 6 ? 2 : 1) void conv3x3_wgrad_kernel(Wgr
 #pragma unroll
         for (int i = 0; i < WP::DSLOTS; ++i) {
             const int s = tid + 256 * i;
-            const bool ok = gt_cur[dz_hb[i]] >= 0;
+            const bool ok = gt_cur[dz_hb[i]] >= 0 && s % WP::DSLOTS < dz_parts;
             *reinterpret_cast<uint4*>(dzt + (s / WP::DSLOTS) * WP::DZS + (s % WP::DSLOTS) * 16) =
                 ok ? dr[i] : make_uint4(0, 0, 0, 0);
         }
@@ -1281,7 +1289,7 @@ __global__ __launch_bounds__(256, XS <= 6 ? 2 : 1) void conv3x3_wgrad_kernel(Wgr
                 int ci, co;
                 WP::coords(wave, lane, j, r, &ci, &co);
                 if (direct) {
-                    if (cib * P::CK + ci < a.cin_real)
+                    if (cib * P::CK + ci < a.cin_real && cob * BN + co < a.cout)
                         a.dw[((size_t)tap * a.cin_real + cib * P::CK + ci) * a.cout + cob * BN + co] = acc[tap][j][r];
                 } else {
                     slab[(tap * P::CK + ci) * BN + co] = acc[tap][j][r];
@@ -1765,36 +1773,39 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------ weight packing
-// w_fwd[tap][kc][co][kv] = W[tap][kc*KV+kv][co]; w_dgrad[tap'][kc][ci][kv] = W[8-tap'][ci][kc*KV+kv]
+// w_fwd[tap][kc][co][kv] = W[tap][kc*KV+kv][co]; w_dgrad[tap'][kc][ci][kv] = W[8-tap'][ci][kc*KV+kv].
+// The output-channel dimension of each pack (co of w_fwd, ci of w_dgrad) is padded with zeros to whole 64-channel
+// blocks (ad_conv3x3_pack_elems), so a layer with 32 output channels is one block whose upper half is never stored.
+static __host__ __device__ inline int pad64(int c) { return (c + BN - 1) / BN * BN; }
+
 template <typename T>
-__global__ void pack_kernel(const float* __restrict__ w, int cin, int cout, int cin_pad, T* __restrict__ wf,
-                            T* __restrict__ wd) {
+__device__ __forceinline__ void pack_element(const float* __restrict__ w, int cin, int cout, int cin_pad, T* __restrict__ wf,
+                                             T* __restrict__ wd, int e) {
     constexpr int KV = 16 / (int)sizeof(T);
-    const int total_f = 9 * cin_pad * cout;
-    const int cout_pad = cout;  // dgrad contraction axis (validated multiple of KV by the launcher)
-    const int total_d = wd ? 9 * cout_pad * cin_pad : 0;
-    int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    int stride = gridDim.x * blockDim.x;
-    for (int i = idx; i < total_f; i += stride) {
-        int kv = i % KV;
-        int r = i / KV;
-        int co = r % cout;
-        r /= cout;
-        int kc = r % (cin_pad / KV);
-        int tap = r / (cin_pad / KV);
+    const int cout_p = (cout + BN - 1) / BN * BN, cin_o = (cin_pad + BN - 1) / BN * BN;
+    const int total_f = 9 * cin_pad * cout_p;
+    if (e < total_f) {
+        int kv = e % KV, r = e / KV;
+        int co = r % cout_p; r /= cout_p;
+        int kc = r % (cin_pad / KV), tap = r / (cin_pad / KV);
         int ci = kc * KV + kv;
-        wf[i] = (T)(ci < cin ? w[((size_t)tap * cin + ci) * cout + co] : 0.f);
-    }
-    for (int i = idx; i < total_d; i += stride) {
-        int kv = i % KV;
-        int r = i / KV;
-        int ci = r % cin_pad;
-        r /= cin_pad;
-        int kc = r % (cout_pad / KV);
-        int tap = r / (cout_pad / KV);
+        wf[e] = (T)(ci < cin && co < cout ? w[((size_t)tap * cin + ci) * cout + co] : 0.f);
+    } else {
+        const int i = e - total_f;
+        int kv = i % KV, r = i / KV;
+        int ci = r % cin_o; r /= cin_o;
+        int kc = r % (cout / KV), tap = r / (cout / KV);
         int co = kc * KV + kv;
         wd[i] = (T)(ci < cin ? w[((size_t)(8 - tap) * cin + ci) * cout + co] : 0.f);
     }
+}
+
+template <typename T>
+__global__ void pack_kernel(const float* __restrict__ w, int cin, int cout, int cin_pad, T* __restrict__ wf,
+                            T* __restrict__ wd) {
+    const int total = 9 * cin_pad * pad64(cout) + (wd ? 9 * cout * pad64(cin_pad) : 0);
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x)
+        pack_element<T>(w, cin, cout, cin_pad, wf, wd, e);
 }
 
 // All layers of a model in one launch.  Work is cut into quanta of PACK_Q elements (forward pack followed by dgrad
@@ -1810,31 +1821,10 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const PackJob* __restri
     int jn = 0;
     while (jn + 1 < njobs && jobs[jn + 1].first_block <= (int)blockIdx.x) ++jn;      // block-uniform scan, <= 64 jobs
     const PackJob j = jobs[jn];
-    constexpr int KV = 16 / (int)sizeof(T);
-    const float* __restrict__ w = j.w;
-    T* __restrict__ wf = (T*)j.wf;
-    T* __restrict__ wd = (T*)j.wd;
-    const int cin = j.cin, cout = j.cout, cin_pad = j.cin_pad;
-    const int total_f = 9 * cin_pad * cout;
-    const int total = wd ? 2 * total_f : total_f;
+    const int total = 9 * j.cin_pad * pad64(j.cout) + (j.wd ? 9 * j.cout * pad64(j.cin_pad) : 0);
     const int lo = ((int)blockIdx.x - j.first_block) * PACK_Q;
     const int hi = lo + PACK_Q < total ? lo + PACK_Q : total;
-    for (int e = lo + threadIdx.x; e < hi; e += 256) {
-        if (e < total_f) {
-            int kv = e % KV, r = e / KV;
-            int co = r % cout; r /= cout;
-            int kc = r % (cin_pad / KV), tap = r / (cin_pad / KV);
-            int ci = kc * KV + kv;
-            wf[e] = (T)(ci < cin ? w[((size_t)tap * cin + ci) * cout + co] : 0.f);
-        } else {
-            const int i = e - total_f;
-            int kv = i % KV, r = i / KV;
-            int ci = r % cin_pad; r /= cin_pad;
-            int kc = r % (cout / KV), tap = r / (cout / KV);
-            int co = kc * KV + kv;
-            wd[i] = (T)(ci < cin ? w[((size_t)(8 - tap) * cin + ci) * cout + co] : 0.f);
-        }
-    }
+    for (int e = lo + threadIdx.x; e < hi; e += 256) pack_element<T>(j.w, j.cin, j.cout, j.cin_pad, (T*)j.wf, (T*)j.wd, e);
 }
 
 template <typename K>
@@ -1850,6 +1840,7 @@ static int fwd_ws_kind(int n, int h, int w, int c1, int c2, int cout, bool ln) {
     Geo g;
     pick_geo(n, h, w, &g);
     const bool geo16 = g.lti == 0 && g.lth == 4 && g.ltw == 4 && g.ph && g.pw;
+    if (cout % BN) return 0;                        // a ragged last output block: generic kernel
     const int nblk = cout / BN, nch = (c1 + c2) / PolBF16::CK;
     const long long nitems = (long long)g.tiles_x * g.tiles_y * g.tiles_i * nblk;
     const long long npix = (long long)n * h * w;
@@ -1885,7 +1876,7 @@ template <typename P>
 int launch_fwd_runs(ConvArgs a, void* ws, size_t ws_bytes, hipStream_t s) {
     int chunk = a.n;
     if constexpr (sizeof(typename P::T) == 2)
-        chunk = images_per_launch(a.n, a.h, a.w, a.c1, a.c2, a.cout, a.epilogue == AD_EPI_LN_RELU, false);
+        chunk = images_per_launch(a.n, a.h, a.w, a.c1, a.c2, a.cout_real, a.epilogue == AD_EPI_LN_RELU, false);
     if (chunk >= a.n) return launch_fwd<P>(a, ws, ws_bytes, s);
     constexpr size_t TSZ = sizeof(typename P::T);
     for (int i0 = 0; i0 < a.n; i0 += chunk) {
@@ -1895,8 +1886,8 @@ int launch_fwd_runs(ConvArgs a, void* ws, size_t ws_bytes, hipStream_t s) {
         b.x1 = a.x1 + pix0 * a.c1 * TSZ;
         if (a.x2) b.x2 = a.x2 + pix0 * a.c2 * TSZ;
         b.y1 = a.y1 + pix0 * a.cy1 * TSZ;
-        if (a.y2) b.y2 = a.y2 + pix0 * (a.cout - a.cy1) * TSZ;
-        if (a.a_out) { b.a_out = a.a_out + pix0 * a.cout * TSZ; b.ln_mean = a.ln_mean + pix0; b.ln_rstd = a.ln_rstd + pix0; }
+        if (a.y2) b.y2 = a.y2 + pix0 * (a.cout_real - a.cy1) * TSZ;
+        if (a.a_out) { b.a_out = a.a_out + pix0 * a.cout_real * TSZ; b.ln_mean = a.ln_mean + pix0; b.ln_rstd = a.ln_rstd + pix0; }
         pick_geo(b.n, b.h, b.w, &b.g);
         b.ntiles = b.g.tiles_x * b.g.tiles_y * b.g.tiles_i;
         const int rc = launch_fwd<P>(b, ws, ws_bytes, s);
@@ -1933,7 +1924,8 @@ int launch_fwd(ConvArgs a, void* ws, size_t ws_bytes, hipStream_t s) {
     }
     if constexpr (sizeof(typename P::T) == 2) {
         a.ksplit = 1; a.slab = nullptr;
-        const int kind = fwd_ws_kind(a.n, a.h, a.w, a.c1, a.c2, a.cout, a.epilogue == AD_EPI_LN_RELU);
+        int kind = fwd_ws_kind(a.n, a.h, a.w, a.c1, a.c2, a.cout_real, a.epilogue == AD_EPI_LN_RELU);
+        if (a.cy1 % BN && a.cy1 != a.cout_real) kind = 0;          // a split inside a 64-channel block: generic kernel
 #define AD_WS_LAUNCH(KERN, NAME)                                                                     \
     {                                                                                                \
         if (a.epilogue == AD_EPI_LN_RELU) KERN<P, 2><<<NUM_CU, WR_T, WR_LDS, s>>>(a);                \
@@ -1968,7 +1960,7 @@ int launch_fwd(ConvArgs a, void* ws, size_t ws_bytes, hipStream_t s) {
         const int64_t total = npix * (a.cout / 4);
         const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
         splitk_finalize_kernel<T><<<blocks, 256, 0, s>>>(a.slab, a.bias, (T*)a.y1, (T*)a.y2, a.cy1, npix, a.cout, a.ksplit,
-                                                         a.epilogue == AD_EPI_RELU);
+                                                         a.epilogue == AD_EPI_RELU, a.cout_real);
         AD_LAUNCH_CHECK("splitk_finalize");
     }
     return AD_OK;
@@ -1985,9 +1977,9 @@ static void plan_wgrad(int n, int h, int w, int c1, int c2, int cout, int dtype,
     const int cin = c1 + c2;
     pick_geo(n, h, w, &p->g);
     p->ntiles = p->g.tiles_x * p->g.tiles_y * p->g.tiles_i;
-    p->ncob = cout / BN;
+    p->ncob = (cout + BN - 1) / BN;
     const long long widest = (long long)n * h * w * (c1 > c2 ? (c1 > cout ? c1 : cout) : (c2 > cout ? c2 : cout)) * 2;
-    p->specialised = ad_is_half(dtype) && p->g.lti == 0 && p->g.lth == 4 && p->g.ltw == 4 && cin % 64 == 0 &&
+    p->specialised = ad_is_half(dtype) && p->g.lti == 0 && p->g.lth == 4 && p->g.ltw == 4 && cin % 64 == 0 && cout % BN == 0 &&
                      c1 % 32 == 0 && widest <= WR_MAX_BYTES && p->ntiles >= 4 * NUM_CU / ((cin / 64) * p->ncob);
     p->ck = p->specialised ? 64 : ad_is_half(dtype) ? PolBF16::CK : PolF32::CK;
     p->ncib = cin / p->ck;
@@ -2062,7 +2054,7 @@ extern "C" int ad_conv3x3_pack(const float* w_hwio, int cin, int cout, int cin_p
     AD_REQUIRE(w_fwd != nullptr, "ad_conv3x3_pack: w_fwd is NULL");
     if (w_dgrad) AD_REQUIRE(cout % gran == 0, "ad_conv3x3_pack: dgrad layout needs cout %% %d == 0 (got %d)", gran, cout);
     hipStream_t s = (hipStream_t)stream;
-    int total = 9 * cin_pad * cout;
+    int total = 9 * cin_pad * pad64(cout) + (w_dgrad ? 9 * cout * pad64(cin_pad) : 0);
     int blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     AD_DISPATCH_DTYPE(dtype, T_, pack_kernel<T_><<<blocks, 256, 0, s>>>(w_hwio, cin, cout, cin_pad, (T_*)w_fwd, (T_*)w_dgrad);)
@@ -2071,6 +2063,10 @@ extern "C" int ad_conv3x3_pack(const float* w_hwio, int cin, int cout, int cin_p
 }
 
 extern "C" size_t ad_conv3x3_pack_job_bytes(void) { return sizeof(PackJob); }
+
+extern "C" size_t ad_conv3x3_pack_elems(int cin_pad, int cout, int dgrad) {
+    return dgrad ? (size_t)9 * cout * pad64(cin_pad) : (size_t)9 * cin_pad * pad64(cout);
+}
 
 extern "C" int ad_conv3x3_pack_quantum(void) { return PACK_Q; }
 
@@ -2092,15 +2088,15 @@ extern "C" int ad_conv3x3_fwd(const void* x1, int c1, const void* x2, int c2, co
     AD_REQUIRE((long)n * h * w < (1L << 31), "ad_conv3x3_fwd: more than 2^31 pixels");
     AD_REQUIRE(x1 && c1 > 0 && c1 % gran == 0, "ad_conv3x3_fwd: c1=%d must be a positive multiple of %d", c1, gran);
     AD_REQUIRE((x2 == nullptr) == (c2 == 0) && c2 % gran == 0, "ad_conv3x3_fwd: c2=%d / x2 mismatch", c2);
-    AD_REQUIRE(cout > 0 && cout % BN == 0, "ad_conv3x3_fwd: cout=%d must be a multiple of %d", cout, BN);
-    AD_REQUIRE(cy1 > 0 && cy1 <= cout && cy1 % BN == 0 && ((cy1 == cout) == (y2 == nullptr)),
+    AD_REQUIRE(cout > 0 && cout % 16 == 0, "ad_conv3x3_fwd: cout=%d must be a multiple of 16", cout);
+    AD_REQUIRE(cy1 > 0 && cy1 <= cout && cy1 % 16 == 0 && ((cy1 == cout) == (y2 == nullptr)),
                "ad_conv3x3_fwd: bad output split cy1=%d cout=%d", cy1, cout);
     AD_REQUIRE(epilogue == AD_EPI_NONE || epilogue == AD_EPI_RELU, "ad_conv3x3_fwd: bad epilogue %d", epilogue);
     ConvArgs a;
     a.x1 = (const char*)x1; a.x2 = (const char*)x2; a.c1 = c1; a.c2 = c2;
     a.wp = (const char*)w_packed; a.bias = bias;
     a.y1 = (char*)y1; a.y2 = (char*)y2; a.cy1 = cy1;
-    a.n = n; a.h = h; a.w = w; a.cout = cout; a.epilogue = epilogue;
+    a.n = n; a.h = h; a.w = w; a.cout = pad64(cout); a.cout_real = cout; a.epilogue = epilogue;
     a.dbg = g_dbg;
     a.ksplit = 1; a.slab = nullptr;
     a.ln_gamma = a.ln_beta = nullptr; a.ln_eps = 0.f; a.a_out = nullptr; a.ln_mean = a.ln_rstd = nullptr;
@@ -2129,12 +2125,12 @@ extern "C" int ad_conv3x3_ln_relu_fwd(const void* x1, int c1, const void* x2, in
     AD_REQUIRE(n > 0 && h > 0 && w > 0 && (long)n * h * w < (1L << 31), "ad_conv3x3_ln_relu_fwd: bad shape n=%d h=%d w=%d", n, h, w);
     AD_REQUIRE(x1 && c1 > 0 && c1 % gran == 0 && (x2 == nullptr) == (c2 == 0) && c2 % gran == 0,
                "ad_conv3x3_ln_relu_fwd: bad input channels c1=%d c2=%d", c1, c2);
-    AD_REQUIRE(cout > 0 && cout % BN == 0, "ad_conv3x3_ln_relu_fwd: cout=%d must be a multiple of %d", cout, BN);
+    AD_REQUIRE(cout > 0 && cout % 16 == 0, "ad_conv3x3_ln_relu_fwd: cout=%d must be a multiple of 16", cout);
     ConvArgs a;
     a.x1 = (const char*)x1; a.x2 = (const char*)x2; a.c1 = c1; a.c2 = c2;
     a.wp = (const char*)w_packed; a.bias = bias;
     a.y1 = (char*)z; a.y2 = nullptr; a.cy1 = cout;
-    a.n = n; a.h = h; a.w = w; a.cout = cout; a.epilogue = AD_EPI_LN_RELU;
+    a.n = n; a.h = h; a.w = w; a.cout = pad64(cout); a.cout_real = cout; a.epilogue = AD_EPI_LN_RELU;
     a.dbg = g_dbg;
     a.ksplit = 1; a.slab = nullptr;
     a.ln_gamma = gamma; a.ln_beta = beta; a.ln_eps = eps;
@@ -2151,7 +2147,8 @@ extern "C" int ad_conv3x3_ln_relu_fwd(const void* x1, int c1, const void* x2, in
 }
 
 extern "C" size_t ad_conv3x3_fwd_ws_bytes(int n, int h, int w, int cin, int cout, int dtype) {
-    if (n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0 || cout % BN) return 0;
+    if (n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0) return 0;
+    cout = pad64(cout);
     Geo g;
     pick_geo(n, h, w, &g);
     const int nitems = g.tiles_x * g.tiles_y * g.tiles_i * (cout / BN);
@@ -2218,7 +2215,7 @@ extern "C" int ad_conv3x3_c3_wgrad(const float* x, const void* dz, float* dw_hwi
 
 extern "C" size_t ad_conv3x3_wgrad_ws_bytes(int n, int h, int w, int cin, int cout, int dtype) {
     WgradPlan p;
-    if (n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0 || cout % BN) return 0;
+    if (n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0) return 0;
     plan_wgrad(n, h, w, cin, 0, cout, dtype, &p);     // the split of cin does not change the slab size
     size_t need = p.ws_bytes;
     const int chunk = ad_is_half(dtype) ? images_per_launch(n, h, w, cin, 0, cout, false, true) : n;
@@ -2240,7 +2237,7 @@ extern "C" int ad_conv3x3_wgrad(const void* x1, int c1, const void* x2, int c2, 
     AD_REQUIRE((long)n * h * w < (1L << 31), "ad_conv3x3_wgrad: more than 2^31 pixels");
     AD_REQUIRE(x1 && c1 > 0 && c1 % gran == 0, "ad_conv3x3_wgrad: c1=%d must be a positive multiple of %d", c1, gran);
     AD_REQUIRE((x2 == nullptr) == (c2 == 0) && c2 % gran == 0, "ad_conv3x3_wgrad: c2=%d / x2 mismatch", c2);
-    AD_REQUIRE(cout > 0 && cout % BN == 0, "ad_conv3x3_wgrad: cout=%d must be a multiple of %d", cout, BN);
+    AD_REQUIRE(cout > 0 && cout % 16 == 0, "ad_conv3x3_wgrad: cout=%d must be a multiple of 16", cout);
     const int cin = c1 + c2;
     AD_REQUIRE(cin_real > 0 && cin_real <= cin, "ad_conv3x3_wgrad: cin_real=%d", cin_real);
     // batches whose tensors reach 2 GiB: runs of `chunk` images, the first run writes dw, the others add to it

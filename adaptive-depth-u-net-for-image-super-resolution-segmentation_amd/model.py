@@ -380,20 +380,70 @@ class Model:
         host = self.G.cpu().numpy()
         return OrderedDict((n, host[o:o + int(np.prod(s))].reshape(s).copy()) for n, (o, s) in self.index.items())
 
-    def save_weights(self, path: str):
-        from safetensors.numpy import save_file
-        save_file({k: np.ascontiguousarray(v) for k, v in self.get_weights().items()}, str(path),
-                  metadata={"model": self.name, "format": "adunet_amd-flat-v1",
-                            "compute_dtype": str(self.dtype).replace("torch.", "")})
+    # ---- checkpoints.  A Keras `.keras` archive holds the weights AND the optimizer variables (ModelCheckpoint at
+    # train_adaptive_unet.py:613-618 saves whole models); `model.load_weights` (:511) reads the weights only, Keras'
+    # BackupAndRestore (:615) brings back everything.  Same split here: one .safetensors file, weights under their Keras
+    # names, training state under `optimizer/...`.
+    def get_training_state(self) -> Dict[str, np.ndarray]:
+        """Adam moments (per parameter, Keras variable order), iteration count and the loss scaler, as host arrays."""
+        self._require_device()
+        out: Dict[str, np.ndarray] = {}
+        m, v = self.M.cpu().numpy(), self.V.cpu().numpy()
+        for n, (o, shp) in self.index.items():
+            k = int(np.prod(shp))
+            out["optimizer/m/" + n] = m[o:o + k].reshape(shp).copy()
+            out["optimizer/v/" + n] = v[o:o + k].reshape(shp).copy()
+        opt = self.optimizer
+        if opt is not None:
+            out["optimizer/iterations"] = np.array([int(opt.iterations)], np.int64)
+            if isinstance(opt, LossScaleOptimizer):
+                opt.ensure(self.device)
+                out["optimizer/loss_scale_state"] = opt.state.cpu().numpy().copy()
+                out["optimizer/loss_scale_calls"] = np.array([opt.calls], np.int64)
+        return out
 
-    def load_weights(self, path: str):
+    def set_training_state(self, state: Dict[str, np.ndarray]):
+        self._require_device()
+        m, v = np.zeros(self._nparams, np.float32), np.zeros(self._nparams, np.float32)
+        for n, (o, shp) in self.index.items():
+            k = int(np.prod(shp))
+            m[o:o + k] = np.asarray(state["optimizer/m/" + n], np.float32).reshape(-1)
+            v[o:o + k] = np.asarray(state["optimizer/v/" + n], np.float32).reshape(-1)
+        self.M.copy_(torch.from_numpy(m))
+        self.V.copy_(torch.from_numpy(v))
+        opt = self.optimizer
+        if opt is not None and "optimizer/iterations" in state:
+            if isinstance(opt, LossScaleOptimizer) and "optimizer/loss_scale_state" in state:
+                opt.ensure(self.device)
+                opt.state.copy_(torch.from_numpy(np.asarray(state["optimizer/loss_scale_state"], np.float32)))
+                opt.calls = int(state["optimizer/loss_scale_calls"][0])
+                opt.inner_optimizer.iterations = int(state["optimizer/iterations"][0])
+            else:
+                opt.iterations = int(state["optimizer/iterations"][0])
+
+    def save_weights(self, path: str, include_optimizer: bool = True):
+        from safetensors.numpy import save_file
+        tensors = {k: np.ascontiguousarray(v) for k, v in self.get_weights().items()}
+        if include_optimizer and self.optimizer is not None:
+            tensors.update({k: np.ascontiguousarray(v) for k, v in self.get_training_state().items()})
+        save_file(tensors, str(path), metadata={"model": self.name, "format": "adunet_amd-flat-v2",
+                                                "compute_dtype": str(self.dtype).replace("torch.", "")})
+
+    def load_weights(self, path: str, restore_optimizer: bool = False):
+        """Weights by Keras variable name (as `model.load_weights`).  restore_optimizer: also the Adam moments, iteration
+        count and loss scaler when the file has them, so that training continues its trajectory bit for bit."""
         path = str(path)
         if path.endswith(".safetensors"):
             from safetensors.numpy import load_file
-            self.set_weights(load_file(path))
+            blob = load_file(path)
+            self.set_weights({k: v for k, v in blob.items() if not k.startswith("optimizer/")})
+            if restore_optimizer and "optimizer/iterations" in blob:
+                self.set_training_state(blob)
         elif path.endswith(".npz"):
             with np.load(path, allow_pickle=False) as z:
-                self.set_weights({k: z[k] for k in z.files})
+                self.set_weights({k: z[k] for k in z.files if not k.startswith("optimizer/")})
+                if restore_optimizer and "optimizer/iterations" in z.files:
+                    self.set_training_state({k: z[k] for k in z.files})
         elif path.endswith(".keras") or path.endswith(".h5"):
             raise RuntimeError("Keras .keras/.h5 archives need h5py, which is not available in this image; "
                                "convert to .safetensors/.npz with the Keras layer names as keys")
@@ -845,6 +895,9 @@ class Model:
                 cb.set_model(self)
             if hasattr(cb, "on_train_begin"):
                 cb.on_train_begin({})
+        for cb in callbacks:                 # BackupAndRestore: an interrupted fit() resumes after its last finished epoch
+            if hasattr(cb, "restore"):
+                initial_epoch = max(initial_epoch, cb.restore(self))
         it = iter(dataset)
         val_it = iter(validation_data) if validation_data is not None and validation_steps else None
         for epoch in range(initial_epoch, epochs):

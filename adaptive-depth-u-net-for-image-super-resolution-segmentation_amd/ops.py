@@ -137,11 +137,12 @@ def conv3x3_pack(w_hwio: torch.Tensor, cin_pad: int, dtype: torch.dtype, want_dg
     in place (the packs keep their addresses, which a captured hipGraph relies on)."""
     kh, kw, cin, cout = w_hwio.shape
     assert (kh, kw) == (3, 3) and w_hwio.dtype == torch.float32
+    lib = _lib.load()
     if out is not None:
         wf, wd = out
-    else:
-        wf = torch.empty(9 * cin_pad * cout, dtype=dtype, device=w_hwio.device)
-        wd = torch.empty(9 * cout * cin_pad, dtype=dtype, device=w_hwio.device) if want_dgrad else None
+    else:      # the packs pad their output-channel dimension to whole 64-channel blocks
+        wf = torch.empty(lib.ad_conv3x3_pack_elems(cin_pad, cout, 0), dtype=dtype, device=w_hwio.device)
+        wd = torch.empty(lib.ad_conv3x3_pack_elems(cin_pad, cout, 1), dtype=dtype, device=w_hwio.device) if want_dgrad else None
     with _timed("conv3x3_pack"):
         check(_lib.load().ad_conv3x3_pack(_p(w_hwio), cin, cout, cin_pad, _p(wf), _p(wd), dt(dtype), _stream()),
               "ad_conv3x3_pack")
@@ -166,12 +167,13 @@ class PackBatch:
         for name, w, cin_pad, want_dgrad in layers:
             kh, kw, cin, cout = w.shape
             assert (kh, kw) == (3, 3) and w.dtype == torch.float32 and w.is_contiguous()
-            wf = torch.empty(9 * cin_pad * cout, dtype=dtype, device=device)
-            wd = torch.empty(9 * cout * cin_pad, dtype=dtype, device=device) if want_dgrad else None
+            nf, nd = lib.ad_conv3x3_pack_elems(cin_pad, cout, 0), (lib.ad_conv3x3_pack_elems(cin_pad, cout, 1) if want_dgrad else 0)
+            wf = torch.empty(nf, dtype=dtype, device=device)
+            wd = torch.empty(nd, dtype=dtype, device=device) if want_dgrad else None
             self.packs[name] = (wf, wd)
             self._keep.append(w)
             rows.append((w.data_ptr(), wf.data_ptr(), wd.data_ptr() if wd is not None else 0, cin, cout, cin_pad, nblocks))
-            nblocks += -(-(9 * cin_pad * cout * (2 if want_dgrad else 1)) // quantum)
+            nblocks += -(-(nf + nd) // quantum)
         self.njobs = len(rows)
         self.nblocks = nblocks
         self.dtype = dtype

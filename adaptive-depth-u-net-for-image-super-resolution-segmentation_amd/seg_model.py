@@ -451,11 +451,13 @@ def build_adaptive_depth_unet(input_size: int = DEFAULT_IMAGE_SIZE, base_channel
 
 def build_unet(input_size: int, num_classes: int = 1, base_channels: int = 32, depth: int = 4, *,
                dtype: torch.dtype = torch.bfloat16, device=None, seed: int = 1234) -> SegModel:
-    """Segmenation/code/unet_vinillia.py:72-91 (name unet_isic_baseline).  The conv kernels work on 64-channel
-    output blocks, so base_channels must be a multiple of 64 here (the reference default 32 is rejected loudly)."""
+    """Segmenation/code/unet_vinillia.py:72-91 (name unet_isic_baseline), reference default base_channels=32.
+    num_classes > 1 (a softmax head) is not built: none of the reference's entry points passes anything but 1
+    (unet_vinillia.py:263, unet_vinillia_optuna.py) and its losses / metrics are binary."""
     if num_classes != 1:
         raise NotImplementedError("softmax heads (num_classes > 1) are not built; the reference only trains binary masks")
-    if base_channels % 64:
-        raise ValueError("base_channels must be a multiple of 64 for the MI355X conv kernels")
+    gran = ops.cin_granule(dtype) if base_channels > 0 else 1
+    if base_channels <= 0 or base_channels % gran:
+        raise ValueError(f"base_channels must be a positive multiple of {gran} for {dtype} (MFMA contraction granule)")
     return SegModel(input_size, base_channels, depth, "ln", "convT", "unet_isic_baseline", "mask_logits",
                     dtype=dtype, device=device, seed=seed)

@@ -15,7 +15,7 @@ from pathlib import Path
 import numpy as np
 
 from . import metrics
-from .callbacks import CSVLogger, EarlyStopping, ModelCheckpoint
+from .callbacks import BackupAndRestore, CSVLogger, EarlyStopping, ModelCheckpoint
 from .evaluate_model import evaluate
 from .model import (DEFAULT_BASE_CHANNELS, DEFAULT_RESIDUAL_HEAD_CHANNELS, Adam, build_losses_and_metrics,
                     build_super_resolution_unet)
@@ -86,8 +86,8 @@ def train(args: argparse.Namespace):
             resume = cands[-1]
         if not resume.exists():
             raise FileNotFoundError(f"Checkpoint not found: {resume}")
-        try:
-            model.load_weights(resume)
+        try:      # weights as in the reference (:511); the optimizer state too when the checkpoint carries it
+            model.load_weights(resume, restore_optimizer=True)
         except Exception as exc:
             raise RuntimeError(f"Failed to load weights from {resume}: {exc}") from exc
 
@@ -108,7 +108,8 @@ def train(args: argparse.Namespace):
 
     monitor = "val_loss" if va else "loss"
     cbs = [EarlyStopping(monitor=monitor, patience=args.patience, restore_best_weights=True),
-           ModelCheckpoint(ckpt, monitor=monitor, save_best_only=True), CSVLogger(run_dir / "epoch_metrics.csv")]
+           ModelCheckpoint(ckpt, monitor=monitor, save_best_only=True), BackupAndRestore(run_dir / "train_backup"),
+           CSVLogger(run_dir / "epoch_metrics.csv")]
     history = model.fit(train_ds, epochs=args.epochs, initial_epoch=args.initial_epoch, steps_per_epoch=steps_per_epoch,
                         validation_data=val_ds, callbacks=cbs, verbose=2)
 

@@ -59,9 +59,13 @@ int ad_cin_granule(int dtype);
 int ad_pad_channels(const float* x, void* y, int64_t npix, int c, int cpad, int dtype, void* stream);
 
 /* Keras HWIO fp32 kernel [3,3,cin,cout] -> MFMA operand layouts (dtype):
- *   w_fwd  : [9][cin_pad/KV][cout][KV]            (KV = 16 B / sizeof(dtype))
- *   w_dgrad: [9 (taps rotated 180)][cout_pad/KV][cin_pad][KV]  (may be NULL)
- * cout must be a multiple of 64 for w_dgrad (it becomes the contraction axis). */
+ *   w_fwd  : [9][cin_pad/KV][pad64(cout)][KV]            (KV = 16 B / sizeof(dtype))
+ *   w_dgrad: [9 (taps rotated 180)][cout/KV][pad64(cin_pad)][KV]  (may be NULL)
+ * The output-channel dimension of each pack is zero-padded to whole 64-channel blocks (the kernels' block size), so
+ * layers with 16 / 32 / 96 ... output channels work (Segmenation/code/unet_vinillia.py:72 defaults to base_channels=32);
+ * ad_conv3x3_pack_elems() gives the element count of either pack.  cout must be a multiple of the dtype's channel
+ * granule for w_dgrad (it becomes the contraction axis). */
+size_t ad_conv3x3_pack_elems(int cin_pad, int cout, int dgrad);
 int ad_conv3x3_pack(const float* w_hwio, int cin, int cout, int cin_pad,
                     void* w_fwd, void* w_dgrad, int dtype, void* stream);
 
@@ -83,8 +87,8 @@ int ad_conv3x3_pack_batch(const void* jobs_dev, int njobs, int nblocks, int dtyp
  * channels (L.Concatenate, :261); pass x2 = NULL, c2 = 0 for a single input.
  * Output channels [0,cy1) go to y1[n,h,w,cy1], the rest to y2[n,h,w,cout-cy1]
  * (used when the same kernel runs as dgrad of a concatenated input); pass
- * y2 = NULL, cy1 = cout normally.  cout % 64 == 0, c1 % granule == 0, c2 % granule == 0,
- * cy1 % 64 == 0.
+ * y2 = NULL, cy1 = cout normally.  cout % 16 == 0 (a ragged last 64-channel block computes the padding and does not
+ * store it), c1 % granule == 0, c2 % granule == 0, cy1 % 16 == 0.
  * Launches with very few spatial tiles (the 4x4 / 1x1 bottleneck maps) split the channel contraction over
  * several workgroups and sum fp32 partial slabs in a fixed order; that path needs ad_conv3x3_fwd_ws_bytes()
  * of workspace (0 for all other shapes; with ws = NULL the unsplit kernel is used). */

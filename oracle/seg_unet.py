@@ -140,8 +140,21 @@ class SegUNetOracle:
 
     def loss_and_grads(self, params, state, img, mask, bce_weight, dice_weight, storage=None):
         p = self.forward(params, state, img, training=True, storage=storage)
-        q = self._storage.q
         loss, dp = ops.seg_loss_fwd_bwd(mask, p, bce_weight, dice_weight)
+        self._dp = dp
+        grads = self.backward(params, dp)
+        dice = ops.dice_coefficient(mask, p)
+        iou = ops.iou_score(mask, p)
+        return float(loss), grads, p, float(dice), float(iou)
+
+    def kink_slack(self, params, delta: float = 1e-5):
+        """After loss_and_grads: per-tensor max|g(+delta) - g(-delta)| with every ReLU decision shifted by +-delta (what
+        float32 rounding at a kink can change; see SRUNetOracle.kink_slack)."""
+        hi, lo = self.backward(params, self._dp, kink=delta), self.backward(params, self._dp, kink=-delta)
+        return {k: float(np.abs(hi[k] - lo[k]).max()) for k in hi}
+
+    def backward(self, params, dp, kink: float = 0.0):
+        q = self._storage.q
         grads = {}
         dskips = {}
         d = None
@@ -155,7 +168,7 @@ class SegUNetOracle:
             elif kind == "cna":
                 _, c, nn, xin, (zs, mu, rstd), a = rec
                 xhat = (zs - mu) * rstd               # from what was saved: stored z, mean, rstd (ReLU mask re-derived)
-                dy = d * (xhat * params[nn + "/gamma"] + params[nn + "/beta"] > 0)
+                dy = d * (xhat * params[nn + "/gamma"] + params[nn + "/beta"] > kink)
                 if self.norm == "bn":
                     dz, dg, dbeta = ops.batchnorm_train_bwd(dy, params[nn + "/gamma"], (xhat, rstd))
                 else:
@@ -179,6 +192,4 @@ class SegUNetOracle:
                 grads[t + "/kernel"], grads[t + "/bias"] = dw, db
             elif kind == "pool":
                 d = q(ops.maxpool2_bwd(d, rec[1]) + dskips[rec[2]])
-        dice = ops.dice_coefficient(mask, p)
-        iou = ops.iou_score(mask, p)
-        return float(loss), grads, p, float(dice), float(iou)
+        return grads

@@ -1,0 +1,107 @@
+"""Checkpoint / resume semantics (train_adaptive_unet.py:496-522 --resume_from, :613-618 ModelCheckpoint +
+BackupAndRestore): weights under their Keras names, optimizer state beside them, and a resumed run that continues the
+trajectory BIT FOR BIT."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def synth(rng, n, p):
+    hr = rng.random((n, p, p, 3), dtype=np.float32)
+    lr = np.clip(hr + 0.05 * rng.standard_normal(hr.shape).astype(np.float32), 0, 1).astype(np.float32)
+    return lr, hr
+
+
+def sr_model(device, dtype):
+    from adunet_amd.model import Adam, build_losses_and_metrics, build_super_resolution_unet
+    model, _ = build_super_resolution_unet(0.5, depth_override=2, input_size=32, dtype=dtype, device=device)
+    loss, metrics = build_losses_and_metrics("charbonnier")
+    model.compile(optimizer=Adam(1e-3), loss=loss, metrics=metrics)
+    model._require_device()
+    model.set_weights(model.initial_weights(np.random.default_rng(1), head_uniform=0.05))
+    return model
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_three_steps_save_two_steps_equals_five_steps(device, dtype, tmp_path):
+    rng = np.random.default_rng(8)
+    batches = [synth(rng, 3, 32) for _ in range(5)]
+    ref_model = sr_model(device, dtype)
+    for b in batches:
+        ref_model.train_on_batch(*b)
+    first = sr_model(device, dtype)
+    for b in batches[:3]:
+        first.train_on_batch(*b)
+    path = tmp_path / "ckpt.safetensors"
+    first.save_weights(path)
+    resumed = sr_model(device, dtype)
+    resumed.load_weights(path, restore_optimizer=True)
+    assert int(resumed.optimizer.iterations) == 3
+    for b in batches[3:]:
+        resumed.train_on_batch(*b)
+    assert torch.equal(resumed.P, ref_model.P) and torch.equal(resumed.M, ref_model.M) and torch.equal(resumed.V, ref_model.V)
+    # weights-only loading (what the reference's --resume_from does) restarts Adam: a different trajectory
+    weights_only = sr_model(device, dtype)
+    weights_only.load_weights(path)
+    assert int(weights_only.optimizer.iterations) == 0 and torch.equal(weights_only.P, first.P)
+    assert float(weights_only.M.abs().max()) == 0.0
+    # the file keeps the Keras variable names for the weights
+    from safetensors.numpy import load_file
+    blob = load_file(str(path))
+    assert "conv2d/kernel" in blob and "optimizer/m/conv2d/kernel" in blob and int(blob["optimizer/iterations"][0]) == 3
+
+
+def test_segmentation_checkpoint_carries_batchnorm_statistics(device, tmp_path):
+    from adunet_amd import seg_model as S
+    rng = np.random.default_rng(2)
+    data = [(rng.random((2, 32, 32, 3), dtype=np.float32), (rng.random((2, 32, 32, 1)) < 0.4).astype(np.float32)) for _ in range(4)]
+    proto = S.PROTOCOLS["A"]
+
+    def make():
+        m = S.build_adaptive_depth_unet(32, 64, 2, dtype=torch.bfloat16, device=device, seed=9)
+        m.compile(optimizer=S.build_optimizer(proto, steps_per_epoch=4, epochs=2), loss=proto.loss_builder())
+        return m
+
+    full = make()
+    for b in data:
+        full.train_on_batch(*b)
+    a = make()
+    for b in data[:2]:
+        a.train_on_batch(*b)
+    a.save_weights(tmp_path / "seg.safetensors")
+    b2 = make()
+    b2.load_weights(tmp_path / "seg.safetensors", restore_optimizer=True)
+    for b in data[2:]:
+        b2.train_on_batch(*b)
+    assert torch.equal(b2.P, full.P) and torch.equal(b2.S, full.S)            # incl. the cosine schedule's step index
+
+
+def test_backup_and_restore_resumes_an_interrupted_fit(device, tmp_path):
+    from adunet_amd.callbacks import BackupAndRestore
+    rng = np.random.default_rng(4)
+    data = [synth(rng, 2, 32) for _ in range(3)]
+
+    class Crash(Exception):
+        pass
+
+    class CrashAfter:
+        def __init__(self, epoch):
+            self.epoch = epoch
+
+        def on_epoch_end(self, epoch, logs):
+            if epoch == self.epoch:
+                raise Crash()
+
+    straight = sr_model(device, torch.bfloat16)
+    straight.fit(data, epochs=4, verbose=0)
+    broken = sr_model(device, torch.bfloat16)
+    with pytest.raises(Crash):
+        broken.fit(data, epochs=4, verbose=0, callbacks=[BackupAndRestore(tmp_path / "bk"), CrashAfter(1)])
+    assert (tmp_path / "bk" / "backup.safetensors").exists()
+    fresh = sr_model(device, torch.bfloat16)                      # a new process: nothing but the backup directory
+    hist = fresh.fit(data, epochs=4, verbose=0, callbacks=[BackupAndRestore(tmp_path / "bk")])
+    assert hist.epoch == [2, 3]
+    assert torch.equal(fresh.P, straight.P)
+    assert not (tmp_path / "bk" / "backup.safetensors").exists()   # removed after a completed fit, as Keras does

@@ -80,3 +80,36 @@ def test_fp32_checkpoint_is_evaluated_in_fp32(device, tmp_path):
     assert cfg["compute_dtype"] == "float16"
     evaluate_model.main(common + ["--run-name", "bf", "--dtype", "bfloat16"])
     assert json.loads((tmp_path / "eval" / "bf" / "config.json").read_text())["compute_dtype"] == "bfloat16"
+
+
+def test_segmentation_train_entry_point(device, tmp_path):
+    """Segmenation/code/train_adaptive_unet.py:463-575 end to end on a synthetic ISIC-shaped folder: protocol B, run
+    artefacts with the reference's config keys, best-val_dice checkpoint, backup removed after a completed fit."""
+    from PIL import Image
+    from adunet_amd import seg_train_adaptive_unet as T
+    rng = np.random.default_rng(0)
+    folders = {}
+    for split, n in (("train", 6), ("val", 3)):
+        for kind in ("img", "mask"):
+            folders[(split, kind)] = tmp_path / f"{split}_{kind}"
+            folders[(split, kind)].mkdir()
+        for i in range(n):
+            m = np.zeros((48, 48), np.uint8)
+            m[8 + i: 30, 10: 28 + i] = 255
+            img = (rng.random((48, 48, 3)) * 80 + m[..., None] * 0.5).astype(np.uint8)      # the lesion is brighter
+            Image.fromarray(img).save(folders[(split, "img")] / f"ISIC_{i:07d}.jpg")
+            Image.fromarray(m).save(folders[(split, "mask")] / f"ISIC_{i:07d}_segmentation.png")
+    argv = ["--protocol", "B", "--epochs", "2", "--batch_size", "3", "--depth", "2", "--image_size", "32", "--bf16",
+            "--train_images", str(folders[("train", "img")]), "--train_masks", str(folders[("train", "mask")]),
+            "--val_images", str(folders[("val", "img")]), "--val_masks", str(folders[("val", "mask")]),
+            "--model_dir", str(tmp_path / "models"), "--log_dir", str(tmp_path / "logs"), "--run_name", "segrun"]
+    history, metrics = T.train(T.parse_args(argv))
+    assert history.epoch == [0, 1] and {"loss", "dice", "iou", "val_dice"} <= set(history.history)
+    cfg = json.loads((tmp_path / "logs" / "segrun" / "config.json").read_text())
+    assert cfg["protocol"] == "B" and cfg["batch_size"] == 3 and cfg["train_samples"] == 6 and cfg["val_samples"] == 3
+    assert cfg["train_steps_per_epoch"] == 2 and cfg["initial_lr"] == 3e-4 and set(cfg["metrics"]) == {"loss", "dice", "iou"}
+    assert cfg["model_name"] == "adaptive_unet_depth2_c64"
+    assert (tmp_path / "models" / "segrun.safetensors").exists() and (tmp_path / "logs" / "segrun" / "model_summary.txt").exists()
+    assert not (tmp_path / "logs" / "segrun" / "train_backup" / "backup.safetensors").exists()
+    with pytest.raises(FileNotFoundError):
+        T.train(T.parse_args(["--protocol", "A"]))

@@ -353,6 +353,7 @@ SEG_CONFIGS = [
     # name, builder kind, input size, depth, batch
     ("bn-small", "bn", 32, 2, 3),
     ("ln-convT-small", "ln", 32, 2, 3),
+    ("ln-convT-c32", "ln32", 64, 3, 2),  # build_unet at the reference's DEFAULT base_channels = 32 (unet_vinillia.py:72)
     ("K3", "bn", 256, 5, 2),          # BASELINE config 3 as the reference expresses it: build_adaptive_depth_unet(256, 64, 5)
 ]
 
@@ -363,7 +364,7 @@ def test_every_step_of_the_segmentation_models_against_the_oracle(device, cfg, d
     from adunet_amd import seg_model as S
     _, kind, p, depth, batch = cfg
     model = (S.build_adaptive_depth_unet(p, 64, depth, dtype=dtype, device=device, seed=5) if kind == "bn"
-             else S.build_unet(p, 1, 64, depth, dtype=dtype, device=device, seed=5))
+             else S.build_unet(p, 1, 32 if kind == "ln32" else 64, depth, dtype=dtype, device=device, seed=5))
     proto = S.PROTOCOLS["A"]
     model.compile(optimizer=S.build_optimizer(proto, steps_per_epoch=10, epochs=2), loss=proto.loss_builder())
     model._require_device()

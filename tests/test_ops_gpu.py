@@ -14,8 +14,8 @@ from oracle import ops as ref
 
 pytestmark = pytest.mark.gpu
 
-F32, BF16 = torch.float32, torch.bfloat16
-TOL = {F32: 1e-3, BF16: 1.5e-2}
+F32, BF16, F16 = torch.float32, torch.bfloat16, torch.float16
+TOL = {F32: 1e-3, BF16: 1.5e-2, F16: 2e-3}     # half: 11 significant bits, 2^-11 per stored element
 
 
 def to_dev(a, dtype, device):
@@ -42,6 +42,11 @@ CONV_SHAPES = [
     (9, 1, 1, 64, 0, 128),      # 1x1 maps: centre tap only
     (2, 20, 20, 64, 64, 64),    # virtual concat
     (1, 3, 5, 32, 0, 64),
+    # output channels that are not whole 64-channel blocks (Segmenation/code/unet_vinillia.py:72: base_channels = 32)
+    (2, 16, 16, 32, 0, 32),
+    (3, 9, 7, 32, 32, 32),
+    (1, 12, 12, 64, 0, 96),     # ragged LAST block after a full one
+    (6, 4, 4, 32, 0, 32),
 ]
 
 
@@ -66,7 +71,8 @@ def test_conv3x3_fwd(device, dtype, shape):
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])
-@pytest.mark.parametrize("shape", [(2, 16, 16, 64, 0, 64), (1, 21, 13, 64, 64, 128), (5, 4, 4, 128, 0, 64), (9, 1, 1, 64, 0, 64)])
+@pytest.mark.parametrize("shape", [(2, 16, 16, 64, 0, 64), (1, 21, 13, 64, 64, 128), (5, 4, 4, 128, 0, 64), (9, 1, 1, 64, 0, 64),
+                                   (2, 16, 16, 32, 0, 32), (1, 11, 9, 32, 0, 64), (2, 8, 8, 96, 0, 32)])
 def test_conv3x3_dgrad(device, dtype, shape):
     """dgrad = the same kernel on the rotated/transposed weight pack, with split outputs."""
     from adunet_amd import ops
@@ -567,3 +573,55 @@ def test_bad_arguments_raise(device):
     with pytest.raises(ValueError):
         ops.layernorm_relu_fwd(torch.zeros((4, 24), dtype=BF16, device=device).reshape(1, 2, 2, 24),
                                torch.ones(24, device=device), torch.zeros(24, device=device))
+
+
+# ----------------------------------------------------------------------------- IEEE half (the reference's mixed_float16)
+@pytest.mark.parametrize("shape", [(2, 16, 16, 32, 0, 64), (1, 37, 29, 64, 0, 64), (5, 4, 4, 64, 64, 64), (9, 1, 1, 64, 0, 128),
+                                   (2, 16, 16, 32, 0, 32)])
+def test_conv3x3_all_passes_fp16(device, ws, shape):
+    """The 16-bit kernels instantiated for half (v_mfma_f32_16x16x32_f16): forward, dgrad, wgrad vs the oracle on
+    half-rounded operands."""
+    from adunet_amd import ops
+    n, h, w, c1, c2, cout = shape
+    cin = c1 + c2
+    rng = np.random.default_rng(12)
+    x = rnd(rng.standard_normal((n, h, w, cin)), F16)
+    wk = rnd(rng.standard_normal((3, 3, cin, cout)) * 0.1, F16)
+    b = rng.standard_normal(cout).astype(np.float32).astype(np.float64)
+    dz = rnd(rng.standard_normal((n, h, w, cout)), F16)
+    x1 = to_dev(x[..., :c1], F16, device)
+    x2 = to_dev(x[..., c1:], F16, device) if c2 else None
+    wf, wd = ops.conv3x3_pack(torch.tensor(wk, dtype=F32, device=device), cin, F16)
+    y = ops.conv3x3_fwd(x1, x2, wf, torch.tensor(b, dtype=F32, device=device), cout)
+    assert y.dtype == F16 and relerr(y, ref.conv2d_same_fwd(x, wk, b)) < TOL[F16]
+    dx, dw_want, _ = ref.conv2d_same_bwd(x, wk, dz)
+    got = ops.conv3x3_fwd(to_dev(dz, F16, device), None, wd, None, cin)
+    assert relerr(got, dx) < TOL[F16]
+    dw = torch.full((3, 3, cin, cout), float("nan"), dtype=F32, device=device)
+    ops.conv3x3_wgrad(x1, x2, to_dev(dz, F16, device), dw, cin, ws)
+    assert relerr(dw, dw_want) < 1e-3
+
+
+def test_wave_specialised_kernels_fp16(device, ws):
+    """Launches large enough for the loader / MFMA wave-specialised kernels (and the fused LayerNorm epilogue) in half:
+    compared with the same launch in fp32 on the same half-rounded operands."""
+    from adunet_amd import ops
+    n, hw, c = 20, 128, 64
+    g = torch.Generator().manual_seed(4)
+    x32 = (torch.rand((n, hw, hw, c), generator=g) * 2 - 1).to(F16).to(F32).to(device)
+    dz32 = (torch.rand((n, hw, hw, c), generator=g) * 2 - 1).to(F16).to(F32).to(device)
+    w = (((torch.rand((3, 3, c, c), generator=g) * 2 - 1) * 0.05).to(F16).to(F32)).to(device)
+    bias = torch.rand(c, generator=g).to(device)
+    gam, bet = (torch.rand(c, generator=g) + 0.5).to(device), (torch.rand(c, generator=g) - 0.5).to(device)
+    out = {}
+    for dt_ in (F32, F16):
+        wf, wd = ops.conv3x3_pack(w, c, dt_)
+        x, dz = x32.to(dt_), dz32.to(dt_)
+        dw = torch.empty_like(w)
+        ops.conv3x3_wgrad(x, None, dz, dw, c, ws)
+        z, a, mean, rstd = ops.conv3x3_ln_relu_fwd(x, None, wf, bias, gam, bet, c)
+        out[dt_] = (ops.conv3x3_fwd(x, None, wf, bias, c, relu=True).float(), ops.conv3x3_fwd(dz, None, wd, None, c).float(),
+                    dw, z.float(), a.float(), mean, rstd)
+    assert ops._lib.load().ad_conv3x3_ln_relu_is_fused(n, hw, hw, c, 0, c, ops.dt(F16))
+    for got, want, tol in zip(out[F16], out[F32], (2e-3, 2e-3, 1e-3, 2e-3, 2e-3, 1e-4, 1e-3)):
+        assert float((got - want).abs().max() / want.abs().max()) < tol

@@ -2,6 +2,8 @@
 /root/reference/shared/pipeline.py (sort order, grid patches, labels, split rules, RNG consumption) and metric
 definitions.  cv2 pixel values for degrade_image are parity unpinned (OpenCV is not installed): only its
 shape / dtype / range / resampling-identity properties are asserted."""
+from pathlib import Path
+
 import numpy as np
 import pytest
 
@@ -112,3 +114,58 @@ def test_ssim_against_a_direct_2d_gaussian_filter():
         c1, c2 = 0.01 ** 2, 0.03 ** 2
         want.append((((2 * mp * mq + c1) * (2 * cov + c2)) / ((mp * mp + mq * mq + c1) * (vp + vq + c2))).mean())
     assert np.allclose(metrics.ssim_per_image(a, b), np.asarray(want), atol=1e-6)
+
+
+# ----------------------------------------------------------------------------- ISIC data path of the segmentation trainer
+def _isic_folder(tmp_path, n=5, size=40, with_mask=True, seed=0):
+    from PIL import Image
+    rng = np.random.default_rng(seed)
+    img_dir, mask_dir = tmp_path / "img", tmp_path / "mask"
+    img_dir.mkdir(exist_ok=True)
+    mask_dir.mkdir(exist_ok=True)
+    for i in range(n):
+        Image.fromarray((rng.random((size, size + 8, 3)) * 255).astype(np.uint8)).save(img_dir / f"ISIC_{i:07d}.jpg")
+        if with_mask:
+            m = np.zeros((size, size + 8), np.uint8)
+            m[size // 4: size // 2 + i, size // 4: size // 2 + 2 * i] = 255
+            Image.fromarray(m).save(mask_dir / f"ISIC_{i:07d}_segmentation.png")
+    Image.fromarray(np.zeros((8, 8, 3), np.uint8)).save(img_dir / "ISIC_0000000_superpixels.png")   # must be ignored
+    return img_dir, mask_dir
+
+
+def test_collect_isic_pairs_contract(tmp_path):
+    """Segmenation/code/train_adaptive_unet.py:70-135: pairing by ISIC id, superpixel files skipped, loud errors."""
+    from adunet_amd import seg_train_adaptive_unet as T
+    img_dir, mask_dir = _isic_folder(tmp_path)
+    pairs = T.collect_isic_pairs(img_dir, mask_dir)
+    assert len(pairs) == 5 and pairs[0][0].endswith("ISIC_0000000.jpg") and pairs[0][1].endswith("ISIC_0000000_segmentation.png")
+    assert T.normalise_isic_key(Path("ISIC_0000123_Segmentation.PNG")) == "isic_0000123"
+    with pytest.raises(FileNotFoundError):
+        T.collect_isic_pairs(tmp_path / "nope", mask_dir)
+    (mask_dir / "ISIC_0000003_segmentation.png").unlink()
+    with pytest.raises(ValueError, match="Missing 1 segmentation masks"):
+        T.collect_isic_pairs(img_dir, mask_dir)
+
+
+def test_isic_loading_and_augmentation(tmp_path):
+    from adunet_amd import seg_train_adaptive_unet as T
+    img_dir, mask_dir = _isic_folder(tmp_path)
+    pairs = T.collect_isic_pairs(img_dir, mask_dir)
+    img, msk = T.load_isic_image(pairs[2][0], 32), T.load_isic_mask(pairs[2][1], 32)
+    assert img.shape == (32, 32, 3) and img.dtype == np.float32 and 0.0 <= img.min() and img.max() <= 1.0
+    assert msk.shape == (32, 32, 1) and set(np.unique(msk)) <= {0.0, 1.0} and msk.sum() > 0
+    assert list(T._nearest_indices(4, 8)) == [0, 0, 1, 1, 2, 2, 3, 3] and list(T._nearest_indices(8, 4)) == [1, 3, 5, 7]
+    assert np.allclose(T._bilinear_matrix(4, 8).sum(axis=1), 1.0)
+    rng = np.random.default_rng(3)
+    a_img, a_msk = T.apply_isic_augmentations(img, msk, 32, rng)
+    assert a_img.shape == (32, 32, 3) and a_msk.shape == (32, 32, 1) and set(np.unique(a_msk)) <= {0.0, 1.0}
+    # the same geometric transform hits image and mask: a mask painted into the image stays aligned
+    marked = np.concatenate([msk, msk, msk], axis=-1)
+    b_img, b_msk = T.apply_isic_augmentations(marked, msk, 32, np.random.default_rng(5))
+    assert np.abs((b_img[..., :1] > 0.5).astype(np.float32) - b_msk).mean() < 0.05
+    ds, count = T.build_isic_dataset(img_dir, mask_dir, batch_size=2, image_size=32, augment=True, shuffle=True, seed=1)
+    batches = list(ds)
+    assert count == 5 and len(ds) == 3 and [b[0].shape[0] for b in batches] == [2, 2, 1]
+    first_pass = np.concatenate([b[1].reshape(b[1].shape[0], -1).sum(axis=1) for b in batches])
+    second_pass = np.concatenate([b[1].reshape(b[1].shape[0], -1).sum(axis=1) for b in ds])
+    assert not np.array_equal(first_pass, second_pass)               # reshuffled / re-augmented every pass

@@ -27,7 +27,7 @@ def main():
     pe = np.abs(prob.cpu().numpy() - pw)
     print("prob max err", pe.max(), "mean err", pe.mean(), "loss", float(model._metrics_from(sums, float(m.numel()))[0]), want_loss)
     got = model.get_grads()
-    rows = sorted(((T.rel(got[k], grads[k]), k) for k in grads), reverse=True)
+    rows = sorted(((T.rel(got[k], grads[k]), k) for k in grads if np.abs(grads[k]).max() > 1e-9), reverse=True)
     for r, k in rows[:14]:
         e = np.abs(got[k].astype(np.float64) - grads[k])
         flat = np.sort(e.reshape(-1))[::-1]
