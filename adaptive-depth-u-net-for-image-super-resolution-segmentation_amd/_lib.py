@@ -62,6 +62,14 @@ SIGNATURES = {
     "ad_seg_head_ws_bytes": (_sz, [_i, _i]),
     "ad_seg_head_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _sz, _i, _vp]),
     "ad_seg_head_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _f, _f, _f, _vp, _vp, _sz, _i, _vp]),
+    "ad_u8_to_float_pad": (_i, [_vp, _vp, _vp, _i64, _vp]),
+    "ad_pad_clip_f32": (_i, [_vp, _vp, _i64, _i, _i, _vp]),
+    "ad_take_channels": (_i, [_vp, _vp, _i64, _i, _i, _vp]),
+    "ad_luma_bt601": (_i, [_vp, _vp, _i64, _vp]),
+    "ad_metrics_ws_bytes": (_sz, [_i, _i, _i]),
+    "ad_mse_per_image": (_i, [_vp, _vp, _i, _i, _i, _i64, _i, _vp, _vp, _sz, _vp]),
+    "ad_ssim_per_image": (_i, [_vp, _vp, _i, _i, _i, _i64, _i, _f, _vp, _vp, _sz, _vp]),
+    "ad_avgpool2_plane": (_i, [_vp, _i, _i, _i, _i64, _i, _vp, _vp]),
     "ad_loss_scale_check": (_i, [_vp, _i64, _vp, _vp]),
     "ad_loss_scale_update": (_i, [_vp, _i, _vp]),
     "ad_adam_step_scaled": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _f, _f, _f, _f, _vp, _vp]),

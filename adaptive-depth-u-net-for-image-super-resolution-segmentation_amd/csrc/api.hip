@@ -71,3 +71,55 @@ extern "C" int ad_pad_channels(const float* x, void* y, int64_t npix, int c, int
     AD_LAUNCH_CHECK("ad_pad_channels");
     return AD_OK;
 }
+
+
+// ---- feed path helpers (pipeline.DeviceDegrader): all fp32, one thread per pixel
+// hr3[p][0..2] = u8[p][0..2] / 255 ; hr4[p] = (r, g, b, 0): the float HR batch and its 16-byte-vector copy for ad_resample
+__global__ void u8_feed_kernel(const unsigned char* __restrict__ x, float* __restrict__ hr3, float* __restrict__ hr4, int64_t npix) {
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (int64_t)gridDim.x * blockDim.x) {
+        const float r = x[p * 3] * (1.0f / 255.0f), g = x[p * 3 + 1] * (1.0f / 255.0f), b = x[p * 3 + 2] * (1.0f / 255.0f);
+        hr3[p * 3] = r; hr3[p * 3 + 1] = g; hr3[p * 3 + 2] = b;
+        reinterpret_cast<float4*>(hr4)[p] = make_float4(r, g, b, 0.f);
+    }
+}
+
+// y[p][0..cpad) = clip(x[p][0..c), 0, 1) then zeros (degrade_image clips the HR patch first, shared/pipeline.py:84)
+__global__ void pad_clip_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t npix, int c, int cpad) {
+    const int64_t total = npix * cpad;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = i / cpad;
+        const int ch = (int)(i - p * cpad);
+        y[i] = ch < c ? fminf(fmaxf(x[p * c + ch], 0.f), 1.f) : 0.f;
+    }
+}
+
+__global__ void take_channels_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t npix, int cin, int cout) {
+    const int64_t total = npix * cout;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = i / cout;
+        y[i] = x[p * cin + (i - p * cout)];
+    }
+}
+
+static int feed_blocks(int64_t work) { return (int)((work + 255) / 256 < 8192 ? (work + 255) / 256 : 8192); }
+
+extern "C" int ad_u8_to_float_pad(const void* x_u8, float* hr3, float* hr4, int64_t npix, void* stream) {
+    AD_REQUIRE(x_u8 && hr3 && hr4 && npix > 0, "ad_u8_to_float_pad: bad arguments");
+    u8_feed_kernel<<<feed_blocks(npix), 256, 0, (hipStream_t)stream>>>((const unsigned char*)x_u8, hr3, hr4, npix);
+    AD_LAUNCH_CHECK("ad_u8_to_float_pad");
+    return AD_OK;
+}
+
+extern "C" int ad_pad_clip_f32(const float* x, float* y, int64_t npix, int c, int cpad, void* stream) {
+    AD_REQUIRE(x && y && npix > 0 && c > 0 && cpad >= c, "ad_pad_clip_f32: bad arguments");
+    pad_clip_kernel<<<feed_blocks(npix * cpad), 256, 0, (hipStream_t)stream>>>(x, y, npix, c, cpad);
+    AD_LAUNCH_CHECK("ad_pad_clip_f32");
+    return AD_OK;
+}
+
+extern "C" int ad_take_channels(const float* x, float* y, int64_t npix, int cin, int cout, void* stream) {
+    AD_REQUIRE(x && y && npix > 0 && cout > 0 && cin >= cout, "ad_take_channels: bad arguments");
+    take_channels_kernel<<<feed_blocks(npix * cout), 256, 0, (hipStream_t)stream>>>(x, y, npix, cin, cout);
+    AD_LAUNCH_CHECK("ad_take_channels");
+    return AD_OK;
+}

@@ -68,22 +68,25 @@ def load_checkpoint_model(model_path: Path, scale: float, patch_size: int, depth
 
 
 def evaluate(model, dataset, eval_shave: int, with_ssim: bool = True) -> Tuple[EvalResults, List[Dict[str, float]]]:
-    """evaluate_model.py:94-163."""
+    """evaluate_model.py:94-163.  The batch stays in HBM: forward, clip + BT.601 luma, shave (a strided window, no copy),
+    per-image MSE / SSIM / MS-SSIM kernels (csrc/metrics.hip); only the per-image scalars come back to the host."""
+    import torch
+    model._require_device()
+    dm = metrics.DeviceMetrics(model.device)
     vals = {"psnr": [], "ssim": [], "msssim": [], "mse": []}
     per_image: List[Dict[str, float]] = []
     offset = 0
     for lr_batch, hr_batch in dataset:
-        pred = np.clip(np.asarray(model(lr_batch, training=False), dtype=np.float32), 0.0, 1.0)
-        pred_y = metrics.rgb_to_luma_bt601(pred)
-        hr_y = metrics.rgb_to_luma_bt601(np.asarray(hr_batch, dtype=np.float32))
-        if eval_shave > 0:
-            pred_y = pred_y[:, eval_shave:-eval_shave, eval_shave:-eval_shave, :]
-            hr_y = hr_y[:, eval_shave:-eval_shave, eval_shave:-eval_shave, :]
-        b_psnr = metrics.psnr_per_image(hr_y, pred_y)
-        b_mse = metrics.mse_per_image(hr_y, pred_y)
-        small = min(hr_y.shape[1:3]) < 11 * 16          # MS-SSIM needs 5 halvings of an 11-pixel window
-        b_ssim = metrics.ssim_per_image(hr_y, pred_y) if with_ssim and min(hr_y.shape[1:3]) >= 11 else np.full_like(b_psnr, np.nan)
-        b_ms = metrics.msssim_per_image(hr_y, pred_y) if with_ssim and not small else np.full_like(b_psnr, np.nan)
+        pred = model(model._to_dev(lr_batch), training=False)                    # [B,P,P,3] fp32 on the device
+        pred_y, hr_y = dm.luma(pred), dm.luma(model._to_dev(hr_batch))           # luma clips its input to [0, 1] first
+        side = min(pred_y.shape[1:3]) - 2 * eval_shave
+        mse, ssim, _ = dm.mse_ssim(hr_y, pred_y, shave=eval_shave, with_ssim=with_ssim)
+        b_mse = mse.cpu().numpy()
+        with np.errstate(divide="ignore"):
+            b_psnr = (-10.0 * np.log10(b_mse)).astype(np.float32)                 # tf.image.psnr(max_val=1): inf at MSE 0
+        b_ssim = ssim.cpu().numpy() if ssim is not None else np.full_like(b_psnr, np.nan)
+        # MS-SSIM needs 5 halvings of an 11-pixel window
+        b_ms = dm.msssim(hr_y, pred_y, shave=eval_shave) if with_ssim and side >= 11 * 16 else np.full_like(b_psnr, np.nan)
         for k, v in (("psnr", b_psnr), ("ssim", b_ssim), ("msssim", b_ms), ("mse", b_mse)):
             vals[k].append(v)
         for i in range(len(b_psnr)):

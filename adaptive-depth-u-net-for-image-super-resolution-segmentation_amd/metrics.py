@@ -1,4 +1,5 @@
-"""Evaluation metrics of the reference's eval loops (host side, NumPy on the model's fp32 outputs).
+"""Evaluation metrics of the reference's eval loops: device kernels (csrc/metrics.hip) for tensors that live in HBM
+(`*_device`, used by evaluate_model.evaluate) and a NumPy restatement with the same definitions for host arrays.
 
 rgb_to_luma_bt601: Super_resolution/code/train_adaptive_unet.py:144-157; shave: evaluate_model.py:49-54;
 PSNR / MSE / SSIM / MS-SSIM on Y: evaluate_model.py:106-126 (tf.image.psnr / ssim / ssim_multiscale).
@@ -84,3 +85,69 @@ def msssim_per_image(a, b, max_val: float = 1.0, weights=MSSSIM_WEIGHTS) -> np.n
             b = b.reshape(n, h // 2, 2, w // 2, 2, c).mean(axis=(2, 4))
     mcs = np.stack(mcs, axis=-1)                                 # [N, C, scales]
     return np.prod(mcs ** np.asarray(weights), axis=-1).mean(axis=-1).astype(np.float32)
+
+
+# ----------------------------------------------------------------------------- device path (csrc/metrics.hip)
+class DeviceMetrics:
+    """Y-channel PSNR / MSE / SSIM / MS-SSIM of a batch that stays in HBM: luma of the clipped prediction and of the
+    target, shave as a strided window (no copy), one launch per metric and scale; returns per-image host arrays."""
+
+    def __init__(self, device):
+        import torch
+        from . import _lib, ops
+        self.torch, self.lib, self.check, self.ops = torch, _lib.load(), _lib.check, ops
+        self.device = device
+        self.ws = ops.Workspace(device, 1 << 20)
+
+    def luma(self, rgb):
+        t = self.torch
+        assert rgb.dtype == t.float32 and rgb.is_contiguous() and rgb.shape[-1] == 3
+        y = t.empty(rgb.shape[:-1], dtype=t.float32, device=rgb.device)
+        self.check(self.lib.ad_luma_bt601(rgb.data_ptr(), y.data_ptr(), y.numel(), t.cuda.current_stream().cuda_stream), "ad_luma_bt601")
+        return y
+
+    def _window(self, plane, shave):
+        n, h, w = plane.shape
+        off = (shave * w + shave) * 4
+        return plane.data_ptr() + off, h - 2 * shave, w - 2 * shave, h * w, w
+
+    def mse_ssim(self, ya, yb, shave: int = 0, with_ssim: bool = True):
+        """(mse[n], ssim[n] or None, cs[n] or None) of two [n, h, w] fp32 planes inside the shaved window."""
+        t = self.torch
+        n = ya.shape[0]
+        pa, h, w, istr, ld = self._window(ya, shave)
+        pb = self._window(yb, shave)[0]
+        self.ws.ensure(self.lib.ad_metrics_ws_bytes(n, h, w))
+        st = t.cuda.current_stream().cuda_stream
+        mse = t.empty(n, dtype=t.float32, device=ya.device)
+        self.check(self.lib.ad_mse_per_image(pa, pb, n, h, w, istr, ld, mse.data_ptr(), self.ws.ptr, self.ws.nbytes, st), "ad_mse_per_image")
+        if not with_ssim or min(h, w) < 11:
+            return mse, None, None
+        sc = t.empty((n, 2), dtype=t.float32, device=ya.device)
+        self.check(self.lib.ad_ssim_per_image(pa, pb, n, h, w, istr, ld, 1.0, sc.data_ptr(), self.ws.ptr, self.ws.nbytes, st), "ad_ssim_per_image")
+        return mse, sc[:, 0], sc[:, 1]
+
+    def msssim(self, ya, yb, shave: int = 0, weights=MSSSIM_WEIGHTS):
+        """tf.image.ssim_multiscale on the shaved window: per-image float32 host array."""
+        t = self.torch
+        n = ya.shape[0]
+        pa, h, w, istr, ld = self._window(ya, shave)
+        pb = self._window(yb, shave)[0]
+        st = t.cuda.current_stream().cuda_stream
+        keep = [ya, yb]
+        mcs = []
+        for i in range(len(weights)):
+            self.ws.ensure(self.lib.ad_metrics_ws_bytes(n, h, w))
+            sc = t.empty((n, 2), dtype=t.float32, device=ya.device)
+            self.check(self.lib.ad_ssim_per_image(pa, pb, n, h, w, istr, ld, 1.0, sc.data_ptr(), self.ws.ptr, self.ws.nbytes, st), "ad_ssim_per_image")
+            mcs.append(sc[:, 0] if i == len(weights) - 1 else sc[:, 1])
+            if i < len(weights) - 1:
+                oh, ow = (h + 1) // 2, (w + 1) // 2
+                na = t.empty((n, oh, ow), dtype=t.float32, device=ya.device)
+                nb = t.empty_like(na)
+                self.check(self.lib.ad_avgpool2_plane(pa, n, h, w, istr, ld, na.data_ptr(), st), "ad_avgpool2_plane")
+                self.check(self.lib.ad_avgpool2_plane(pb, n, h, w, istr, ld, nb.data_ptr(), st), "ad_avgpool2_plane")
+                keep += [na, nb]
+                pa, pb, h, w, istr, ld = na.data_ptr(), nb.data_ptr(), oh, ow, oh * ow, ow
+        host = np.maximum(np.stack([m.cpu().numpy().astype(np.float64) for m in mcs], axis=-1), 0.0)     # [n, scales]
+        return np.prod(host ** np.asarray(weights), axis=-1).astype(np.float32)

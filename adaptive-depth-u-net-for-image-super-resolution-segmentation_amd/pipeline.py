@@ -241,3 +241,158 @@ def split_indices(n_samples: int, train: float, val: float, test: float, seed: i
     if train_count <= 0:
         raise ValueError("Train split is empty; adjust fractions.")
     return indices[:train_count], indices[train_count:train_count + val_count], indices[train_count + val_count:]
+
+
+# ----------------------------------------------------------------------------- MI355X feed path
+# The reference's feed is ONE Python generator that decodes a PNG, crops, and runs two cv2.resize calls per patch
+# (shared/pipeline.py:177-246): a few hundred patches per second at best, against ~4.5 k patches/s that one MI355X
+# consumes on K2' and 36 k/s for a node.  The feed below splits the work where it belongs:
+#   * host: every training image is decoded ONCE into a uint8 cache; worker processes (forked, so the cache is shared
+#     copy-on-write) cut random HR crops straight into shared-memory batch slots -- memcpy-speed work;
+#   * device: the LR input is synthesised from the HR batch in HBM (DeviceDegrader: INTER_AREA shrink then INTER_CUBIC
+#     enlarge as two launches of the separable banded resample kernel), so only HR crops cross PCIe (uint8: 1/8 of the
+#     bytes of two float32 tensors).
+def banded_tables(dense: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """Dense [n_out, n_in] resampling matrix -> (starts[n_out], weights[n_out, K]) of its row bands, the form ad_resample
+    takes (a row's taps are in-range by construction; trailing zeros pad short bands)."""
+    n_out, n_in = dense.shape
+    nz = dense != 0
+    first = nz.argmax(axis=1)
+    last = n_in - 1 - nz[:, ::-1].argmax(axis=1)
+    k = int((last - first).max()) + 1
+    starts = np.minimum(first, n_in - k).astype(np.int32)           # keep start + K inside the row
+    weights = np.zeros((n_out, k), np.float32)
+    for o in range(n_out):
+        weights[o] = dense[o, starts[o]:starts[o] + k]
+    return starts, weights
+
+
+class DeviceDegrader:
+    """degrade_image (shared/pipeline.py:79-94) for a whole HR batch resident in HBM: clip -> area shrink to
+    round(P * scale) -> cubic (a = -0.75) enlarge back to P, not clipped.  Same matrices as the host function, applied
+    by the resample kernel in fp32."""
+
+    def __init__(self, patch_size: int, scale: float, device):
+        from . import ops
+        if not 0 < scale < 1:
+            raise ValueError("Scale must be between 0 and 1 for degradation.")
+        self.ops, self.p = ops, int(patch_size)
+        small = max(1, int(round(self.p * scale)))
+        sa, wa = banded_tables(_area_matrix(self.p, small))
+        sc, wc = banded_tables(_cubic_matrix(small, self.p))
+        self.down = ops.ResampleTables(sa, wa, sa, wa, device)
+        self.up = ops.ResampleTables(sc, wc, sc, wc, device)
+
+    def __call__(self, hr):
+        """hr: [B, P, P, 3] uint8 (0..255) or float32 device tensor -> (lr, hr) float32 [B, P, P, 3] in HBM."""
+        import torch
+        from . import _lib
+        lib, check = _lib.load(), _lib.check
+        st = torch.cuda.current_stream().cuda_stream
+        b, p = hr.shape[0], self.p
+        assert hr.is_cuda and hr.is_contiguous() and tuple(hr.shape[1:]) == (p, p, 3)
+        x4 = torch.empty((b, p, p, 4), dtype=torch.float32, device=hr.device)
+        if hr.dtype == torch.uint8:
+            hr3 = torch.empty((b, p, p, 3), dtype=torch.float32, device=hr.device)
+            check(lib.ad_u8_to_float_pad(hr.data_ptr(), hr3.data_ptr(), x4.data_ptr(), b * p * p, st), "ad_u8_to_float_pad")
+            hr = hr3
+        else:
+            check(lib.ad_pad_clip_f32(hr.data_ptr(), x4.data_ptr(), b * p * p, 3, 4, st), "ad_pad_clip_f32")
+        lr4 = self.ops.resample(self.ops.resample(x4, self.down), self.up)
+        lr = torch.empty((b, p, p, 3), dtype=torch.float32, device=hr.device)
+        check(lib.ad_take_channels(lr4.data_ptr(), lr.data_ptr(), b * p * p, 4, 3, st), "ad_take_channels")
+        return lr, hr
+
+
+def _crop_worker(cache, order_seed, patch_size, batch_size, slots, free_q, full_q, shm_name, stop):
+    """Worker process: fill free batch slots with random HR crops (uint8) until told to stop."""
+    from multiprocessing import shared_memory
+    shm = shared_memory.SharedMemory(name=shm_name)
+    ring = np.ndarray((slots, batch_size, patch_size, patch_size, 3), np.uint8, buffer=shm.buf)
+    rng = np.random.default_rng(order_seed)
+    try:
+        while not stop.is_set():
+            try:
+                slot = free_q.get(timeout=0.2)
+            except Exception:
+                continue
+            for i in range(batch_size):
+                img = cache[int(rng.integers(0, len(cache)))]
+                top = int(rng.integers(0, img.shape[0] - patch_size + 1))
+                left = int(rng.integers(0, img.shape[1] - patch_size + 1))
+                ring[slot, i] = img[top:top + patch_size, left:left + patch_size]
+            full_q.put(slot)
+    finally:
+        shm.close()
+
+
+class PrefetchPatchLoader:
+    """Infinite stream of HR crop batches [B, P, P, 3] uint8 from a decode-once image cache, cut by `workers` forked
+    processes into a shared-memory ring of `slots` batches.  `shard=(rank, world)` gives every data-parallel rank its own
+    random streams (seed + 1000 * rank + worker).  Use with DeviceDegrader:
+
+        loader = PrefetchPatchLoader(files, 256, 64, seed=1234, workers=8)
+        degrade = DeviceDegrader(256, 0.5, device)
+        for hr_u8 in loader:                       # numpy view of a ring slot, valid until the next iteration
+            lr, hr = degrade(torch.from_numpy(hr_u8).to(device, non_blocking=True))
+    """
+
+    def __init__(self, hr_files: Sequence[str], patch_size: int, batch_size: int, seed: int = 1234, workers: int = 4,
+                 slots: int = 8, shard: Tuple[int, int] = (0, 1)):
+        import multiprocessing as mp
+        from multiprocessing import shared_memory
+        hr_files = list(hr_files)
+        if not hr_files:
+            raise ValueError("hr_files must contain at least one path.")
+        if patch_size <= 0 or batch_size <= 0 or workers <= 0 or slots < 2:
+            raise ValueError("patch_size, batch_size and workers must be positive; slots >= 2.")
+        self.cache = []
+        for path in hr_files:                                      # decode once, keep 8-bit
+            from PIL import Image
+            with Image.open(str(path)) as im:
+                arr = np.asarray(im.convert("RGB"), np.uint8)
+            if arr.shape[0] < patch_size or arr.shape[1] < patch_size:
+                raise ValueError("patch_size exceeds image dimensions.")
+            self.cache.append(arr)
+        self.patch_size, self.batch_size, self.slots = patch_size, batch_size, slots
+        nbytes = slots * batch_size * patch_size * patch_size * 3
+        self._shm = shared_memory.SharedMemory(create=True, size=nbytes)
+        self._ring = np.ndarray((slots, batch_size, patch_size, patch_size, 3), np.uint8, buffer=self._shm.buf)
+        ctx = mp.get_context("fork")                               # the image cache is shared copy-on-write
+        self._free, self._full, self._stop = ctx.Queue(), ctx.Queue(), ctx.Event()
+        for s in range(slots):
+            self._free.put(s)
+        rank, world = shard
+        self._procs = [ctx.Process(target=_crop_worker, daemon=True,
+                                   args=(self.cache, seed + 1000 * rank + w, patch_size, batch_size, slots, self._free,
+                                         self._full, self._shm.name, self._stop)) for w in range(workers)]
+        for p in self._procs:
+            p.start()
+        self._held = None
+
+    def __iter__(self):
+        return self
+
+    def __next__(self) -> np.ndarray:
+        if self._held is not None:
+            self._free.put(self._held)                              # the previous batch's slot may be refilled now
+        self._held = self._full.get()
+        return self._ring[self._held]
+
+    def close(self):
+        self._stop.set()
+        for p in self._procs:
+            p.join(timeout=2.0)
+            if p.is_alive():
+                p.terminate()
+        self._procs = []
+        try:
+            self._ring = None
+            self._shm.close()
+            self._shm.unlink()
+        except Exception:
+            pass
+
+    def __del__(self):
+        if getattr(self, "_procs", None):
+            self.close()

@@ -282,6 +282,37 @@ int ad_adam_step_scaled(float* p, const float* g, float* m, float* v, int64_t co
 
 int ad_cast(const void* x, int dtype_in, void* y, int dtype_out, int64_t count, void* stream);
 
+/* ------------------------------------------------------------- feed path -- */
+
+/* LR synthesis on the device (shared/pipeline.py:79-94 degrade_image, applied to a whole HR batch in HBM by two
+ * ad_resample launches with INTER_AREA / INTER_CUBIC tables): layout helpers around the 16-byte channel vectors the
+ * resample kernel works on.  All fp32.
+ *   ad_u8_to_float_pad  x_u8[npix,3] -> hr3[npix,3] = x/255 and hr4[npix,4] = (r,g,b,0)
+ *   ad_pad_clip_f32     y[npix,cpad] = clip(x[npix,c], 0, 1), zero channel padding
+ *   ad_take_channels    y[npix,cout] = x[npix, 0..cout) */
+int ad_u8_to_float_pad(const void* x_u8, float* hr3, float* hr4, int64_t npix, void* stream);
+int ad_pad_clip_f32(const float* x, float* y, int64_t npix, int c, int cpad, void* stream);
+int ad_take_channels(const float* x, float* y, int64_t npix, int cin, int cout, void* stream);
+
+/* ------------------------------------------------------- evaluation metrics -- */
+
+/* The reference's eval loops (Super_resolution/code/train_adaptive_unet.py:673-694, evaluate_model.py:94-163) on the
+ * device.  Planes are single-channel fp32 images addressed as plane[img * image_stride + y * row_stride + x], so a
+ * shaved window of a larger plane needs no copy (pass the window's first pixel, its extent and the parent's strides).
+ *   ad_luma_bt601     y = clip((65.481 r + 128.553 g + 24.966 b + 16) / 255, 0, 1) of clip(rgb, 0, 1)     (:144-157)
+ *   ad_mse_per_image  mse[img] = mean (a - b)^2            (tf.reduce_mean(tf.square(..)), :691; PSNR = -10 log10)
+ *   ad_ssim_per_image ssim_cs[img][0] = tf.image.ssim(a, b, max_val) (11x11 Gaussian sigma 1.5, VALID, K1 .01, K2 .03),
+ *                     ssim_cs[img][1] = the mean contrast-structure term that tf.image.ssim_multiscale multiplies
+ *   ad_avgpool2_plane 2x2 average pooling between MS-SSIM scales; odd extents repeat their last row / column
+ * ws: ad_metrics_ws_bytes(n, h, w). */
+int ad_luma_bt601(const float* rgb, float* y, int64_t npix, void* stream);
+size_t ad_metrics_ws_bytes(int n, int h, int w);
+int ad_mse_per_image(const float* a, const float* b, int n, int h, int w, int64_t image_stride, int row_stride,
+                     float* mse, void* ws, size_t ws_bytes, void* stream);
+int ad_ssim_per_image(const float* a, const float* b, int n, int h, int w, int64_t image_stride, int row_stride,
+                      float max_val, float* ssim_cs, void* ws, size_t ws_bytes, void* stream);
+int ad_avgpool2_plane(const float* x, int n, int h, int w, int64_t image_stride, int row_stride, float* y, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -169,3 +169,37 @@ def test_isic_loading_and_augmentation(tmp_path):
     first_pass = np.concatenate([b[1].reshape(b[1].shape[0], -1).sum(axis=1) for b in batches])
     second_pass = np.concatenate([b[1].reshape(b[1].shape[0], -1).sum(axis=1) for b in ds])
     assert not np.array_equal(first_pass, second_pass)               # reshuffled / re-augmented every pass
+
+
+# ----------------------------------------------------------------------------- MI355X feed path (host half)
+def test_banded_tables_reproduce_the_dense_resampling_matrices():
+    for dense in (pipeline._area_matrix(64, 32), pipeline._area_matrix(50, 13), pipeline._cubic_matrix(32, 64),
+                  pipeline._cubic_matrix(13, 50)):
+        starts, weights = pipeline.banded_tables(dense)
+        back = np.zeros_like(dense)
+        for o in range(dense.shape[0]):
+            back[o, starts[o]:starts[o] + weights.shape[1]] = weights[o]
+        assert np.allclose(back, dense, atol=1e-7) and (starts >= 0).all() and (starts + weights.shape[1] <= dense.shape[1]).all()
+
+
+def test_prefetch_loader_streams_crops_from_the_decoded_cache(tmp_path):
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    files = []
+    for i in range(3):
+        arr = np.full((40, 56, 3), 10 * (i + 1), np.uint8)           # image i is the constant 10 (i + 1)
+        arr[0, 0] = 255
+        Image.fromarray(arr).save(tmp_path / f"im{i}.png")
+        files.append(str(tmp_path / f"im{i}.png"))
+    loader = pipeline.PrefetchPatchLoader(files, patch_size=16, batch_size=5, seed=3, workers=2, slots=4)
+    try:
+        seen = set()
+        for _ in range(12):
+            batch = next(loader)
+            assert batch.shape == (5, 16, 16, 3) and batch.dtype == np.uint8
+            seen |= {int(v) for v in np.unique(batch[:, 8, 8, 0])}
+        assert seen <= {10, 20, 30} and len(seen) == 3              # crops of every image, never torn between images
+    finally:
+        loader.close()
+    with pytest.raises(ValueError):
+        pipeline.PrefetchPatchLoader(files, patch_size=64, batch_size=2)      # patch larger than the images
