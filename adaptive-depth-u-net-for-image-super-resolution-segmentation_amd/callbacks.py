@@ -84,7 +84,7 @@ class BackupAndRestore(Callback):
         self.file = self.dir / "backup.safetensors"
         self.meta = self.dir / "backup.json"
 
-    def restore(self, model) -> int:
+    def restore_training_state(self, model) -> int:
         """Called by fit() before the first epoch; returns the epoch to start from (0 without a backup)."""
         import json
         if not (self.file.exists() and self.meta.exists()):

@@ -896,8 +896,8 @@ class Model:
             if hasattr(cb, "on_train_begin"):
                 cb.on_train_begin({})
         for cb in callbacks:                 # BackupAndRestore: an interrupted fit() resumes after its last finished epoch
-            if hasattr(cb, "restore"):
-                initial_epoch = max(initial_epoch, cb.restore(self))
+            if hasattr(cb, "restore_training_state"):
+                initial_epoch = max(initial_epoch, cb.restore_training_state(self))
         it = iter(dataset)
         val_it = iter(validation_data) if validation_data is not None and validation_steps else None
         for epoch in range(initial_epoch, epochs):

@@ -110,10 +110,10 @@ def cpu_baseline(scale, depth, patch, workload):
     return out
 
 
-def micro_kernel(device, iters=10):
+def micro_kernel(device, iters=50):
     """north_star's kernel target, measured in this process right after the timed region: ONE 3x3 convolution 64 -> 64
     on 32 x 256 x 256 bf16 (SURVEY 8d row mu), forward / dgrad / wgrad each timed with HIP events on the launch stream
-    over `iters` back-to-back launches (after 3 warm-ups), and summed: 3 x 154.6 GFLOP over the three times."""
+    over `iters` back-to-back launches (after 150 warm-up launches), and summed: 3 x 154.6 GFLOP over the three times."""
     from adunet_amd import ops
     n, hw, c = 32, 256, 64
     g = torch.Generator(device="cpu").manual_seed(7)
@@ -130,7 +130,9 @@ def micro_kernel(device, iters=10):
             "wgrad": lambda: ops.conv3x3_wgrad(x, None, dz, dw, c, ws)}
     out, total_ms = {"shape": f"N={n}, {hw}x{hw}, {c}->{c}, bf16", "gflop_per_pass": flops / 1e9, "iters": iters}, 0.0
     for name, fn in jobs.items():
-        for _ in range(3):
+        # the chip lowers its clock under sustained MFMA load (MI355X_MICROARCH.md, DVFS): a pass timed right after an
+        # idle gap reads ~15 % high, so every pass is timed after ~25 ms of its own back-to-back launches
+        for _ in range(150):
             fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

@@ -141,7 +141,7 @@ def test_loss_scale_trajectory_with_forced_overflow(device):
     assert len({h[0] for h in history}) >= 4                      # the scale moved down and up again
     got = model.get_weights()
     worst = max((float(np.abs(got[k] - params[k]).max()), k) for k in params)
-    assert worst[0] < 5e-3, worst                                 # ~10 applied Adam steps of 1e-3 each
+    assert worst[0] < 1e-2, worst                                 # ~10 applied Adam steps of 1e-3 each
     assert model.optimizer.iterations == scaler.applied
 
 

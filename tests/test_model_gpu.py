@@ -92,7 +92,9 @@ def check_step_against_oracle(oracle, params, model, lr, hr, *, f32):
     bound = {k: base * max(1.0, (1024.0 / pixels[k]) ** 0.5) for k in want_grads}
     if f32 and any(errs[k] >= bound[k] for k in errs):
         slack = oracle.kink_slack(params)
-        bound = {k: bound[k] + 2.0 * slack[k] / (np.abs(want_grads[k]).max() + 1e-30) for k in bound}
+        # (x4: the bracket flips every near-kink decision the same way; the product may flip a subset whose effects on
+        #  one tensor do not cancel the way they do in the bracket)
+        bound = {k: bound[k] + 4.0 * slack[k] / (np.abs(want_grads[k]).max() + 1e-30) for k in bound}
     worst = max((errs[k] / bound[k], k, errs[k], bound[k]) for k in errs)
     assert worst[0] < 1.0, worst
     ga = np.concatenate([grads[k].reshape(-1) for k in want_grads]).astype(np.float64)
@@ -157,17 +159,16 @@ def test_k2p_config_against_oracle(device, dtype):
     lr, hr = synth(rng, 2, 256)
     f32 = dtype == torch.float32
     _, want_grads = check_step_against_oracle(oracle, params, model, lr, hr, f32=f32)
-    # ... and the Adam update that follows from those gradients (Keras form, epsilon outside the bias correction)
-    before = model.get_weights()
-    model.train_on_batch(lr, hr)
+    # ... and the Keras-form Adam update (epsilon outside the bias correction) applied to the gradients the model just
+    # produced: p1 = adam(p0, G) restated by the oracle on the product's own G, so only the optimizer kernel is compared
+    before, g = model.get_weights(), model.get_grads()
+    model.train_on_batch(lr, hr)                                   # recomputes the same (deterministic) gradients, then steps
     after = model.get_weights()
-    for name in ("conv2d_9/kernel", "conv2d_1/kernel", "residual_rgb/kernel", "layer_normalization_3/gamma"):
+    for name in ("conv2d_9/kernel", "conv2d_1/kernel", "residual_rgb/kernel", "layer_normalization_3/gamma", "conv2d/bias"):
         p0 = before[name].astype(np.float64)
         m, v = np.zeros_like(p0), np.zeros_like(p0)
-        ref.adam_step(p0, want_grads[name], m, v, 1, lr=1e-3)
-        # first Adam step = -lr * sign(g) up to epsilon: compare where the oracle gradient is well away from zero
-        big = np.abs(want_grads[name]) > 1e-3 * np.abs(want_grads[name]).max()
-        assert np.abs(after[name] - p0)[big].max() < (2e-6 if f32 else 2e-5), name
+        ref.adam_step(p0, g[name].astype(np.float64), m, v, 1, lr=1e-3)
+        assert np.abs(after[name] - p0).max() < 1e-6, name          # |update| = 1e-3: a 1e-3 relative bound
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
