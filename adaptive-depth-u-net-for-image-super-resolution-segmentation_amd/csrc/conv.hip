@@ -1778,34 +1778,48 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // blocks (ad_conv3x3_pack_elems), so a layer with 32 output channels is one block whose upper half is never stored.
 static __host__ __device__ inline int pad64(int c) { return (c + BN - 1) / BN * BN; }
 
+// One thread writes one 16-byte vector (KV elements) of a pack: the forward pack gathers KV input channels of one
+// output channel (consecutive threads = consecutive output channels: coalesced 4-byte reads, coalesced 16-byte
+// writes), the dgrad pack reads KV consecutive output channels (one 32 / 16-byte read).  `e` = first element of the vector.
 template <typename T>
-__device__ __forceinline__ void pack_element(const float* __restrict__ w, int cin, int cout, int cin_pad, T* __restrict__ wf,
-                                             T* __restrict__ wd, int e) {
+__device__ __forceinline__ void pack_vector(const float* __restrict__ w, int cin, int cout, int cin_pad, T* __restrict__ wf,
+                                            T* __restrict__ wd, int e) {
     constexpr int KV = 16 / (int)sizeof(T);
     const int cout_p = (cout + BN - 1) / BN * BN, cin_o = (cin_pad + BN - 1) / BN * BN;
     const int total_f = 9 * cin_pad * cout_p;
+    float f[KV];
     if (e < total_f) {
-        int kv = e % KV, r = e / KV;
-        int co = r % cout_p; r /= cout_p;
-        int kc = r % (cin_pad / KV), tap = r / (cin_pad / KV);
-        int ci = kc * KV + kv;
-        wf[e] = (T)(ci < cin && co < cout ? w[((size_t)tap * cin + ci) * cout + co] : 0.f);
+        int r = e / KV;
+        const int co = r % cout_p; r /= cout_p;
+        const int kc = r % (cin_pad / KV), tap = r / (cin_pad / KV);
+#pragma unroll
+        for (int kv = 0; kv < KV; ++kv) {
+            const int ci = kc * KV + kv;
+            f[kv] = ci < cin && co < cout ? w[((size_t)tap * cin + ci) * cout + co] : 0.f;
+        }
+        Vec16<T> st;
+        st.from_f32(f);
+        st.store(wf + e);
     } else {
         const int i = e - total_f;
-        int kv = i % KV, r = i / KV;
-        int ci = r % cin_o; r /= cin_o;
-        int kc = r % (cout / KV), tap = r / (cout / KV);
-        int co = kc * KV + kv;
-        wd[i] = (T)(ci < cin ? w[((size_t)(8 - tap) * cin + ci) * cout + co] : 0.f);
+        int r = i / KV;
+        const int ci = r % cin_o; r /= cin_o;
+        const int kc = r % (cout / KV), tap = r / (cout / KV);
+#pragma unroll
+        for (int kv = 0; kv < KV; ++kv) f[kv] = ci < cin ? w[((size_t)(8 - tap) * cin + ci) * cout + kc * KV + kv] : 0.f;
+        Vec16<T> st;
+        st.from_f32(f);
+        st.store(wd + i);
     }
 }
 
 template <typename T>
 __global__ void pack_kernel(const float* __restrict__ w, int cin, int cout, int cin_pad, T* __restrict__ wf,
                             T* __restrict__ wd) {
+    constexpr int KV = 16 / (int)sizeof(T);
     const int total = 9 * cin_pad * pad64(cout) + (wd ? 9 * cout * pad64(cin_pad) : 0);
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x)
-        pack_element<T>(w, cin, cout, cin_pad, wf, wd, e);
+    for (int v = blockIdx.x * blockDim.x + threadIdx.x; v * KV < total; v += gridDim.x * blockDim.x)
+        pack_vector<T>(w, cin, cout, cin_pad, wf, wd, v * KV);
 }
 
 // All layers of a model in one launch.  Work is cut into quanta of PACK_Q elements (forward pack followed by dgrad
@@ -1818,13 +1832,14 @@ struct PackJob {
 constexpr int PACK_Q = 16384;
 template <typename T>
 __global__ __launch_bounds__(256) void pack_batch_kernel(const PackJob* __restrict__ jobs, int njobs) {
+    constexpr int KV = 16 / (int)sizeof(T);
     int jn = 0;
     while (jn + 1 < njobs && jobs[jn + 1].first_block <= (int)blockIdx.x) ++jn;      // block-uniform scan, <= 64 jobs
     const PackJob j = jobs[jn];
     const int total = 9 * j.cin_pad * pad64(j.cout) + (j.wd ? 9 * j.cout * pad64(j.cin_pad) : 0);
     const int lo = ((int)blockIdx.x - j.first_block) * PACK_Q;
     const int hi = lo + PACK_Q < total ? lo + PACK_Q : total;
-    for (int e = lo + threadIdx.x; e < hi; e += 256) pack_element<T>(j.w, j.cin, j.cout, j.cin_pad, (T*)j.wf, (T*)j.wd, e);
+    for (int e = lo + threadIdx.x * KV; e < hi; e += 256 * KV) pack_vector<T>(j.w, j.cin, j.cout, j.cin_pad, (T*)j.wf, (T*)j.wd, e);
 }
 
 template <typename K>

@@ -101,59 +101,75 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
             a_g[v][e] = a_b[v][e] = a_z[v][e] = 0.f;
         }
     const float inv_c = 1.0f / (float)c;
-    for (int64_t pix = (int64_t)blockIdx.x * PPB + gp; pix < npix; pix += (int64_t)gridDim.x * PPB) {
-        float xh[NV][EPT], g[NV][EPT];
-        float mu = 0.f, rs = 1.f;
-        if (MODE != 2) {
-            mu = mean[pix];
-            rs = rstd[pix];
+    // U pixels per thread and pass, all their loads issued before the first use: the kernel is a pure stream (read dy
+    // and z, write dz) and with one pixel in flight per thread a CU had only ~32 KB outstanding -- 5.0 TB/s; Little's
+    // law at ~2 us of HBM latency wants ~64 KB per CU.
+    constexpr int U = NV == 1 ? 2 : 1;
+    const int64_t step = (int64_t)gridDim.x * PPB;
+    for (int64_t pix0 = (int64_t)blockIdx.x * PPB + gp; pix0 < npix; pix0 += U * step) {
+        Vec16<T> lz[U][NV], ld[U][NV];
+        float mu_u[U], rs_u[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t pix = pix0 + u * step < npix ? pix0 + u * step : pix0;      // past the end: re-read, never stored
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                lz[u][v].load(z + pix * c + (v * G + gl) * EPT);
+                ld[u][v].load(dy + pix * c + (v * G + gl) * EPT);
+            }
+            mu_u[u] = MODE != 2 ? mean[pix] : 0.f;
+            rs_u[u] = MODE != 2 ? rstd[pix] : 1.f;
         }
-        float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            Vec16<T> l0, l1;
-            float zz[EPT], dd[EPT];
-            l0.load(z + pix * c + (v * G + gl) * EPT);
-            l1.load(dy + pix * c + (v * G + gl) * EPT);
-            l0.to_f32(zz);
-            l1.to_f32(dd);
+        for (int u = 0; u < U; ++u) {
+            const int64_t pix = pix0 + u * step;
+            if (pix >= npix) break;
+            float xh[NV][EPT], g[NV][EPT];
+            const float mu = mu_u[u], rs = rs_u[u];
+            float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-            for (int e = 0; e < EPT; ++e) {
-                if (MODE == 2) {
-                    g[v][e] = zz[e] > 0.f ? dd[e] : 0.f;  // dz directly
-                } else {
-                    float h = (zz[e] - mu) * rs;
-                    float yv = h * gam[v][e] + bet[v][e];
-                    float dl = (MODE == 0 && !(yv > 0.f)) ? 0.f : dd[e];
-                    xh[v][e] = h;
-                    a_g[v][e] += dl * h;
-                    a_b[v][e] += dl;
-                    float gg = dl * gam[v][e];
-                    g[v][e] = gg;
-                    s1 += gg;
-                    s2 += gg * h;
+            for (int v = 0; v < NV; ++v) {
+                float zz[EPT], dd[EPT];
+                lz[u][v].to_f32(zz);
+                ld[u][v].to_f32(dd);
+#pragma unroll
+                for (int e = 0; e < EPT; ++e) {
+                    if (MODE == 2) {
+                        g[v][e] = zz[e] > 0.f ? dd[e] : 0.f;  // dz directly
+                    } else {
+                        float h = (zz[e] - mu) * rs;
+                        float yv = h * gam[v][e] + bet[v][e];
+                        float dl = (MODE == 0 && !(yv > 0.f)) ? 0.f : dd[e];
+                        xh[v][e] = h;
+                        a_g[v][e] += dl * h;
+                        a_b[v][e] += dl;
+                        float gg = dl * gam[v][e];
+                        g[v][e] = gg;
+                        s1 += gg;
+                        s2 += gg * h;
+                    }
                 }
             }
-        }
-        if (MODE != 2) {
-            s1 = group_sum<G>(s1) * inv_c;
-            s2 = group_sum<G>(s2) * inv_c;
-        }
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            float o[EPT];
-#pragma unroll
-            for (int e = 0; e < EPT; ++e) {
-                float d = MODE == 2 ? g[v][e] : rs * (g[v][e] - s1 - xh[v][e] * s2);
-                o[e] = d;
+            if (MODE != 2) {
+                s1 = group_sum<G>(s1) * inv_c;
+                s2 = group_sum<G>(s2) * inv_c;
             }
-            Vec16<T> st;
-            st.from_f32(o);
-            st.store(dz + pix * c + (v * G + gl) * EPT);
-            float back[EPT];  // dbias sums the values as stored (what the conv wgrad sees)
-            st.to_f32(back);
 #pragma unroll
-            for (int e = 0; e < EPT; ++e) a_z[v][e] += back[e];
+            for (int v = 0; v < NV; ++v) {
+                float o[EPT];
+#pragma unroll
+                for (int e = 0; e < EPT; ++e) {
+                    float d = MODE == 2 ? g[v][e] : rs * (g[v][e] - s1 - xh[v][e] * s2);
+                    o[e] = d;
+                }
+                Vec16<T> st;
+                st.from_f32(o);
+                st.store(dz + pix * c + (v * G + gl) * EPT);
+                float back[EPT];  // dbias sums the values as stored (what the conv wgrad sees)
+                st.to_f32(back);
+#pragma unroll
+                for (int e = 0; e < EPT; ++e) a_z[v][e] += back[e];
+            }
         }
     }
     // block reduction over the PPB pixel groups (fixed order => deterministic)
