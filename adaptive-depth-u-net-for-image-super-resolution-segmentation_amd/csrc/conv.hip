@@ -278,6 +278,7 @@ __device__ __forceinline__ uint4 load_w_slot(const char* wp, int kc_total, int c
 }
 
 #define AD_EPI_LN_RELU 2        // internal: ad_conv3x3_ln_relu_fwd
+#define AD_EPI_MASK 3           // internal: ad_conv3x3_dgrad_relu (ReLU-grad of the producer fused into this dgrad)
 #define AD_ERR_UNFUSED 1000     // internal: no fused kernel for this shape, run the two launches
 
 struct ConvArgs {
@@ -293,6 +294,9 @@ struct ConvArgs {
     // fused LayerNorm + ReLU epilogue (epilogue == AD_EPI_LN_RELU, cout == 64): y1 receives z, a_out the activation
     const float* ln_gamma; const float* ln_beta; float ln_eps;
     char* a_out; float* ln_mean; float* ln_rstd;
+    // AD_EPI_MASK: outputs of y1's blocks are zeroed where mask1 (the producer's stored ReLU output, laid out like y1)
+    // is not positive; dbias_part[workgroup][64] receives the column sums of what the workgroup stored into y1
+    const char* mask1; float* dbias_part;
     Geo g;
 };
 
@@ -748,6 +752,38 @@ __device__ __forceinline__ void ws_mma_role(const ConvArgs& a, const char* xb0, 
     unsigned pvo[4] = {WR_OOB, WR_OOB, WR_OOB, WR_OOB};   // before the first item: out of range, stores dropped
 #pragma unroll
     for (int i = 0; i < NPEND; ++i) pend[i] = u32x4{0u, 0u, 0u, 0u};
+    // EPI 3: the eight 16-byte pieces of the producer's ReLU output that line up with pend[0..7] (fetched right after
+    // the tile is packed, used a whole chunk later), and this lane's column sums of what it stored: after the row swap
+    // a lane holds channels (grp&1)*16 + (grp>>1)*8 .. +7 of n-tile pair np, i.e. 2 x 8 distinct channels.
+    const bool masked = EPI == 3 && nb * BN < a.cy1 && a.mask1 != nullptr;        // wave uniform
+    const auto rsk = wave_uniform_rsrc(masked ? (const void*)a.mask1 : (const void*)yp, masked ? npix * cy * TSZ : 0);
+    u32x4 mkv[EPI == 3 ? 8 : 1];
+    float dbs[EPI == 3 ? 16 : 1];
+    if (EPI == 3) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) mkv[i] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dbs[i] = 0.f;
+    }
+    // stores pend[IDX] after zeroing the elements whose mask element is not positive (|x| bits != 0: the mask is a ReLU
+    // output, never negative) and adds what is stored to the column sums
+#define WS_MASK_STORE(IDX)                                                                                    \
+    do {                                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        u32x4 v_ = pend[IDX];                                                                                 \
+        if (masked) {                                                                                         \
+            const u32x4 m_ = mkv[IDX];                                                                        \
+            _Pragma("unroll") for (int d_ = 0; d_ < 4; ++d_) {                                                \
+                const unsigned keep_ = ((m_[d_] & 0x7fffu) ? 0xffffu : 0u) | ((m_[d_] & 0x7fff0000u) ? 0xffff0000u : 0u); \
+                v_[d_] &= keep_;                                                                              \
+            }                                                                                                 \
+            typedef typename Half16<typename P::T>::v8 hv8_;                                                  \
+            const hv8_ h_ = __builtin_bit_cast(hv8_, v_);                                                     \
+            _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) dbs[((IDX) & 1) * 8 + j_] += (float)h_[j_];      \
+        }                                                                                                     \
+        __builtin_amdgcn_raw_buffer_store_b128(v_, rsy, pvo[(IDX) >> 1], ((IDX) & 1) * 32 * TSZ, 0);          \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+    } while (0)
 #define WS_PEND_STORE(IDX, RS)                                                                                \
     do {                                                                                                      \
         __builtin_amdgcn_sched_barrier(0);   /* pin the store between two tap steps (hipcc would bunch them) */ \
@@ -756,10 +792,12 @@ __device__ __forceinline__ void ws_mma_role(const ConvArgs& a, const char* xb0, 
     } while (0)
     auto hook0 = [&](int st) {
         if (EPI == 2) { if (st < 8) WS_PEND_STORE(st, rsy); }
+        else if (EPI == 3) {}                             // the mask pieces are still in flight: all stores in chunk 1
         else if ((st & 1) && st < 8) WS_PEND_STORE(st >> 1, rsy);
     };
     auto hook1 = [&](int st) {
         if (EPI == 2) { if (st < 8) WS_PEND_STORE(8 + st, rsa); }
+        else if (EPI == 3) { if (st < 8) WS_MASK_STORE(st); }
         else if ((st & 1) && st < 8) WS_PEND_STORE(4 + (st >> 1), rsy);
     };
     for (int k = 0; k < nloc; ++k) {
@@ -785,15 +823,43 @@ __device__ __forceinline__ void ws_mma_role(const ConvArgs& a, const char* xb0, 
             lds_barrier();
             P::mma_chunk_rows(acc, xb1, abase0, HWB, wt1, lane, [](int) {});
         }
-        ws_pack_tile<EPI, typename P::T>(acc, gb, a.ln_eps, wave, lane, a.h, a.w, nn, y0, x0, cy, soff, rsm, rsr, pend, pvo);
+        ws_pack_tile<(EPI == 3 ? 0 : EPI), typename P::T>(acc, gb, a.ln_eps, wave, lane, a.h, a.w, nn, y0, x0, cy, soff, rsm, rsr,
+                                                          pend, pvo);
+        if (EPI == 3) {        // unconditional loads (zero records when this block is not masked): exact vmcnt bookkeeping
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                mkv[i] = __builtin_amdgcn_raw_buffer_load_b128(rsk, pvo[i >> 1], (i & 1) * 32 * TSZ, 0);
+        }
     }
+    if (EPI == 3) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) WS_PEND_STORE(i, rsy);
-    if (EPI == 2) {
+        for (int i = 0; i < 8; ++i) WS_MASK_STORE(i);
+        // column sums: fold the 16 pixel lanes of each lane group; one row of 64 per MFMA wave goes to
+        // dbias_part[workgroup][wave][64] (zeros from workgroups whose block is not masked) and
+        // mask_dbias_reduce_kernel adds the rows of a block in a fixed order
 #pragma unroll
-        for (int i = 0; i < 8; ++i) WS_PEND_STORE(8 + i, rsa);
+        for (int j = 0; j < 16; ++j) {
+            float v = dbs[j];
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o, 64);
+            dbs[j] = v;
+        }
+        if ((lane & 15) == 0 && a.dbias_part) {
+            float* row = a.dbias_part + ((size_t)blockIdx.x * 4 + wave) * 64;
+#pragma unroll
+            for (int j = 0; j < 16; ++j)                                         // channel of slot j: see dbs above
+                row[(j >> 3) * 32 + (grp & 1) * 16 + (grp >> 1) * 8 + (j & 7)] = dbs[j];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) WS_PEND_STORE(i, rsy);
+        if (EPI == 2) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) WS_PEND_STORE(8 + i, rsa);
+        }
     }
 #undef WS_PEND_STORE
+#undef WS_MASK_STORE
 }
 
 template <typename P, int EPI>
@@ -1745,15 +1811,17 @@ __global__ __launch_bounds__(C3_T, 2) void conv3x3_c3_wgrad_kernel(C3Args a) {
 #undef C3_TILE
 
 // dw_hwio[tap][ci][co] = sum over splits of the slabs, fixed order (deterministic).
-// block = 64 consecutive (tap, ci, co) columns x 4 split groups.
+// block = 32 float4 column vectors (128 consecutive (tap, ci, co) outputs) x 8 split groups; a thread walks its splits
+// four at a time (four independent 16-byte loads in flight), the eight groups are folded through LDS in a fixed order.
+// (cout % 4 == 0 and the slab rows are 64 floats, so a float4 never straddles a row or a channel block.)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
                                                            int nsplit, int ncib, int ncob, int ck, int cin_real,
                                                            int cout, int accumulate = 0) {
-    __shared__ float sm[4][64];
-    const int tid = threadIdx.x, cl = tid & 63, rg = tid >> 6;
-    const int idx = blockIdx.x * 64 + cl;
+    __shared__ float4 sm[8][32];
+    const int tid = threadIdx.x, cl = tid & 31, rg = tid >> 5;
+    const int idx = (blockIdx.x * 32 + cl) * 4;
     const int total = 9 * cin_real * cout;
-    float s = 0.f;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (idx < total) {
         const int co = idx % cout;
         const int r = idx / cout;
@@ -1762,14 +1830,43 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         const int cib = ci / ck, cil = ci % ck, cob = co / BN, col = co % BN;
         const size_t base = (((size_t)cib * ncob + cob) * 9 + tap) * (ck * BN) + cil * BN + col;
         const size_t stride = (size_t)ncib * ncob * 9 * ck * BN;
-        for (int sp = rg; sp < nsplit; sp += 4) s += ws[base + sp * stride];
+        int sp = rg;
+        for (; sp + 24 < nsplit; sp += 32) {
+            const float4 v0 = *reinterpret_cast<const float4*>(ws + base + (size_t)sp * stride);
+            const float4 v1 = *reinterpret_cast<const float4*>(ws + base + (size_t)(sp + 8) * stride);
+            const float4 v2 = *reinterpret_cast<const float4*>(ws + base + (size_t)(sp + 16) * stride);
+            const float4 v3 = *reinterpret_cast<const float4*>(ws + base + (size_t)(sp + 24) * stride);
+            s.x += (v0.x + v1.x) + (v2.x + v3.x); s.y += (v0.y + v1.y) + (v2.y + v3.y);
+            s.z += (v0.z + v1.z) + (v2.z + v3.z); s.w += (v0.w + v1.w) + (v2.w + v3.w);
+        }
+        for (; sp < nsplit; sp += 8) {
+            const float4 v = *reinterpret_cast<const float4*>(ws + base + (size_t)sp * stride);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
     }
     sm[rg][cl] = s;
     __syncthreads();
     if (rg == 0 && idx < total) {
-        const float t = (sm[0][cl] + sm[1][cl]) + (sm[2][cl] + sm[3][cl]);
-        dw[idx] = accumulate ? dw[idx] + t : t;      // later runs of an image-chunked launch add to the first
+        float4 t = sm[0][cl];
+#pragma unroll
+        for (int r = 1; r < 8; ++r) { const float4 v = sm[r][cl]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+        float4* dst = reinterpret_cast<float4*>(dw + idx);
+        if (accumulate) { const float4 o = *dst; t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }   // later image runs add
+        *dst = t;
     }
+}
+
+// dbias[c] = sum over the MFMA-wave rows of the workgroups that own output block c / 64 (ws_order: workgroup b owns
+// block (b >> 3) % nblk), ascending row order: deterministic.  One thread per channel.
+__global__ void mask_dbias_reduce_kernel(const float* __restrict__ part, int nwg, int nblk, int cy1, float* __restrict__ dbias) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cy1) return;
+    const int blk = c / BN, col = c % BN;
+    float s = 0.f;
+    for (int b = 0; b < nwg; ++b)
+        if ((b >> 3) % nblk == blk)
+            for (int wv = 0; wv < 4; ++wv) s += part[((size_t)b * 4 + wv) * BN + col];
+    dbias[c] = s;
 }
 
 // ------------------------------------------------------------------ weight packing
@@ -1778,48 +1875,36 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // blocks (ad_conv3x3_pack_elems), so a layer with 32 output channels is one block whose upper half is never stored.
 static __host__ __device__ inline int pad64(int c) { return (c + BN - 1) / BN * BN; }
 
-// One thread writes one 16-byte vector (KV elements) of a pack: the forward pack gathers KV input channels of one
-// output channel (consecutive threads = consecutive output channels: coalesced 4-byte reads, coalesced 16-byte
-// writes), the dgrad pack reads KV consecutive output channels (one 32 / 16-byte read).  `e` = first element of the vector.
+// One element per thread (a 16-byte-vector-per-thread variant with coalesced reads for the forward pack measured
+// slower, 0.285 vs 0.179 ms for the 24 layers of K2': the dgrad half then reads one 32-byte sector per lane).
 template <typename T>
-__device__ __forceinline__ void pack_vector(const float* __restrict__ w, int cin, int cout, int cin_pad, T* __restrict__ wf,
-                                            T* __restrict__ wd, int e) {
+__device__ __forceinline__ void pack_element(const float* __restrict__ w, int cin, int cout, int cin_pad, T* __restrict__ wf,
+                                             T* __restrict__ wd, int e) {
     constexpr int KV = 16 / (int)sizeof(T);
     const int cout_p = (cout + BN - 1) / BN * BN, cin_o = (cin_pad + BN - 1) / BN * BN;
     const int total_f = 9 * cin_pad * cout_p;
-    float f[KV];
     if (e < total_f) {
-        int r = e / KV;
-        const int co = r % cout_p; r /= cout_p;
-        const int kc = r % (cin_pad / KV), tap = r / (cin_pad / KV);
-#pragma unroll
-        for (int kv = 0; kv < KV; ++kv) {
-            const int ci = kc * KV + kv;
-            f[kv] = ci < cin && co < cout ? w[((size_t)tap * cin + ci) * cout + co] : 0.f;
-        }
-        Vec16<T> st;
-        st.from_f32(f);
-        st.store(wf + e);
+        int kv = e % KV, r = e / KV;
+        int co = r % cout_p; r /= cout_p;
+        int kc = r % (cin_pad / KV), tap = r / (cin_pad / KV);
+        int ci = kc * KV + kv;
+        wf[e] = (T)(ci < cin && co < cout ? w[((size_t)tap * cin + ci) * cout + co] : 0.f);
     } else {
         const int i = e - total_f;
-        int r = i / KV;
-        const int ci = r % cin_o; r /= cin_o;
-        const int kc = r % (cout / KV), tap = r / (cout / KV);
-#pragma unroll
-        for (int kv = 0; kv < KV; ++kv) f[kv] = ci < cin ? w[((size_t)(8 - tap) * cin + ci) * cout + kc * KV + kv] : 0.f;
-        Vec16<T> st;
-        st.from_f32(f);
-        st.store(wd + i);
+        int kv = i % KV, r = i / KV;
+        int ci = r % cin_o; r /= cin_o;
+        int kc = r % (cout / KV), tap = r / (cout / KV);
+        int co = kc * KV + kv;
+        wd[i] = (T)(ci < cin ? w[((size_t)(8 - tap) * cin + ci) * cout + co] : 0.f);
     }
 }
 
 template <typename T>
 __global__ void pack_kernel(const float* __restrict__ w, int cin, int cout, int cin_pad, T* __restrict__ wf,
                             T* __restrict__ wd) {
-    constexpr int KV = 16 / (int)sizeof(T);
     const int total = 9 * cin_pad * pad64(cout) + (wd ? 9 * cout * pad64(cin_pad) : 0);
-    for (int v = blockIdx.x * blockDim.x + threadIdx.x; v * KV < total; v += gridDim.x * blockDim.x)
-        pack_vector<T>(w, cin, cout, cin_pad, wf, wd, v * KV);
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x)
+        pack_element<T>(w, cin, cout, cin_pad, wf, wd, e);
 }
 
 // All layers of a model in one launch.  Work is cut into quanta of PACK_Q elements (forward pack followed by dgrad
@@ -1832,14 +1917,13 @@ struct PackJob {
 constexpr int PACK_Q = 16384;
 template <typename T>
 __global__ __launch_bounds__(256) void pack_batch_kernel(const PackJob* __restrict__ jobs, int njobs) {
-    constexpr int KV = 16 / (int)sizeof(T);
     int jn = 0;
     while (jn + 1 < njobs && jobs[jn + 1].first_block <= (int)blockIdx.x) ++jn;      // block-uniform scan, <= 64 jobs
     const PackJob j = jobs[jn];
     const int total = 9 * j.cin_pad * pad64(j.cout) + (j.wd ? 9 * j.cout * pad64(j.cin_pad) : 0);
     const int lo = ((int)blockIdx.x - j.first_block) * PACK_Q;
     const int hi = lo + PACK_Q < total ? lo + PACK_Q : total;
-    for (int e = lo + threadIdx.x * KV; e < hi; e += 256 * KV) pack_vector<T>(j.w, j.cin, j.cout, j.cin_pad, (T*)j.wf, (T*)j.wd, e);
+    for (int e = lo + threadIdx.x; e < hi; e += 256) pack_element<T>(j.w, j.cin, j.cout, j.cin_pad, (T*)j.wf, (T*)j.wd, e);
 }
 
 template <typename K>
@@ -1934,6 +2018,7 @@ int launch_fwd(ConvArgs a, void* ws, size_t ws_bytes, hipStream_t s) {
             allow_big_lds(conv3x3_fwd_ws_kernel<P, 0>);
             allow_big_lds(conv3x3_fwd_ws_kernel<P, 1>);
             allow_big_lds(conv3x3_fwd_ws_kernel<P, 2>);
+            allow_big_lds(conv3x3_fwd_wres_kernel<P, 3>);
         }
         attr_set = true;
     }
@@ -1941,6 +2026,14 @@ int launch_fwd(ConvArgs a, void* ws, size_t ws_bytes, hipStream_t s) {
         a.ksplit = 1; a.slab = nullptr;
         int kind = fwd_ws_kind(a.n, a.h, a.w, a.c1, a.c2, a.cout_real, a.epilogue == AD_EPI_LN_RELU);
         if (a.cy1 % BN && a.cy1 != a.cout_real) kind = 0;          // a split inside a 64-channel block: generic kernel
+        // the ReLU-grad mask epilogue exists for the weights-resident kernel only (the streamed-weights variant would
+        // spill: 256 registers + scratch); ad_conv3x3_dgrad_relu_is_fused says so to the caller
+        if (a.epilogue == AD_EPI_MASK) {
+            if (kind != 1) return AD_ERR_UNFUSED;
+            conv3x3_fwd_wres_kernel<P, 3><<<NUM_CU, WR_T, WR_LDS, s>>>(a);
+            AD_LAUNCH_CHECK("conv3x3_fwd_wres (relu-grad)");
+            return AD_OK;
+        }
 #define AD_WS_LAUNCH(KERN, NAME)                                                                     \
     {                                                                                                \
         if (a.epilogue == AD_EPI_LN_RELU) KERN<P, 2><<<NUM_CU, WR_T, WR_LDS, s>>>(a);                \
@@ -1953,7 +2046,7 @@ int launch_fwd(ConvArgs a, void* ws, size_t ws_bytes, hipStream_t s) {
         if (kind == 2) AD_WS_LAUNCH(conv3x3_fwd_ws_kernel, "conv3x3_fwd_ws")
 #undef AD_WS_LAUNCH
     }
-    if (a.epilogue == AD_EPI_LN_RELU) return AD_ERR_UNFUSED;     // the caller runs conv + LayerNorm as two launches
+    if (a.epilogue == AD_EPI_LN_RELU || a.epilogue == AD_EPI_MASK) return AD_ERR_UNFUSED;     // the caller runs two launches
     size_t lds = 2 * (size_t)g.NPHP * 4 + 2 * BN * 4 + (((size_t)g.NPH * PIXB + 15) & ~15) + (size_t)FWS * FT * 16;
     if (lds > 160 * 1024) return ad_set_error(AD_ERR_ARG, "conv3x3_fwd: LDS %zu too large", lds);
     const int per_cu = lds <= 80 * 1024 ? 2 : 1;
@@ -2115,6 +2208,7 @@ extern "C" int ad_conv3x3_fwd(const void* x1, int c1, const void* x2, int c2, co
     a.dbg = g_dbg;
     a.ksplit = 1; a.slab = nullptr;
     a.ln_gamma = a.ln_beta = nullptr; a.ln_eps = 0.f; a.a_out = nullptr; a.ln_mean = a.ln_rstd = nullptr;
+    a.mask1 = nullptr; a.dbias_part = nullptr;
     pick_geo(n, h, w, &a.g);
     a.ntiles = a.g.tiles_x * a.g.tiles_y * a.g.tiles_i;
     hipStream_t s = (hipStream_t)stream;
@@ -2150,6 +2244,7 @@ extern "C" int ad_conv3x3_ln_relu_fwd(const void* x1, int c1, const void* x2, in
     a.ksplit = 1; a.slab = nullptr;
     a.ln_gamma = gamma; a.ln_beta = beta; a.ln_eps = eps;
     a.a_out = (char*)act; a.ln_mean = mean; a.ln_rstd = rstd;
+    a.mask1 = nullptr; a.dbias_part = nullptr;
     pick_geo(n, h, w, &a.g);
     a.ntiles = a.g.tiles_x * a.g.tiles_y * a.g.tiles_i;
     hipStream_t s = (hipStream_t)stream;
@@ -2169,6 +2264,44 @@ extern "C" size_t ad_conv3x3_fwd_ws_bytes(int n, int h, int w, int cin, int cout
     const int nitems = g.tiles_x * g.tiles_y * g.tiles_i * (cout / BN);
     const int ks = pick_ksplit(nitems, cin / (ad_is_half(dtype) ? PolBF16::CK : PolF32::CK));
     return ks > 1 ? (size_t)ks * n * h * w * cout * sizeof(float) : 0;
+}
+
+// ---- dgrad with the producer's ReLU-grad fused (decoder: dgrad of conv_block's first conv -> gradient of the up-conv's
+// ReLU output, train_adaptive_unet.py:259-262)
+extern "C" int ad_conv3x3_dgrad_relu_is_fused(int n, int h, int w, int c1, int cout, int cy1, int dtype) {
+    if (!ad_is_half(dtype) || n <= 0 || h <= 0 || w <= 0 || c1 <= 0 || cout <= 0 || cout % BN || cy1 <= 0 || cy1 % BN) return 0;
+    if (images_per_launch(n, h, w, c1, 0, cout, false, false) < n) return 0;        // image runs: plain path
+    return fwd_ws_kind(n, h, w, c1, 0, cout, false) == 1;      // weights-resident kernel (contraction over 64 channels)
+}
+
+extern "C" size_t ad_conv3x3_dgrad_relu_ws_bytes(void) { return (size_t)NUM_CU * 4 * BN * sizeof(float); }
+
+extern "C" int ad_conv3x3_dgrad_relu(const void* dz, int c1, const void* w_dgrad, const void* relu_out, void* y1, int cy1,
+                                     void* y2, float* dbias, int n, int h, int w, int cout, void* ws, size_t ws_bytes,
+                                     int dtype, void* stream) {
+    AD_REQUIRE(ad_conv3x3_dgrad_relu_is_fused(n, h, w, c1, cout, cy1, dtype),
+               "ad_conv3x3_dgrad_relu: no fused kernel for n=%d %dx%d c1=%d cout=%d cy1=%d dtype=%d (ask _is_fused first)", n, h, w,
+               c1, cout, cy1, dtype);
+    AD_REQUIRE(dz && w_dgrad && relu_out && y1 && dbias && ((cy1 == cout) == (y2 == nullptr)), "ad_conv3x3_dgrad_relu: bad operands");
+    if (!ws || ws_bytes < ad_conv3x3_dgrad_relu_ws_bytes())
+        return ad_set_error(AD_ERR_WS, "ad_conv3x3_dgrad_relu: workspace %zu < %zu bytes", ws_bytes, ad_conv3x3_dgrad_relu_ws_bytes());
+    ConvArgs a;
+    a.x1 = (const char*)dz; a.x2 = nullptr; a.c1 = c1; a.c2 = 0;
+    a.wp = (const char*)w_dgrad; a.bias = nullptr;
+    a.y1 = (char*)y1; a.y2 = (char*)y2; a.cy1 = cy1;
+    a.n = n; a.h = h; a.w = w; a.cout = cout; a.cout_real = cout; a.epilogue = AD_EPI_MASK;
+    a.dbg = g_dbg;
+    a.ksplit = 1; a.slab = nullptr;
+    a.ln_gamma = a.ln_beta = nullptr; a.ln_eps = 0.f; a.a_out = nullptr; a.ln_mean = a.ln_rstd = nullptr;
+    a.mask1 = (const char*)relu_out; a.dbias_part = (float*)ws;
+    pick_geo(n, h, w, &a.g);
+    a.ntiles = a.g.tiles_x * a.g.tiles_y * a.g.tiles_i;
+    hipStream_t s = (hipStream_t)stream;
+    const int rc = launch_fwd_dtype(dtype, a, nullptr, 0, s);
+    if (rc) return rc == AD_ERR_UNFUSED ? ad_set_error(AD_ERR_ARG, "ad_conv3x3_dgrad_relu: launch not specialised") : rc;
+    mask_dbias_reduce_kernel<<<(cy1 + 63) / 64, 64, 0, s>>>((const float*)ws, NUM_CU, cout / BN, cy1, dbias);
+    AD_LAUNCH_CHECK("mask_dbias_reduce");
+    return AD_OK;
 }
 
 // ---- first layer (3 input channels, 64 output channels, bf16)
@@ -2210,7 +2343,7 @@ extern "C" size_t ad_conv3x3_c3_wgrad_ws_bytes(int n, int h, int w) {
 extern "C" int ad_conv3x3_c3_wgrad(const float* x, const void* dz, float* dw_hwio, int n, int h, int w, void* ws,
                                    size_t ws_bytes, int dtype, void* stream) {
     AD_REQUIRE(ad_is_half(dtype), "ad_conv3x3_c3_wgrad: 16-bit storage types only (dtype %d)", dtype);
-    AD_REQUIRE(x && dz && dw_hwio, "ad_conv3x3_c3_wgrad: NULL operand");
+    AD_REQUIRE(x && dz && dw_hwio && (uintptr_t)dw_hwio % 16 == 0, "ad_conv3x3_c3_wgrad: NULL or unaligned operand");
     C3Args a; int grid;
     AD_REQUIRE(c3_plan(n, h, w, &a, &grid), "ad_conv3x3_c3_wgrad: unsupported shape n=%d h=%d w=%d", n, h, w);
     const size_t need = (size_t)grid * 27 * 64 * sizeof(float);
@@ -2223,7 +2356,7 @@ extern "C" int ad_conv3x3_c3_wgrad(const float* x, const void* dz, float* dw_hwi
     else conv3x3_c3_wgrad_kernel<f16_t><<<grid, C3_T, 2 * C3_HB + TM * WgradPol<PolF16>::DZS, s>>>(a);
     AD_LAUNCH_CHECK("ad_conv3x3_c3_wgrad");
     // slabs [grid][27][64] -> dw_hwio [3][3][3][64]: the generic slab reduce with 3-channel input blocks
-    wgrad_reduce_kernel<<<(27 * 64 + 63) / 64, 256, 0, s>>>((const float*)ws, dw_hwio, grid, 1, 1, 3, 3, 64);
+    wgrad_reduce_kernel<<<(27 * 64 + 127) / 128, 256, 0, s>>>((const float*)ws, dw_hwio, grid, 1, 1, 3, 3, 64);
     AD_LAUNCH_CHECK("wgrad_reduce");
     return AD_OK;
 }
@@ -2255,6 +2388,7 @@ extern "C" int ad_conv3x3_wgrad(const void* x1, int c1, const void* x2, int c2, 
     AD_REQUIRE(cout > 0 && cout % 16 == 0, "ad_conv3x3_wgrad: cout=%d must be a multiple of 16", cout);
     const int cin = c1 + c2;
     AD_REQUIRE(cin_real > 0 && cin_real <= cin, "ad_conv3x3_wgrad: cin_real=%d", cin_real);
+    AD_REQUIRE((uintptr_t)dw_hwio % 16 == 0, "ad_conv3x3_wgrad: dw_hwio must be 16-byte aligned");
     // batches whose tensors reach 2 GiB: runs of `chunk` images, the first run writes dw, the others add to it
     const int chunk = ad_is_half(dtype) ? images_per_launch(n, h, w, c1, c2, cout, false, true) : n;
     hipStream_t s = (hipStream_t)stream;
@@ -2278,7 +2412,7 @@ extern "C" int ad_conv3x3_wgrad(const void* x1, int c1, const void* x2, int c2, 
                  : dtype == AD_F16 ? launch_wgrad<PolF16>(a, p, s) : launch_wgrad<PolF32>(a, p, s);
         if (rc || direct) return rc;
         int total = 9 * cin_real * cout;
-        wgrad_reduce_kernel<<<(total + 63) / 64, 256, 0, s>>>((const float*)ws, dw_hwio, p.nsplit, p.ncib, p.ncob, p.ck,
+        wgrad_reduce_kernel<<<(total + 127) / 128, 256, 0, s>>>((const float*)ws, dw_hwio, p.nsplit, p.ncib, p.ncob, p.ck,
                                                              cin_real, cout, i0 > 0);
         AD_LAUNCH_CHECK("wgrad_reduce");
     }

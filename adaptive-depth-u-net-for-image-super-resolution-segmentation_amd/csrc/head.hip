@@ -39,9 +39,9 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ xh,
         for (int o = 0; o < 3; ++o) wl[e][o] = w[(gl * EPT + e) * 3 + o];
     const float bo = gl < 3 ? b[gl] : 0.f;
     float lsum = 0.f, qsum = 0.f;
-    // U pixels per thread and pass: their 16-byte loads are issued together (one dependent load per pass kept the
-    // kernel at 2.8 TB/s)
-    constexpr int U = 4;
+    // U pixels per thread and pass with their 16-byte loads issued together: measured neutral-to-worse in this kernel
+    // (0.195 -> 0.234 ms at U = 4; the backward kernel gains: 0.363 -> 0.287 ms), so the forward keeps U = 1
+    constexpr int U = 1;
     const int64_t step = (int64_t)gridDim.x * PPB;
     for (int64_t q0 = (int64_t)blockIdx.x * PPB + gp; q0 < ppi; q0 += U * step) {
         Vec16<T> ld[U];

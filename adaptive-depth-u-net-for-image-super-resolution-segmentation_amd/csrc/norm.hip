@@ -101,10 +101,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
             a_g[v][e] = a_b[v][e] = a_z[v][e] = 0.f;
         }
     const float inv_c = 1.0f / (float)c;
-    // U pixels per thread and pass, all their loads issued before the first use: the kernel is a pure stream (read dy
-    // and z, write dz) and with one pixel in flight per thread a CU had only ~32 KB outstanding -- 5.0 TB/s; Little's
-    // law at ~2 us of HBM latency wants ~64 KB per CU.
-    constexpr int U = NV == 1 ? 2 : 1;
+    // U pixels per thread and pass with all their loads issued before the first use.  Measured on the full-resolution
+    // 64-channel layers (K2', batch 64): U = 2 is SLOWER than U = 1 (0.345 vs 0.319 ms per launch) -- the four resident
+    // blocks per CU already keep the memory system busy and the extra registers cost occupancy -- so U stays 1.
+    constexpr int U = 1;
     const int64_t step = (int64_t)gridDim.x * PPB;
     for (int64_t pix0 = (int64_t)blockIdx.x * PPB + gp; pix0 < npix; pix0 += U * step) {
         Vec16<T> lz[U][NV], ld[U][NV];

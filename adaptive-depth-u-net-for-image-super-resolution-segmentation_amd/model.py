@@ -542,6 +542,7 @@ class Model:
         sc = self._scaler() if self.optimizer is not None else None
         dskips: Dict[int, torch.Tensor] = {}
         d = None
+        relu_done = False
         while tape:
             rec = tape.pop()
             kind = rec[0]
@@ -566,20 +567,33 @@ class Model:
                     ops.conv3x3_wgrad(x1, x2, dz, self.grad(cs.name + "/kernel"), cs.cin, ws)
                 self._done(cs.name + "/kernel")
                 dsk = None
+                fused_relu = False
                 if not cs.need_dgrad:
                     d = None
                 elif x2 is not None:
-                    d, dsk = ops.conv3x3_fwd(dz, None, self._packs[cs.name][1], None, cs.cin, split=x1.shape[-1])
+                    # x1 is the up-conv's ReLU output (:259-261): where the library has the fused epilogue, this dgrad
+                    # also applies that ReLU's gradient and sums the up-conv's bias gradient (no relu_bwd pass later)
+                    up = tape[-1][1] if tape and tape[-1][0] == "ca" and tape[-1][3] is x1 else None
+                    fused_relu = (up is not None and os.environ.get("ADUNET_NO_DGRAD_RELU") != "1"
+                                  and ops.conv3x3_dgrad_relu_is_fused(dz, cs.cin, x1.shape[-1]))
+                    if fused_relu:
+                        d, dsk = ops.conv3x3_dgrad_relu(dz, self._packs[cs.name][1], x1, self.grad(up.name + "/bias"), cs.cin, ws)
+                    else:
+                        d, dsk = ops.conv3x3_fwd(dz, None, self._packs[cs.name][1], None, cs.cin, split=x1.shape[-1])
                     dskips[lvl] = dsk
                 else:
                     d = ops.conv3x3_fwd(dz, None, self._packs[cs.name][1], None, self._cin_pad(cs))
+                relu_done = fused_relu
                 if audit is not None:
                     # (the skip half is accumulated into in place later on: record a copy)
-                    audit.append(("bwd_cla", cs.name, x1, x2, z, mean, rstd, d_in, dz, d, dsk.clone() if dsk is not None else None))
+                    audit.append(("bwd_cla", cs.name, x1, x2, z, mean, rstd, d_in, dz, d,
+                                  dsk.clone() if dsk is not None else None, fused_relu))
             elif kind == "ca":
                 _, cs, xin, u = rec
                 d_in = d
-                dz = ops.relu_bwd(d, u, self.grad(cs.name + "/bias"), ws)
+                # (already the pre-activation gradient, bias gradient included, when the dgrad above fused the ReLU)
+                dz = d if relu_done else ops.relu_bwd(d, u, self.grad(cs.name + "/bias"), ws)
+                relu_done = False
                 ops.conv3x3_wgrad(xin, None, dz, self.grad(cs.name + "/kernel"), cs.cin, ws)
                 self._done(cs.name + "/kernel")
                 d = ops.conv3x3_fwd(dz, None, self._packs[cs.name][1], None, cs.cin)

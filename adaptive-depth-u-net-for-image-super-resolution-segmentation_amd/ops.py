@@ -217,6 +217,27 @@ def conv3x3_fwd(x1: torch.Tensor, x2: Optional[torch.Tensor], w_packed: torch.Te
     return (y1, y2) if split is not None else y1
 
 
+def conv3x3_dgrad_relu_is_fused(dz: torch.Tensor, cout: int, cy1: int) -> bool:
+    n, h, w, c1 = dz.shape
+    return bool(_lib.load().ad_conv3x3_dgrad_relu_is_fused(n, h, w, c1, cout, cy1, dt(dz.dtype)))
+
+
+def conv3x3_dgrad_relu(dz: torch.Tensor, w_dgrad: torch.Tensor, relu_out: torch.Tensor, dbias: torch.Tensor, cout: int,
+                       ws: Workspace):
+    """dgrad through a conv whose first input is `relu_out` (the decoder's up-conv output) with that ReLU's gradient and
+    bias gradient fused: returns (d_pre_relu [.., cy1], d_skip [.., cout - cy1] or None); writes dbias [cy1]."""
+    n, h, w, c1 = dz.shape
+    cy1 = relu_out.shape[-1]
+    y1 = torch.empty((n, h, w, cy1), dtype=dz.dtype, device=dz.device)
+    y2 = torch.empty((n, h, w, cout - cy1), dtype=dz.dtype, device=dz.device) if cy1 < cout else None
+    lib = _lib.load()
+    ws.ensure(lib.ad_conv3x3_dgrad_relu_ws_bytes())
+    with _timed("conv3x3_fwd", 2.0 * n * h * w * 9 * c1 * cout, float(n * h * w * (c1 + cout + cy1) * dz.element_size())):
+        check(lib.ad_conv3x3_dgrad_relu(_p(dz), c1, _p(w_dgrad), _p(relu_out), _p(y1), cy1, _p(y2), _p(dbias), n, h, w, cout,
+                                        ws.ptr, ws.nbytes, dt(dz.dtype), _stream()), "ad_conv3x3_dgrad_relu")
+    return y1, y2
+
+
 def conv3x3_ln_relu_fwd(x1: torch.Tensor, x2: Optional[torch.Tensor], w_packed: torch.Tensor, bias: Optional[torch.Tensor],
                         gamma: torch.Tensor, beta: torch.Tensor, cout: int, eps: float = LN_EPS):
     """conv_block's Conv2D -> LayerNormalization -> ReLU.  Returns (z, act, mean, rstd): z is the conv output kept for

@@ -282,6 +282,19 @@ int ad_adam_step_scaled(float* p, const float* g, float* m, float* v, int64_t co
 
 int ad_cast(const void* x, int dtype_in, void* y, int dtype_out, int64_t count, void* stream);
 
+/* dgrad of a conv whose (first) input is the ReLU output of a preceding Conv2D(..., activation="relu") -- the decoder's
+ * up-conv (train_adaptive_unet.py:259) feeding conv_block -- with that ReLU's gradient fused into the epilogue:
+ *   y1 = (dz (*) W^T)[..., :cy1] * [relu_out > 0]      (= the gradient w.r.t. the up-conv's PRE-activation output)
+ *   y2 = (dz (*) W^T)[..., cy1:]                        (skip half of the virtual concat, untouched; NULL if cy1 == cout)
+ *   dbias[cy1] = column sums of y1 as stored            (the up-conv's bias gradient, BiasAddGrad)
+ * replacing ad_conv3x3_fwd on the dgrad pack followed by ad_relu_bwd (one full read-modify-write pass less).  Only
+ * launches that ad_conv3x3_dgrad_relu_is_fused() accepts (16-bit dtypes, 64-channel contraction, >= 4 tiles per CU);
+ * ws: ad_conv3x3_dgrad_relu_ws_bytes(). */
+int ad_conv3x3_dgrad_relu_is_fused(int n, int h, int w, int c1, int cout, int cy1, int dtype);
+size_t ad_conv3x3_dgrad_relu_ws_bytes(void);
+int ad_conv3x3_dgrad_relu(const void* dz, int c1, const void* w_dgrad, const void* relu_out, void* y1, int cy1, void* y2,
+                          float* dbias, int n, int h, int w, int cout, void* ws, size_t ws_bytes, int dtype, void* stream);
+
 /* ------------------------------------------------------------- feed path -- */
 
 /* LR synthesis on the device (shared/pipeline.py:79-94 degrade_image, applied to a whole HR batch in HBM by two

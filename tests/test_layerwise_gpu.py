@@ -128,7 +128,7 @@ def audit_sr_step(model, lr, hr):
             check_f32(G["residual_rgb/kernel"], dw, "residual_rgb/kernel grad", slack=slack)
             check_f32(G["residual_rgb/bias"], db, "residual_rgb/bias grad", slack=slack)
         elif kind == "bwd_cla":
-            _, _, x1, x2, z, mean, rstd, d_in, dz, d, dsk = rec
+            _, _, x1, x2, z, mean, rstd, d_in, dz, d, dsk, fused_relu = rec
             ln = model.convs[name].ln
             gam, bet = W[ln + "/gamma"], W[ln + "/beta"]
             zs = f64(z)
@@ -151,7 +151,11 @@ def audit_sr_step(model, lr, hr):
             check_f32(G[name + "/bias"], db, name + "/bias grad")
             if need_dx:
                 c1 = d.shape[-1] if dsk is not None else model.convs[name].cin
-                check_stored(d[..., :c1] if dsk is None else d, dx[..., :c1], name + " dgrad", bf16)
+                want_d = dx[..., :c1]
+                if fused_relu:        # the dgrad kernel also applied the up-conv's ReLU gradient (x1 = its ReLU output)
+                    want_d = want_d * (f64(x1) > 0)
+                    seen.add("fused_relu_grad")
+                check_stored(d[..., :c1] if dsk is None else d, want_d, name + " dgrad", bf16)
                 if dsk is not None:
                     check_stored(dsk, dx[..., c1:], name + " dgrad (skip half)", bf16)
         elif kind == "bwd_ca":
@@ -168,8 +172,8 @@ def audit_sr_step(model, lr, hr):
             if before is not None:
                 want = want + f64(before)
             check_stored(d, want, name + " bwd", bf16)
-    assert seen == {"fwd_cla", "fwd_resize", "fwd_ca", "fwd_head", "bwd_head", "bwd_cla", "bwd_ca", "bwd_resize"}
-    return len(records)
+    assert seen - {"fused_relu_grad"} == {"fwd_cla", "fwd_resize", "fwd_ca", "fwd_head", "bwd_head", "bwd_cla", "bwd_ca", "bwd_resize"}
+    return len(records), "fused_relu_grad" in seen
 
 
 def check_stored_masked(got, want, ok_pixels, what, store_bf16):
@@ -200,6 +204,7 @@ CONFIGS = [
     ("small-ragged", 0.6, 3, 40, 3),
     ("K2p", 0.25, 4, 256, 2),        # BASELINE `metric` headline / config 2 (depth 4, x4): pyramid 256/64/16/4/1
     ("R3", 0.5, 3, 256, 1),          # the reference's own Experiment-1 shape: 256/128/64/32
+    ("K2p-b8", 0.25, 4, 256, 8),     # enough tiles for the wave-specialised launches incl. the fused ReLU-grad dgrad
 ]
 
 
@@ -209,7 +214,9 @@ def test_every_step_of_the_model_against_the_oracle(device, cfg, dtype):
     _, scale, depth, p, n = cfg
     model = build(scale, depth, p, dtype, device)
     lr, hr = synth(np.random.default_rng(4321), n, p)
-    nrec = audit_sr_step(model, lr, hr)
+    nrec, fused_relu = audit_sr_step(model, lr, hr)
+    if cfg[0] == "K2p-b8":
+        assert fused_relu == (dtype == torch.bfloat16)       # batch 8 reaches the weights-resident kernels at full resolution
     # forward: 2 convs per block (2 depth + 2 blocks), depth up-convs, 2 depth resizes, head; backward: the same again
     assert nrec == 2 * (2 * (2 * depth + 2) + depth + 2 * depth + 1)
 

@@ -625,3 +625,34 @@ def test_wave_specialised_kernels_fp16(device, ws):
     assert ops._lib.load().ad_conv3x3_ln_relu_is_fused(n, hw, hw, c, 0, c, ops.dt(F16))
     for got, want, tol in zip(out[F16], out[F32], (2e-3, 2e-3, 1e-3, 2e-3, 2e-3, 1e-4, 1e-3)):
         assert float((got - want).abs().max() / want.abs().max()) < tol
+
+
+@pytest.mark.parametrize("dtype", [BF16, F16])
+@pytest.mark.parametrize("shape", [(6, 256, 256, 64, 128, 64), (20, 128, 128, 64, 64, 64), (5, 250, 243, 64, 128, 64)])
+def test_dgrad_with_fused_relu_grad_equals_dgrad_then_relu_bwd(device, ws, dtype, shape):
+    """ad_conv3x3_dgrad_relu (ReLU-grad of the up-conv and its bias gradient in the dgrad epilogue) against the two
+    launches it replaces: the masked half and the skip half bit for bit (masking a stored value is exact), the bias
+    gradient to fp32 summation order.  Ragged tiles included (250 x 243)."""
+    from adunet_amd import ops
+    n, h, w, c1, cout, cy1 = shape
+    g = torch.Generator().manual_seed(9)
+    dz = (torch.rand((n, h, w, c1), generator=g) * 2 - 1).to(device=device, dtype=dtype)
+    u = torch.relu(torch.rand((n, h, w, cy1), generator=g) * 2 - 1).to(device=device, dtype=dtype)      # ~half zeros
+    wk = ((torch.rand((3, 3, cout, c1), generator=g) * 2 - 1) * 0.05).to(device)
+    _, wd = ops.conv3x3_pack(wk, cout, dtype)
+    assert ops.conv3x3_dgrad_relu_is_fused(dz, cout, cy1)
+    dbias = torch.full((cy1,), float("nan"), dtype=F32, device=device)
+    y1, y2 = ops.conv3x3_dgrad_relu(dz, wd, u, dbias, cout, ws)
+    if cy1 < cout:
+        r1, r2 = ops.conv3x3_fwd(dz, None, wd, None, cout, split=cy1)
+        assert torch.equal(y2, r2)
+    else:
+        r1, r2 = ops.conv3x3_fwd(dz, None, wd, None, cout), None
+        assert y2 is None
+    want_db = torch.full((cy1,), float("nan"), dtype=F32, device=device)
+    want = ops.relu_bwd(r1, u, want_db, ws)
+    assert torch.equal(y1, want)
+    assert float((dbias - want_db).abs().max() / want_db.abs().max()) < 1e-5
+    db2 = torch.empty_like(dbias)
+    y1b, _ = ops.conv3x3_dgrad_relu(dz, wd, u, db2, cout, ws)
+    assert torch.equal(y1, y1b) and torch.equal(dbias, db2)          # deterministic
