@@ -205,6 +205,143 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ xh,
     }
 }
 
+// head_bwd_kernel and the LayerNorm + ReLU backward of the layer that feeds the head (conv_block's last
+// Conv2D -> LayerNormalization -> ReLU, train_adaptive_unet.py:265) in ONE pass: the gradient of the head activations
+// never goes to memory (it stays fp32 in registers), so the pair "write dxh, read dxh + z, write dz" becomes "read z,
+// write dz".  Same lane layout as both kernels: G = ch / EPT lanes own a pixel's channels.
+// part[block][ch*3 + 3 + 3*ch] = { dW head, db head, dgamma, dbeta, dbias of the conv in front of the LayerNorm }
+template <typename T, int G>
+__global__ __launch_bounds__(256) void head_ln_bwd_kernel(const T* __restrict__ xh, const float* __restrict__ w,
+                                                          const float* __restrict__ b, const float* __restrict__ inp,
+                                                          const float* __restrict__ target, const T* __restrict__ z,
+                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          T* __restrict__ dz, float* __restrict__ part, int64_t ppi, int ch,
+                                                          int loss_kind, float eps, float gscale_host,
+                                                          const float* __restrict__ loss_scale) {
+    constexpr int EPT = ElemTraits<T>::EPT;
+    constexpr int PPB = 256 / G;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = reinterpret_cast<float*>(smem);  // [PPB][ncol]
+    const float gscale = loss_scale ? gscale_host * loss_scale[0] : gscale_host;
+    const int ncol = ch * 6 + 3;
+    const int tid = threadIdx.x, gl = tid % G, gp = tid / G;
+    const int img = blockIdx.y;
+    float wl[EPT][3], aw[EPT][3], ab[3] = {0.f, 0.f, 0.f};
+    float gam[EPT], bet[EPT], a_g[EPT], a_b[EPT], a_z[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            wl[e][o] = w[(gl * EPT + e) * 3 + o];
+            aw[e][o] = 0.f;
+        }
+        gam[e] = gamma[gl * EPT + e]; bet[e] = beta[gl * EPT + e];
+        a_g[e] = a_b[e] = a_z[e] = 0.f;
+    }
+    const float b0 = b[0], b1 = b[1], b2 = b[2];
+    const float inv_c = 1.0f / (float)ch;
+    for (int64_t q = (int64_t)blockIdx.x * PPB + gp; q < ppi; q += (int64_t)gridDim.x * PPB) {
+        const int64_t pix = (int64_t)img * ppi + q;
+        Vec16<T> lx, lz;
+        lx.load(xh + pix * ch + gl * EPT);
+        lz.load(z + pix * ch + gl * EPT);
+        const float mu = mean[pix], rs = rstd[pix];
+        float x[EPT], zz[EPT];
+        lx.to_f32(x);
+        lz.to_f32(zz);
+        float r[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            r[0] += x[e] * wl[e][0];
+            r[1] += x[e] * wl[e][1];
+            r[2] += x[e] * wl[e][2];
+        }
+        r[0] = gsum<G>(r[0]) + b0; r[1] = gsum<G>(r[1]) + b1; r[2] = gsum<G>(r[2]) + b2;
+        float g[3];
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            float pre = inp[pix * 3 + o] + r[o];
+            float ov = fminf(fmaxf(pre, 0.f), 1.f);
+            float d = target[pix * 3 + o] - ov;
+            float dl = loss_kind == 0 ? -d * rsqrtf(d * d + eps * eps) : (d > 0.f ? -1.f : (d < 0.f ? 1.f : 0.f));
+            g[o] = (pre >= 0.f && pre <= 1.f) ? dl * gscale : 0.f;
+        }
+        float h[EPT], gg[EPT];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const float da = g[0] * wl[e][0] + g[1] * wl[e][1] + g[2] * wl[e][2];       // gradient of the head activation
+#pragma unroll
+            for (int o = 0; o < 3; ++o) aw[e][o] += x[e] * g[o];
+            h[e] = (zz[e] - mu) * rs;
+            const float yv = h[e] * gam[e] + bet[e];
+            const float dl = yv > 0.f ? da : 0.f;                                        // ReLU
+            a_g[e] += dl * h[e];
+            a_b[e] += dl;
+            gg[e] = dl * gam[e];
+            s1 += gg[e];
+            s2 += gg[e] * h[e];
+        }
+#pragma unroll
+        for (int o = 0; o < 3; ++o) ab[o] += g[o];
+        s1 = gsum<G>(s1) * inv_c;
+        s2 = gsum<G>(s2) * inv_c;
+        float o8[EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) o8[e] = rs * (gg[e] - s1 - h[e] * s2);
+        Vec16<T> st;
+        st.from_f32(o8);
+        st.store(dz + pix * ch + gl * EPT);
+        float back[EPT];                     // the conv's bias gradient sums dz as stored (what its wgrad sees)
+        st.to_f32(back);
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) a_z[e] += back[e];
+    }
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int c = gl * EPT + e;
+#pragma unroll
+        for (int o = 0; o < 3; ++o) red[gp * ncol + c * 3 + o] = aw[e][o];
+        red[gp * ncol + ch * 3 + 3 + c] = a_g[e];
+        red[gp * ncol + ch * 4 + 3 + c] = a_b[e];
+        red[gp * ncol + ch * 5 + 3 + c] = a_z[e];
+    }
+    if (gl == 0)
+#pragma unroll
+        for (int o = 0; o < 3; ++o) red[gp * ncol + ch * 3 + o] = ab[o];
+    __syncthreads();
+    for (int i = tid; i < ncol; i += 256) {
+        float s = 0.f;
+        for (int p = 0; p < PPB; ++p) s += red[p * ncol + i];
+        part[((size_t)img * gridDim.x + blockIdx.x) * ncol + i] = s;
+    }
+}
+
+// out_k[col - start_k] = sum over rows of part[row][col] for the column ranges of up to five outputs, fixed order
+struct HeadLnOuts {
+    float* ptr[5];
+    int end[5];      // exclusive column end of each output
+};
+__global__ __launch_bounds__(256) void rows_reduce5_kernel(const float* __restrict__ part, int nrows, int ncols, HeadLnOuts o) {
+    __shared__ float sm[64][5];
+    const int tid = threadIdx.x, cl = tid & 3, rg = tid >> 2;
+    const int i = blockIdx.x * 4 + cl;
+    float s = 0.f;
+    if (i < ncols)
+        for (int r = rg; r < nrows; r += 64) s += part[(size_t)r * ncols + i];
+    sm[rg][cl] = s;
+    __syncthreads();
+    if (rg == 0 && i < ncols) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 64; ++r) t += sm[r][cl];
+        int k = 0, start = 0;
+        while (i >= o.end[k]) { start = o.end[k]; ++k; }
+        o.ptr[k][i - start] = t;
+    }
+}
+
 // out[col] = sum over rows of part[row][col], fixed order (4 columns x 64 row-groups per block)
 __global__ __launch_bounds__(256) void rows_reduce_kernel(const float* __restrict__ part, int nrows, int ncols,
                                                           float* __restrict__ o0, int n0, float* __restrict__ o1) {
@@ -302,5 +439,43 @@ extern "C" int ad_head_bwd(const void* xh, const float* w, const float* b, const
     AD_LAUNCH_CHECK("ad_head_bwd");
     rows_reduce_kernel<<<(ncol + 3) / 4, 256, 0, s>>>((const float*)ws, n * bpi, ncol, dw, ch * 3, db);
     AD_LAUNCH_CHECK("head rows_reduce");
+    return AD_OK;
+}
+
+
+extern "C" size_t ad_head_ln_bwd_ws_bytes(int n, int ch) { return (size_t)n * BPI_MAX * (ch * 6 + 3) * sizeof(float); }
+
+extern "C" int ad_head_ln_bwd(const void* xh, const float* w, const float* b, const float* inp, const float* target,
+                              const void* z, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                              void* dz, float* dw, float* db, float* dgamma, float* dbeta, float* dbias_conv, int n,
+                              int64_t pix_per_img, int ch, int loss_kind, float eps, float grad_scale,
+                              const float* loss_scale, void* ws, size_t ws_bytes, int dtype, void* stream) {
+    AD_REQUIRE(ad_dtype_ok(dtype), "ad_head_ln_bwd: bad dtype %d", dtype);
+    AD_REQUIRE(n > 0 && pix_per_img > 0 && target && z && mean && rstd && gamma && beta && dz && dgamma && dbeta && dbias_conv,
+               "ad_head_ln_bwd: bad shape / missing operand");
+    AD_REQUIRE(loss_kind == 0 || loss_kind == 1, "ad_head_ln_bwd: loss_kind=%d", loss_kind);
+    int g;
+    AD_REQUIRE(head_group(ch, ad_is_half(dtype) ? 8 : 4, &g), "ad_head_ln_bwd: unsupported ch=%d", ch);
+    const int bpi = head_bpi(pix_per_img, g);
+    const int ncol = ch * 6 + 3;
+    size_t need = (size_t)n * bpi * ncol * sizeof(float);
+    if (!ws || ws_bytes < need) return ad_set_error(AD_ERR_WS, "ad_head_ln_bwd: workspace %zu < %zu", ws_bytes, need);
+    size_t lds = (size_t)(256 / g) * ncol * sizeof(float);
+    if (lds > 64 * 1024) return ad_set_error(AD_ERR_ARG, "ad_head_ln_bwd: ch=%d needs %zu B of LDS", ch, lds);
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(bpi, n);
+    AD_DISPATCH_DTYPE(dtype, T_,
+        HEAD_DISPATCH(head_ln_bwd_kernel<T_, G_><<<grid, 256, lds, s>>>((const T_*)xh, w, b, inp, target, (const T_*)z, mean, rstd,
+                                                                        gamma, beta, (T_*)dz, (float*)ws, pix_per_img, ch,
+                                                                        loss_kind, eps, grad_scale, loss_scale);))
+    AD_LAUNCH_CHECK("ad_head_ln_bwd");
+    HeadLnOuts o;
+    o.ptr[0] = dw; o.end[0] = ch * 3;
+    o.ptr[1] = db; o.end[1] = ch * 3 + 3;
+    o.ptr[2] = dgamma; o.end[2] = ch * 4 + 3;
+    o.ptr[3] = dbeta; o.end[3] = ch * 5 + 3;
+    o.ptr[4] = dbias_conv; o.end[4] = ch * 6 + 3;
+    rows_reduce5_kernel<<<(ncol + 3) / 4, 256, 0, s>>>((const float*)ws, n * bpi, ncol, o);
+    AD_LAUNCH_CHECK("head_ln rows_reduce");
     return AD_OK;
 }

@@ -543,24 +543,45 @@ class Model:
         dskips: Dict[int, torch.Tensor] = {}
         d = None
         relu_done = False
+        dz_ready = None           # dz of the next "cla" record when the head's backward already produced it
         while tape:
             rec = tape.pop()
             kind = rec[0]
             if kind == "head":
                 w = self.param("residual_rgb/kernel").view(self.head, 3)
-                d = ops.head_bwd(rec[1], w, self.param("residual_rgb/bias"), x, target,
-                                 self.grad("residual_rgb/kernel").view(self.head, 3), self.grad("residual_rgb/bias"),
-                                 grad_scale, ws, loss_kind=self.loss.kind, eps=self.loss.eps,
-                                 loss_scale=sc.state if sc is not None else None)
+                nxt = tape[-1] if tape else None
+                if (nxt is not None and nxt[0] == "cla" and nxt[4].shape == rec[1].shape
+                        and os.environ.get("ADUNET_NO_HEAD_LN_FUSION") != "1"):
+                    # the layer feeding the head is Conv2D -> LayerNorm -> ReLU (:265): its LayerNorm/ReLU backward runs
+                    # inside the head's backward pass, the gradient of the head activations never goes to memory
+                    _, hcs, _, _, hz, hmean, hrstd, _ = nxt
+                    dz_ready = ops.head_ln_bwd(rec[1], w, self.param("residual_rgb/bias"), x, target, hz, hmean, hrstd,
+                                               self.param(hcs.ln + "/gamma"), self.param(hcs.ln + "/beta"),
+                                               self.grad("residual_rgb/kernel").view(self.head, 3), self.grad("residual_rgb/bias"),
+                                               self.grad(hcs.ln + "/gamma"), self.grad(hcs.ln + "/beta"),
+                                               self.grad(hcs.name + "/bias"), grad_scale, ws, loss_kind=self.loss.kind,
+                                               eps=self.loss.eps, loss_scale=sc.state if sc is not None else None)
+                    d = None
+                    if audit is not None:
+                        audit.append(("bwd_head_ln", "residual_rgb", rec[1], x, target, grad_scale, hcs.name, hz, hmean, hrstd,
+                                      dz_ready))
+                else:
+                    d = ops.head_bwd(rec[1], w, self.param("residual_rgb/bias"), x, target,
+                                     self.grad("residual_rgb/kernel").view(self.head, 3), self.grad("residual_rgb/bias"),
+                                     grad_scale, ws, loss_kind=self.loss.kind, eps=self.loss.eps,
+                                     loss_scale=sc.state if sc is not None else None)
+                    if audit is not None:
+                        audit.append(("bwd_head", "residual_rgb", rec[1], x, target, grad_scale, d))
                 self._done("residual_rgb/kernel")
-                if audit is not None:
-                    audit.append(("bwd_head", "residual_rgb", rec[1], x, target, grad_scale, d))
             elif kind == "cla":
                 _, cs, x1, x2, z, mean, rstd, lvl = rec
                 d_in = d
-                dz = ops.layernorm_relu_bwd(d, z, mean, rstd, self.param(cs.ln + "/gamma"), self.param(cs.ln + "/beta"),
-                                            self.grad(cs.ln + "/gamma"), self.grad(cs.ln + "/beta"),
-                                            self.grad(cs.name + "/bias"), ws)
+                if dz_ready is not None:
+                    dz, dz_ready = dz_ready, None
+                else:
+                    dz = ops.layernorm_relu_bwd(d, z, mean, rstd, self.param(cs.ln + "/gamma"), self.param(cs.ln + "/beta"),
+                                                self.grad(cs.ln + "/gamma"), self.grad(cs.ln + "/beta"),
+                                                self.grad(cs.name + "/bias"), ws)
                 if x1.dtype == torch.float32 and self.dtype != torch.float32:      # raw 3-channel batch: first layer
                     ops.conv3x3_c3_wgrad(x1, dz, self.grad(cs.name + "/kernel"), ws)
                 else:

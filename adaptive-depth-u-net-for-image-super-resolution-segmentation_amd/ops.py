@@ -404,6 +404,20 @@ def head_bwd(xh, w, b, inp, target, dw, db, grad_scale: float, ws: Workspace, lo
     return dxh
 
 
+def head_ln_bwd(xh, w, b, inp, target, z, mean, rstd, gamma, beta, dw, db, dgamma, dbeta, dbias_conv, grad_scale: float,
+                ws: Workspace, loss_kind: int = 0, eps: float = CHARBONNIER_EPS, loss_scale: Optional[torch.Tensor] = None):
+    """head_bwd + the LayerNorm/ReLU backward of the layer feeding the head, one pass; returns that layer's dz."""
+    n, h, wd, ch = xh.shape
+    dz = torch.empty_like(z)
+    lib = _lib.load()
+    ws.ensure(lib.ad_head_ln_bwd_ws_bytes(n, ch))
+    with _timed("head_ln_bwd"):
+        check(lib.ad_head_ln_bwd(_p(xh), _p(w), _p(b), _p(inp), _p(target), _p(z), _p(mean), _p(rstd), _p(gamma), _p(beta),
+                                 _p(dz), _p(dw), _p(db), _p(dgamma), _p(dbeta), _p(dbias_conv), n, h * wd, ch, loss_kind, eps,
+                                 grad_scale, _p(loss_scale), ws.ptr, ws.nbytes, dt(xh.dtype), _stream()), "ad_head_ln_bwd")
+    return dz
+
+
 def adam_step(p, g, m, v, step: int, lr=1e-4, b1=0.9, b2=0.999, eps=1e-7, gscale: float = 1.0):
     with _timed("adam_step"):
         check(_lib.load().ad_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, b1, b2, eps, step, gscale, _stream()),

@@ -203,6 +203,19 @@ int ad_head_bwd(const void* xh, const float* w, const float* b, const float* inp
                 const float* loss_scale /* NULL, or device float: g is multiplied by loss_scale[0] (ad_loss_scale_*) */,
                 void* ws, size_t ws_bytes, int dtype, void* stream);
 
+/* ad_head_bwd and the LayerNormalization + ReLU backward of the conv_block layer that feeds the head
+ * (train_adaptive_unet.py:265-276: head_conv's second Conv2D -> LayerNormalization -> ReLU -> residual_rgb) in one
+ * pass over the pixels: the gradient of the head activations stays in fp32 registers instead of being stored and read
+ * back.  Inputs as ad_head_bwd plus that layer's saved conv output z, per-pixel mean / rstd and gamma / beta;
+ *   dz[npix,ch] = LayerNorm/ReLU backward of (g @ w^T)        (what ad_layernorm_relu_bwd would return)
+ *   dw, db: as ad_head_bwd;  dgamma, dbeta: the LayerNorm's;  dbias_conv[ch] = column sums of dz as stored. */
+size_t ad_head_ln_bwd_ws_bytes(int n, int ch);
+int ad_head_ln_bwd(const void* xh, const float* w, const float* b, const float* inp, const float* target,
+                   const void* z, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                   void* dz, float* dw, float* db, float* dgamma, float* dbeta, float* dbias_conv,
+                   int n, int64_t pix_per_img, int ch, int loss_kind, float eps, float grad_scale,
+                   const float* loss_scale, void* ws, size_t ws_bytes, int dtype, void* stream);
+
 /* -------------------------------------------------------------- optimizer -- */
 
 /* Keras-form Adam (tf.keras.optimizers.Adam, train_adaptive_unet.py:489-494):

@@ -127,21 +127,48 @@ def audit_sr_step(model, lr, hr):
             slack = np.abs(ref.charbonnier_bwd(f64(target), want_out) * edge).sum() * np.abs(f64(xh)).max()
             check_f32(G["residual_rgb/kernel"], dw, "residual_rgb/kernel grad", slack=slack)
             check_f32(G["residual_rgb/bias"], db, "residual_rgb/bias grad", slack=slack)
-        elif kind == "bwd_cla":
-            _, _, x1, x2, z, mean, rstd, d_in, dz, d, dsk, fused_relu = rec
-            ln = model.convs[name].ln
+        elif kind == "bwd_head_ln":
+            # head backward + LayerNorm/ReLU backward of the layer feeding the head in one kernel: the gradient of the
+            # head activations is never stored, so the oracle chains the two steps without rounding in between
+            _, _, xh, inp, target, gscale, cname, z, mean, rstd, dz = rec
+            seen.add("bwd_head")
+            r = ref.conv2d_same_fwd(f64(xh), W["residual_rgb/kernel"], W["residual_rgb/bias"])
+            want_out, pre = ref.clip_add_fwd(f64(inp), r)
+            dout = ref.charbonnier_bwd(f64(target), want_out)
+            dr = ref.clip_add_bwd(dout, pre)
+            edge = (np.abs(pre) < KINK) | (np.abs(pre - 1.0) < KINK)
+            dxh, dw, db = ref.conv2d_same_bwd(f64(xh), W["residual_rgb/kernel"], dr)
+            slack = np.abs(dout * edge).sum() * np.abs(f64(xh)).max()
+            check_f32(G["residual_rgb/kernel"], dw, "residual_rgb/kernel grad", slack=slack)
+            check_f32(G["residual_rgb/bias"], db, "residual_rgb/bias grad", slack=slack)
+            ln = model.convs[cname].ln
             gam, bet = W[ln + "/gamma"], W[ln + "/beta"]
             zs = f64(z)
             mu = mean.cpu().numpy().astype(np.float64).reshape(zs.shape[:-1] + (1,))
             rs = rstd.cpu().numpy().astype(np.float64).reshape(zs.shape[:-1] + (1,))
             xhat = (zs - mu) * rs
             y = xhat * gam + bet
-            din = f64(d_in)
-            res = [ref.layernorm_bwd(din * (y > thr), gam, (xhat, rs)) for thr in (0.0, KINK, -KINK)]
-            ok = ~(np.abs(y) <= KINK).any(axis=-1)             # pixels without an element on the ReLU kink
-            check_stored_masked(f64(dz), res[0][0], ok, name + " dz", bf16)
+            res = [ref.layernorm_bwd(dxh * (y > thr), gam, (xhat, rs)) for thr in (0.0, KINK, -KINK)]
+            ok = ~(np.abs(y) <= KINK).any(axis=-1) & ~edge.any(axis=-1)
+            check_stored_masked(f64(dz), res[0][0], ok, cname + " dz (fused with the head)", bf16)
             for j, pname in ((1, ln + "/gamma"), (2, ln + "/beta")):
-                check_f32(G[pname], res[0][j], pname + " grad", slack=np.abs(res[1][j] - res[2][j]))
+                check_f32(G[pname], res[0][j], pname + " grad", slack=np.abs(res[1][j] - res[2][j]) + slack)
+        elif kind == "bwd_cla":
+            _, _, x1, x2, z, mean, rstd, d_in, dz, d, dsk, fused_relu = rec
+            ln = model.convs[name].ln
+            if d_in is not None:              # (None: this layer's dz came out of the fused head kernel, checked above)
+                gam, bet = W[ln + "/gamma"], W[ln + "/beta"]
+                zs = f64(z)
+                mu = mean.cpu().numpy().astype(np.float64).reshape(zs.shape[:-1] + (1,))
+                rs = rstd.cpu().numpy().astype(np.float64).reshape(zs.shape[:-1] + (1,))
+                xhat = (zs - mu) * rs
+                y = xhat * gam + bet
+                din = f64(d_in)
+                res = [ref.layernorm_bwd(din * (y > thr), gam, (xhat, rs)) for thr in (0.0, KINK, -KINK)]
+                ok = ~(np.abs(y) <= KINK).any(axis=-1)             # pixels without an element on the ReLU kink
+                check_stored_masked(f64(dz), res[0][0], ok, name + " dz", bf16)
+                for j, pname in ((1, ln + "/gamma"), (2, ln + "/beta")):
+                    check_f32(G[pname], res[0][j], pname + " grad", slack=np.abs(res[1][j] - res[2][j]))
             # conv backward on the product's own dz
             dzp = f64(dz)
             xin = conv_input(name, x1, x2)
