@@ -544,27 +544,6 @@ class Model:
         d = None
         relu_done = False
         dz_ready = None           # dz of the next "cla" record when the head's backward already produced it
-        # Weight gradients hang off the critical chain (LayerNorm-bwd -> dgrad -> LayerNorm-bwd ...): they are issued on
-        # a second HIP stream (own workspace) and overlap the dgrad / LayerNorm-backward launches of the main stream --
-        # measured on the full-resolution 64-channel layers: wgrad || dgrad 0.531 ms against 0.618 ms back to back,
-        # wgrad || LayerNorm-bwd 0.575 against 0.641 (tools/overlap_probe.py).  The streams fork where dz is final and
-        # join once, before the optimizer; under hipGraph capture that is a graph with two branches.  Not used under
-        # DataParallel (its bucket hooks close graph segments in the middle of the backward pass).
-        use_side = (x.is_cuda and self.grad_ready is None and os.environ.get("ADUNET_NO_SIDE_STREAM") != "1")
-        if use_side and self.__dict__.get("_side") is None:
-            self._side = torch.cuda.Stream(device=self.device)
-            self._ws_side = ops.Workspace(self.device)
-        main_stream = torch.cuda.current_stream() if use_side else None
-        keep = []                 # operands of in-flight side-stream launches: not to be recycled by the allocator
-
-        def wgrad_on_side(fn, *operands):
-            if not use_side:
-                return fn(ws)
-            self._side.wait_stream(main_stream)
-            with torch.cuda.stream(self._side):
-                fn(self._ws_side)
-            keep.append(operands)
-
         while tape:
             rec = tape.pop()
             kind = rec[0]
@@ -604,11 +583,9 @@ class Model:
                                                 self.grad(cs.ln + "/gamma"), self.grad(cs.ln + "/beta"),
                                                 self.grad(cs.name + "/bias"), ws)
                 if x1.dtype == torch.float32 and self.dtype != torch.float32:      # raw 3-channel batch: first layer
-                    wgrad_on_side(lambda w_, x1=x1, dz=dz, cs=cs: ops.conv3x3_c3_wgrad(x1, dz, self.grad(cs.name + "/kernel"), w_),
-                                  x1, dz)
+                    ops.conv3x3_c3_wgrad(x1, dz, self.grad(cs.name + "/kernel"), ws)
                 else:
-                    wgrad_on_side(lambda w_, x1=x1, x2=x2, dz=dz, cs=cs: ops.conv3x3_wgrad(
-                        x1, x2, dz, self.grad(cs.name + "/kernel"), cs.cin, w_), x1, x2, dz)
+                    ops.conv3x3_wgrad(x1, x2, dz, self.grad(cs.name + "/kernel"), cs.cin, ws)
                 self._done(cs.name + "/kernel")
                 dsk = None
                 fused_relu = False
@@ -638,8 +615,7 @@ class Model:
                 # (already the pre-activation gradient, bias gradient included, when the dgrad above fused the ReLU)
                 dz = d if relu_done else ops.relu_bwd(d, u, self.grad(cs.name + "/bias"), ws)
                 relu_done = False
-                wgrad_on_side(lambda w_, xin=xin, dz=dz, cs=cs: ops.conv3x3_wgrad(xin, None, dz, self.grad(cs.name + "/kernel"),
-                                                                                  cs.cin, w_), xin, dz)
+                ops.conv3x3_wgrad(xin, None, dz, self.grad(cs.name + "/kernel"), cs.cin, ws)
                 self._done(cs.name + "/kernel")
                 d = ops.conv3x3_fwd(dz, None, self._packs[cs.name][1], None, cs.cin)
                 if audit is not None:
@@ -656,9 +632,6 @@ class Model:
                 d = self.enc_down.resize_grad(d, h, w, out=acc)
                 if audit is not None:
                     audit.append(("bwd_resize", "enc_down", d_in, before, d))
-        if use_side:
-            main_stream.wait_stream(self._side)            # every weight gradient is final from here on
-            keep.clear()
 
     def _done(self, name: str):
         if self.grad_ready is not None:
