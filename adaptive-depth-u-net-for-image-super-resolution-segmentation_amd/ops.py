@@ -232,7 +232,7 @@ def conv3x3_dgrad_relu(dz: torch.Tensor, w_dgrad: torch.Tensor, relu_out: torch.
     y2 = torch.empty((n, h, w, cout - cy1), dtype=dz.dtype, device=dz.device) if cy1 < cout else None
     lib = _lib.load()
     ws.ensure(lib.ad_conv3x3_dgrad_relu_ws_bytes())
-    with _timed("conv3x3_fwd", 2.0 * n * h * w * 9 * c1 * cout, float(n * h * w * (c1 + cout + cy1) * dz.element_size())):
+    with _timed("conv3x3_dgrad_relu", 2.0 * n * h * w * 9 * c1 * cout, float(n * h * w * (c1 + cout + cy1) * dz.element_size())):
         check(lib.ad_conv3x3_dgrad_relu(_p(dz), c1, _p(w_dgrad), _p(relu_out), _p(y1), cy1, _p(y2), _p(dbias), n, h, w, cout,
                                         ws.ptr, ws.nbytes, dt(dz.dtype), _stream()), "ad_conv3x3_dgrad_relu")
     return y1, y2

@@ -288,6 +288,9 @@ def main():
             "fused_ln_fwd": family(["conv3x3_ln_relu_fwd", "conv3x3_c3_ln_relu_fwd"],
                                    padded_first if args.dtype != "f32" else 0.0),
             "wgrad": family(["conv3x3_wgrad", "conv3x3_c3_wgrad"], padded_first),
+            # dgrad launches that also apply the up-conv's ReLU gradient and sum its bias gradient in their epilogue (an extra
+            # 128 B/pixel stream through the MFMA waves; replaces a separate relu_bwd pass)
+            "dgrad_relu_fused": family(["conv3x3_dgrad_relu"]),
         }
         conv_ms = sum(f["ms_per_step"] for f in fam.values())
         conv_gf = sum(f["gflop_per_step"] for f in fam.values())

@@ -113,3 +113,31 @@ def test_segmentation_train_entry_point(device, tmp_path):
     assert not (tmp_path / "logs" / "segrun" / "train_backup" / "backup.safetensors").exists()
     with pytest.raises(FileNotFoundError):
         T.train(T.parse_args(["--protocol", "A"]))
+
+
+def test_bench_plain_and_under_torchrun_agree(device):
+    """The driver starts N = 1 as `python bench.py --gpus 1 ...` and N > 1 through torch.distributed.run: both start-up
+    paths must run and report the same workload (throughput within 5 %; at world size 1 the second goes through RCCL,
+    the bucketed all-reduce and the segmented graph replay)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    flags = ["--gpus", "1", "--steps", "8", "--warmup", "3", "--no-cpu-baseline", "--no-micro"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    plain = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + flags, capture_output=True, text=True, timeout=600,
+                           env=env, cwd=root)
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    dist_run = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+                               "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py")] + flags,
+                              capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert dist_run.returncode == 0, dist_run.stderr[-2000:]
+    a = json.loads(plain.stdout.strip().splitlines()[-1])
+    b = json.loads(dist_run.stdout.strip().splitlines()[-1])
+    assert a["metric"] == b["metric"] and a["config"]["workload"] == b["config"]["workload"] and a["n_gpus"] == b["n_gpus"] == 1
+    assert b["rccl_ranks"] == 1 and b["exposed_comm_ms_per_step"] is not None and "rccl_ranks" not in a
+    assert abs(a["value"] - b["value"]) < 0.05 * a["value"], (a["value"], b["value"])
+    for line in (a, b):
+        rf = line["roofline"]
+        assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "frac_step", "families"} <= set(rf)
+        assert 0.2 < rf["frac"] < 1.0 and 0.1 < rf["frac_step"] < rf["frac"]

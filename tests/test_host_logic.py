@@ -118,3 +118,42 @@ def test_losses_contract():
     assert build_losses_and_metrics("l1")[0].__name__ == "l1_loss"
     with pytest.raises(ValueError, match="Unknown loss"):
         build_losses_and_metrics("mse")
+
+
+def test_bench_starts_its_own_ranks_for_n_gpus(monkeypatch):
+    """`python bench.py --gpus N` (no torchrun) must start N ranks itself: one child `python -m torch.distributed.run
+    --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same flags>` and its return code becomes ours;
+    nothing in the parent touches the GPU before that."""
+    import importlib.util
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    calls = []
+
+    class Done:
+        returncode = 7
+
+    def fake_run(cmd, env=None, **kw):
+        calls.append((cmd, env))
+        return Done()
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "5", "--warmup", "2"])
+    for var in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(var, raising=False)
+    import torch
+
+    def boom(*a, **k):
+        raise AssertionError("the launching parent must not touch the GPU")
+
+    monkeypatch.setattr(torch.cuda, "set_device", boom)
+    with pytest.raises(SystemExit) as exc:
+        bench.main()
+    assert exc.value.code == 7
+    (cmd, env), = calls
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "5", "--warmup", "2"]
+    assert cmd[-7].endswith("bench.py") and env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

@@ -19,6 +19,7 @@ FAMILIES = {       # kernel name -> op family used by bench.py's roofline ("_ln"
     "conv3x3_fwd_wres_kernel": "conv3x3_fwd", "conv3x3_fwd_ws_kernel": "conv3x3_fwd", "conv3x3_fwd_kernel": "conv3x3_fwd",
     "splitk_finalize_kernel": "conv3x3_fwd",
     "conv3x3_fwd_wres_kernel_ln": "conv3x3_ln_relu_fwd", "conv3x3_fwd_ws_kernel_ln": "conv3x3_ln_relu_fwd",
+    "conv3x3_fwd_wres_kernel_relugrad": "conv3x3_dgrad_relu",
     "conv3x3_wgrad_kernel": "conv3x3_wgrad", "conv3x3_wgrad_ws_kernel": "conv3x3_wgrad", "wgrad_reduce_kernel": "conv3x3_wgrad",
 }
 
@@ -26,6 +27,8 @@ FAMILIES = {       # kernel name -> op family used by bench.py's roofline ("_ln"
 def short(name):
     if re.search(r"conv3x3_fwd_w(res|s)_kernel", name) and ("Li2EEE" in name or re.search(r", 2>", name)):
         return re.search(r"conv3x3_fwd_w(?:res|s)_kernel", name).group(0) + "_ln"
+    if re.search(r"conv3x3_fwd_wres_kernel", name) and ("Li3EEE" in name or re.search(r", 3>", name)):
+        return "conv3x3_fwd_wres_kernel_relugrad"
     name = re.sub(r"^void ", "", name).replace("(anonymous namespace)::", "")
     m = re.match(r"_ZN12_GLOBAL__N_1\d+([a-z0-9_]+?_kernel)", name)
     if m:
@@ -61,8 +64,14 @@ def main():
             g["hbm_bytes"] += (2.0 * k["fetch_kib_raw"] + k["write_kib"]) * 1024.0
     for g in fam.values():
         g["hbm_bytes_per_launch"] = g["hbm_bytes"] / g["launches"]
+    # the kernel sources these passes were taken on: bench.py quotes the figure only while that stamp still matches
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
     json.dump({"correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950, MI355X_MICROARCH.md)",
-               "kernels": per, "families": fam}, open(out, "w"), indent=1)
+               "kernel_source_stamp": bench.kernel_source_stamp(), "kernels": per, "families": fam}, open(out, "w"), indent=1)
     for name, k in sorted(per.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"]):
         print(f"{name:34s} launches={k['launches']:4d}  {k['hbm_bytes_per_launch'] / 1e6:10.2f} MB/launch")
 
