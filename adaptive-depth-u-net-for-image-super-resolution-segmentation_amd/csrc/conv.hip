@@ -1857,16 +1857,22 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 // dbias[c] = sum over the MFMA-wave rows of the workgroups that own output block c / 64 (ws_order: workgroup b owns
-// block (b >> 3) % nblk), ascending row order: deterministic.  One thread per channel.
-__global__ void mask_dbias_reduce_kernel(const float* __restrict__ part, int nwg, int nblk, int cy1, float* __restrict__ dbias) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= cy1) return;
-    const int blk = c / BN, col = c % BN;
+// block (b >> 3) % nblk).  One block per output block: 64 channels x 4 row groups, each group walks its rows in
+// ascending order and the four partial sums are folded in a fixed order: deterministic.
+__global__ __launch_bounds__(256) void mask_dbias_reduce_kernel(const float* __restrict__ part, int nwg, int nblk, int cy1,
+                                                                float* __restrict__ dbias) {
+    __shared__ float sm[4][BN];
+    const int blk = blockIdx.x, col = threadIdx.x & 63, rg = threadIdx.x >> 6;
     float s = 0.f;
-    for (int b = 0; b < nwg; ++b)
-        if ((b >> 3) % nblk == blk)
-            for (int wv = 0; wv < 4; ++wv) s += part[((size_t)b * 4 + wv) * BN + col];
-    dbias[c] = s;
+    int k = 0;
+    for (int b = 0; b < nwg; ++b) {
+        if ((b >> 3) % nblk != blk) continue;
+        for (int wv = 0; wv < 4; ++wv, ++k)
+            if ((k & 3) == rg) s += part[((size_t)b * 4 + wv) * BN + col];
+    }
+    sm[rg][col] = s;
+    __syncthreads();
+    if (rg == 0 && blk * BN + col < cy1) dbias[blk * BN + col] = (sm[0][col] + sm[1][col]) + (sm[2][col] + sm[3][col]);
 }
 
 // ------------------------------------------------------------------ weight packing
@@ -2299,7 +2305,7 @@ extern "C" int ad_conv3x3_dgrad_relu(const void* dz, int c1, const void* w_dgrad
     hipStream_t s = (hipStream_t)stream;
     const int rc = launch_fwd_dtype(dtype, a, nullptr, 0, s);
     if (rc) return rc == AD_ERR_UNFUSED ? ad_set_error(AD_ERR_ARG, "ad_conv3x3_dgrad_relu: launch not specialised") : rc;
-    mask_dbias_reduce_kernel<<<(cy1 + 63) / 64, 64, 0, s>>>((const float*)ws, NUM_CU, cout / BN, cy1, dbias);
+    mask_dbias_reduce_kernel<<<(cy1 + BN - 1) / BN, 256, 0, s>>>((const float*)ws, NUM_CU, cout / BN, cy1, dbias);
     AD_LAUNCH_CHECK("mask_dbias_reduce");
     return AD_OK;
 }
