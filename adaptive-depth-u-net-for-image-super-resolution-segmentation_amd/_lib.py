@@ -47,6 +47,9 @@ SIGNATURES = {
     "ad_layernorm_relu_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _sz, _i, _vp]),
     "ad_relu_bwd": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _vp, _sz, _i, _vp]),
     "ad_resample": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "ad_resample_ln_bwd_supported": (_i, [_i, _i, _i, _i, _i, _i]),
+    "ad_resample_ln_bwd_ws_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "ad_resample_ln_bwd": (_i, [_vp] * 11 + [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _i, _vp]),
     "ad_head_ws_bytes": (_sz, [_i, _i]),
     "ad_head_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _f, _vp, _sz, _i, _vp]),
     "ad_head_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _f, _f, _vp, _vp, _sz, _i, _vp]),

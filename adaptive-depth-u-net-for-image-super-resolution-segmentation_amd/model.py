@@ -628,10 +628,24 @@ class Model:
             elif kind == "down":
                 _, lvl, h, w = rec
                 d_in, acc = d, dskips.pop(lvl)
-                before = acc.clone() if audit is not None else None        # the skip gradient is accumulated into in place
-                d = self.enc_down.resize_grad(d, h, w, out=acc)
-                if audit is not None:
-                    audit.append(("bwd_resize", "enc_down", d_in, before, d))
+                nxt = tape[-1] if tape else None
+                tab = self.enc_down.tables(h, w, d.shape[1], d.shape[2], d.device, transposed=True)
+                if (nxt is not None and nxt[0] == "cla" and nxt[4].shape == acc.shape and ops.resample_ln_bwd_supported(acc, tab)
+                        and os.environ.get("ADUNET_NO_SKIP_LN_FUSION") != "1"):
+                    # the skip's gradient junction and the LayerNorm/ReLU backward of the block that produced the skip in
+                    # one pass: dskip + enc_down^T(d) stays in registers, dz of that block comes out
+                    _, hcs, _, _, hz, hmean, hrstd, _ = nxt
+                    dz_ready = ops.resample_ln_bwd(d, tab, acc, hz, hmean, hrstd, self.param(hcs.ln + "/gamma"),
+                                                   self.param(hcs.ln + "/beta"), self.grad(hcs.ln + "/gamma"),
+                                                   self.grad(hcs.ln + "/beta"), self.grad(hcs.name + "/bias"), ws)
+                    d = None
+                    if audit is not None:
+                        audit.append(("bwd_resize_ln", "enc_down", d_in, acc, hcs.name, hz, hmean, hrstd, dz_ready))
+                else:
+                    before = acc.clone() if audit is not None else None    # the skip gradient is accumulated into in place
+                    d = self.enc_down.resize_grad(d, h, w, out=acc)
+                    if audit is not None:
+                        audit.append(("bwd_resize", "enc_down", d_in, before, d))
 
     def _done(self, name: str):
         if self.grad_ready is not None:

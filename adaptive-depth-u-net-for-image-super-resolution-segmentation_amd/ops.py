@@ -375,6 +375,26 @@ def resample(x: torch.Tensor, tab: ResampleTables, out: Optional[torch.Tensor] =
     return out
 
 
+def resample_ln_bwd_supported(dskip: torch.Tensor, tab: ResampleTables) -> bool:
+    n, oh, ow, c = dskip.shape
+    return bool(_lib.load().ad_resample_ln_bwd_supported(n, oh, ow, c, tab.kx, dt(dskip.dtype)))
+
+
+def resample_ln_bwd(d_low, tab: ResampleTables, dskip, z, mean, rstd, gamma, beta, dgamma, dbeta, dbias, ws: Workspace):
+    """dz of the conv_block that produced a skip tensor: LayerNorm/ReLU backward of (dskip + resample^T(d_low)) in one
+    pass (the sum is never stored).  `tab`: the transposed tables of the down-resize."""
+    n, h, w, c = d_low.shape
+    _, oh, ow, _ = dskip.shape
+    dz = torch.empty_like(z)
+    lib = _lib.load()
+    ws.ensure(lib.ad_resample_ln_bwd_ws_bytes(n, oh, ow, c, dt(z.dtype)))
+    with _timed("resample_ln_bwd"):
+        check(lib.ad_resample_ln_bwd(_p(d_low), _p(dskip), _p(z), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dz), _p(dgamma),
+                                     _p(dbeta), _p(dbias), _p(tab.sy), _p(tab.wy), tab.ky, _p(tab.sx), _p(tab.wx), tab.kx,
+                                     n, h, w, oh, ow, c, ws.ptr, ws.nbytes, dt(z.dtype), _stream()), "ad_resample_ln_bwd")
+    return dz
+
+
 def head_fwd(xh, w, b, inp, target, ws: Workspace, loss_kind: int = 0, eps: float = CHARBONNIER_EPS):
     """Returns (out[n,h,w,3] fp32, stats[3] = (loss SUM, mean PSNR, loss MEAN) or None, sqerr[n] or None)."""
     n, h, wd, ch = xh.shape

@@ -308,6 +308,19 @@ size_t ad_conv3x3_dgrad_relu_ws_bytes(void);
 int ad_conv3x3_dgrad_relu(const void* dz, int c1, const void* w_dgrad, const void* relu_out, void* y1, int cy1, void* y2,
                           float* dbias, int n, int h, int w, int cout, void* ws, size_t ws_bytes, int dtype, void* stream);
 
+/* The skip connection's gradient junction (train_adaptive_unet.py:247-250: `skips.append(x); x = enc_down(x)`) fused
+ * with the LayerNorm + ReLU backward of the conv_block that produced the skip:
+ *   d(act) = dskip + ResizeByScale^T d_low       (= ad_resample(..., accumulate = 1) into dskip)
+ *   dz, dgamma, dbeta, dbias = LayerNorm/ReLU backward of d(act)      (= ad_layernorm_relu_bwd)
+ * in one pass, d(act) never stored.  Tables as ad_resample (transposed spans).  Shapes ad_resample_ln_bwd_supported()
+ * accepts: c / (16 B of dtype) a power of two <= 64, ow * that a multiple of 256, kx <= 8. */
+int ad_resample_ln_bwd_supported(int n, int oh, int ow, int c, int kx, int dtype);
+size_t ad_resample_ln_bwd_ws_bytes(int n, int oh, int ow, int c, int dtype);
+int ad_resample_ln_bwd(const void* d_low, const void* dskip, const void* z, const float* mean, const float* rstd,
+                       const float* gamma, const float* beta, void* dz, float* dgamma, float* dbeta, float* dbias,
+                       const int* sy, const float* wy, int ky, const int* sx, const float* wx, int kx,
+                       int n, int h, int w, int oh, int ow, int c, void* ws, size_t ws_bytes, int dtype, void* stream);
+
 /* ------------------------------------------------------------- feed path -- */
 
 /* LR synthesis on the device (shared/pipeline.py:79-94 degrade_image, applied to a whole HR batch in HBM by two

@@ -193,13 +193,31 @@ def audit_sr_step(model, lr, hr):
             check_f32(G[name + "/kernel"], dw, name + "/kernel grad")
             check_f32(G[name + "/bias"], db, name + "/bias grad")
             check_stored(d, dx, name + " dgrad", bf16)
+        elif kind == "bwd_resize_ln":
+            # skip-gradient junction + LayerNorm/ReLU backward of the block that produced the skip, one kernel: the
+            # oracle chains resize^T, the add and the LayerNorm backward without rounding in between
+            _, _, d_in, dskip, cname, z, mean, rstd, dz = rec
+            seen.add("bwd_resize")
+            da = ref.resize_aa_bwd(f64(d_in), dskip.shape[1], dskip.shape[2]) + f64(dskip)
+            ln = model.convs[cname].ln
+            gam, bet = W[ln + "/gamma"], W[ln + "/beta"]
+            zs = f64(z)
+            mu = mean.cpu().numpy().astype(np.float64).reshape(zs.shape[:-1] + (1,))
+            rs = rstd.cpu().numpy().astype(np.float64).reshape(zs.shape[:-1] + (1,))
+            xhat = (zs - mu) * rs
+            y = xhat * gam + bet
+            res = [ref.layernorm_bwd(da * (y > thr), gam, (xhat, rs)) for thr in (0.0, KINK, -KINK)]
+            ok = ~(np.abs(y) <= KINK).any(axis=-1)
+            check_stored_masked(f64(dz), res[0][0], ok, cname + " dz (fused with the skip junction)", bf16)
+            for j, pname in ((1, ln + "/gamma"), (2, ln + "/beta")):
+                check_f32(G[pname], res[0][j], pname + " grad", slack=np.abs(res[1][j] - res[2][j]))
         elif kind == "bwd_resize":
             _, _, d_in, before, d = rec
             want = ref.resize_aa_bwd(f64(d_in), d.shape[1], d.shape[2])
             if before is not None:
                 want = want + f64(before)
             check_stored(d, want, name + " bwd", bf16)
-    assert seen - {"fused_relu_grad", "bwd_head_ln"} == {"fwd_cla", "fwd_resize", "fwd_ca", "fwd_head", "bwd_head", "bwd_cla", "bwd_ca",
+    assert seen - {"fused_relu_grad", "bwd_head_ln", "bwd_resize_ln"} == {"fwd_cla", "fwd_resize", "fwd_ca", "fwd_head", "bwd_head", "bwd_cla", "bwd_ca",
                                                         "bwd_resize"}
     return len(records), "fused_relu_grad" in seen
 
