@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.normpath(os.path.join(HERE, "..", "include"))
 LIB = os.path.join(CSRC, "libadunet_hip.so")
-SOURCES = ["api.hip", "conv.hip", "norm.hip", "resize.hip", "head.hip", "optim.hip", "tier2.hip", "metrics.hip"]
+SOURCES = ["api.hip", "conv.hip", "norm.hip", "resize.hip", "head.hip", "optim.hip", "tier2.hip", "metrics.hip", "comm.hip"]
 ARCH = "gfx950"
 
 
@@ -45,7 +45,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
             subprocess.check_call(cmd)
         objs.append(obj)
     if force or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
-        cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
         if verbose:
             print("[build]", " ".join(cmd), flush=True)
         subprocess.check_call(cmd)

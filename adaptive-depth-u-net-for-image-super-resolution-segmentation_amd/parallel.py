@@ -14,7 +14,8 @@ messages keep every link busy without paying the per-collective latency 20+ time
 """
 from __future__ import annotations
 
-from typing import List, Tuple
+import os
+from typing import List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -35,15 +36,34 @@ def plan_buckets(index, total: int, bucket_elems: int) -> List[Tuple[int, int]]:
     return buckets
 
 
+class _EventWork:
+    """`wait()` of a native all-reduce: the current (compute) stream waits for the event recorded after it."""
+
+    def __init__(self, event):
+        self.event = event
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.event)
+
+
 class DataParallel:
     """Attach to a Model: broadcasts rank-0 weights, then all-reduces gradients bucket by bucket."""
 
-    def __init__(self, model, bucket_bytes: int = 32 << 20, group=None):
+    def __init__(self, model, bucket_bytes: int = 32 << 20, group=None, native: Optional[bool] = None):
+        """native: run the bucket all-reduces through the library's own RCCL entry point (`ad_allreduce_bucket`,
+        include/adunet.h) instead of `torch.distributed.all_reduce`; default from ADUNET_NATIVE_RCCL=1.  torch.distributed
+        is then only the bootstrap channel for the 128-byte RCCL unique id and the initial weight broadcast."""
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.model = model
         self.group = group
         self.world = dist.get_world_size(group)
+        self._comm = None
+        self._native = None
+        if native is None:
+            native = os.environ.get("ADUNET_NATIVE_RCCL") == "1"
+        if native and model.G.is_cuda:
+            self._native = self._create_native_comm(model.G.device, group)
         self.buckets = plan_buckets(model.index, model.count_params(), max(1, bucket_bytes // 4))
         self._next = 0
         self._works = []
@@ -58,8 +78,43 @@ class DataParallel:
         model.grad_sync = self._sync
         model._dp = self
 
+    def _create_native_comm(self, device, group):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        uid = torch.zeros(128, dtype=torch.uint8)
+        if dist.get_rank(group) == 0:
+            buf = (C.c_char * 128)()
+            _lib.check(lib.ad_comm_unique_id(buf), "ad_comm_unique_id")
+            uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+        uid = uid.to(device)
+        dist.broadcast(uid, src=0, group=group)
+        raw = bytes(uid.cpu().tolist())
+        comm = C.c_void_p()
+        torch.cuda.synchronize(device)
+        _lib.check(lib.ad_comm_create(raw, dist.get_rank(group), self.world, C.byref(comm)), "ad_comm_create")
+        self._lib, self._check = lib, _lib.check
+        return comm
+
+    def close(self):
+        """Destroy the native communicator (after the last step, before the process group goes away)."""
+        if self._native is not None:
+            torch.cuda.synchronize()
+            self._check(self._lib.ad_comm_destroy(self._native), "ad_comm_destroy")
+            self._native = None
+
     def _launch(self, lo: int, hi: int):
         g = self.model.G[lo:hi]
+        if self._native is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self._comm.wait_event(ev)
+            self._check(self._lib.ad_allreduce_bucket(self._native, g.data_ptr(), hi - lo, self._comm.cuda_stream),
+                        "ad_allreduce_bucket")
+            done = torch.cuda.Event()
+            done.record(self._comm)
+            self._works.append(_EventWork(done))
+            return
         if self._cuda:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())

@@ -212,7 +212,7 @@ def main():
     # non-degenerate head so that every gradient is exercised (SURVEY 8d workload recipe)
     model.set_weights(model.initial_weights(np.random.default_rng(1234), head_uniform=0.05))
     if use_dist:
-        DataParallel(model)
+        DataParallel(model)            # ADUNET_NATIVE_RCCL=1: bucket all-reduces through the library's ad_allreduce_bucket
     lr_img, hr_img = synth_batch(rank, batch, patch, device)
 
     def sync():
@@ -333,12 +333,14 @@ def main():
         if use_dist:
             line["rccl_ranks"] = dist.get_world_size()
             line["exposed_comm_ms_per_step"] = exposed_ms
+            line["exchange"] = "ad_allreduce_bucket" if model._dp._native is not None else "torch.distributed.all_reduce"
         if world == 1 and args.dtype == "bf16" and not args.no_micro:
             line["micro"] = micro_kernel(device)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(scale, depth, patch, args.workload)
         print(json.dumps(line), flush=True)
     if use_dist:
+        model._dp.close()
         del step_fn, model            # graphs and side streams go before the communicator they reference
         torch.cuda.synchronize()
         dist.barrier()

@@ -321,6 +321,18 @@ int ad_resample_ln_bwd(const void* d_low, const void* dskip, const void* z, cons
                        const int* sy, const float* wy, int ky, const int* sx, const float* wx, int kx,
                        int n, int h, int w, int oh, int ow, int c, void* ws, size_t ws_bytes, int dtype, void* stream);
 
+/* ------------------------------------------------------- gradient exchange -- */
+
+/* Data parallelism over patches (the reference is single-GPU): one process per GPU, the flat fp32 gradient
+ * buffer is summed across ranks bucket by bucket with RCCL over xGMI, in place, on a communication stream the caller
+ * orders against its compute stream with events; the optimizer applies 1/world.  The communicator is created from a
+ * 128-byte unique id that rank 0 obtains and the host distributes (any channel: torch.distributed, a file, MPI).
+ * RCCL is loaded with dlopen at the first call. */
+int ad_comm_unique_id(void* id128);
+int ad_comm_create(const void* id128, int rank, int world, void** comm);
+int ad_comm_destroy(void* comm);
+int ad_allreduce_bucket(void* comm, float* grads, int64_t count, void* stream);
+
 /* ------------------------------------------------------------- feed path -- */
 
 /* LR synthesis on the device (shared/pipeline.py:79-94 degrade_image, applied to a whole HR batch in HBM by two

@@ -141,3 +141,21 @@ def test_bench_plain_and_under_torchrun_agree(device):
         rf = line["roofline"]
         assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "frac_step", "families"} <= set(rf)
         assert 0.2 < rf["frac"] < 1.0 and 0.1 < rf["frac_step"] < rf["frac"]
+
+
+def test_experiment_sweep_launcher(device, tmp_path):
+    """Two rows of the Experiment-2 table end to end: per-run metadata files with the reference's keys, checkpoints,
+    and the summary table with the offline Y-channel metrics."""
+    from adunet_amd import run_experiment_adaptive_depth as R
+    hr = tmp_path / "hr"
+    hr.mkdir()
+    _pngs(hr, 8, size=64)
+    rows = R.run(R.parse_args(["--high_res_dir", str(hr), "--output_root", str(tmp_path / "exp"), "--scales", "0.30", "0.50",
+                               "--epochs", "1", "--patch_size", "32", "--patches_per_image", "2", "--learning_rate", "1e-3",
+                               "--reference_batch_sizes", "--bf16"]))
+    assert [r["depth"] for r in rows] == [2, 3] and all(r["psnr_y"] > 5 and r["samples"] > 0 for r in rows)
+    metas = sorted((tmp_path / "exp" / "metadata").glob("exp2_adaptive_depth_scale*.txt"))
+    assert len(metas) == 2 and set(l.split("=")[0] for l in metas[0].read_text().splitlines()) == {
+        "scale", "batch_size", "depth", "run_name", "log_dir", "model_dir", "submitted"}
+    table = (tmp_path / "exp" / "metadata" / "summary.csv").read_text().splitlines()
+    assert table[0].startswith("scale,depth,batch_size,run_name") and len(table) == 3

@@ -157,3 +157,17 @@ def test_bench_starts_its_own_ranks_for_n_gpus(monkeypatch):
     assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "4"
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "5", "--warmup", "2"]
     assert cmd[-7].endswith("bench.py") and env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_experiment_2_sweep_table_matches_the_reference_launcher():
+    """Super_resolution/sbatch_scripts/run_experiment_adaptive_depth.sh:36-65: scales, depth per scale, run names, and the
+    2080 Ti batch sizes (behind --reference_batch_sizes)."""
+    from adunet_amd import run_experiment_adaptive_depth as R
+    table = R.plan(reference_batch_sizes=True)
+    assert [t["scale"] for t in table] == ["0.20", "0.30", "0.40", "0.50", "0.60", "0.70", "0.80"]
+    assert [t["depth"] for t in table] == [1, 2, 3, 3, 4, 5, 5]
+    assert [t["batch_size"] for t in table] == [8, 8, 6, 4, 3, 2, 1]
+    assert table[3]["run_name"] == "exp2_adaptive_depth_scale0.50"
+    assert all(t["batch_size"] >= r["batch_size"] for t, r in zip(R.plan(), table))
+    args = R.parse_args(["--high_res_dir", "/x", "--scales", "0.30", "0.50"])
+    assert args.scales == ["0.30", "0.50"] and args.patch_size == 256 and args.epochs == 100

@@ -332,9 +332,11 @@ def test_graph_replayed_step_equals_eager_step(device):
     assert torch.equal(results[0][1], results[1][1])
 
 
-def test_segmented_graph_step_under_data_parallel(device):
+@pytest.mark.parametrize("native", [False, True], ids=["torch.distributed", "ad_allreduce_bucket"])
+def test_segmented_graph_step_under_data_parallel(device, native):
     """DataParallel (world size 1 on RCCL): the step is captured as several graph segments with the bucket all-reduces
-    launched eagerly in between; it must follow the eager data-parallel trajectory bit for bit."""
+    launched eagerly in between; it must follow the eager data-parallel trajectory bit for bit.  Both exchange paths:
+    torch.distributed.all_reduce and the library's own RCCL entry point (include/adunet.h, ad_allreduce_bucket)."""
     import os
     import torch.distributed as dist
     from adunet_amd.model import Adam, build_losses_and_metrics, build_super_resolution_unet
@@ -355,8 +357,8 @@ def test_segmented_graph_step_under_data_parallel(device):
             model.compile(optimizer=Adam(1e-3), loss=loss, metrics=metrics)
             model._require_device()
             model.set_weights(model.initial_weights(np.random.default_rng(1), head_uniform=0.05))
-            dp = DataParallel(model, bucket_bytes=1 << 20)          # several buckets -> several graph segments
-            assert len(dp.buckets) >= 3
+            dp = DataParallel(model, bucket_bytes=1 << 20, native=native)          # several buckets -> several graph segments
+            assert len(dp.buckets) >= 3 and (dp._native is not None) == native
             if graphed:
                 step = model.make_graphed_train_step(*batches[0])
                 assert len(step.segments) >= 3
@@ -366,6 +368,8 @@ def test_segmented_graph_step_under_data_parallel(device):
                 step(*batches[0]); step(*batches[0])
             losses = [float(step(*b)[0]) for b in batches[1:]]
             results.append((losses, model.P.clone(), model.optimizer.iterations))
+            del step
+            dp.close()
         assert results[0][2] == results[1][2] == 5
         assert results[0][0] == results[1][0]
         assert torch.equal(results[0][1], results[1][1])

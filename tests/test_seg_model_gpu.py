@@ -199,3 +199,22 @@ def test_seg_fit_replays_graphs_and_matches_eager_fit(device, kind, monkeypatch)
     assert results[0][3] == results[1][3] == 6
     assert results[0][0] == results[1][0]
     assert torch.equal(results[0][1], results[1][1]) and torch.equal(results[0][2], results[1][2])
+
+
+def test_segmentation_under_mixed_float16(device):
+    """Segmenation/code/train_adaptive_unet.py:471-476: the seg trainer's --mixed_precision is mixed_float16 too.  The
+    half kernels + dynamic loss scaling drive the BatchNorm model: finite losses that fall, scaler at work."""
+    from adunet_amd import seg_model as S
+    from adunet_amd.model import LossScaleOptimizer
+    rng = np.random.default_rng(2)
+    img = rng.random((4, 32, 32, 3), dtype=np.float32)
+    mask = (img[..., :1] > 0.5).astype(np.float32)                  # learnable: the mask is a threshold of the red channel
+    proto = S.PROTOCOLS["B"]
+    model = S.build_adaptive_depth_unet(32, 64, 2, dtype=torch.float16, device=device, seed=1)
+    model.compile(optimizer=S.build_optimizer(proto, steps_per_epoch=10, epochs=1), loss=proto.loss_builder())
+    assert isinstance(model.optimizer, LossScaleOptimizer)
+    losses = [float(model.train_on_batch(img, mask)[0]) for _ in range(12)]
+    st = model.optimizer.sync()
+    assert all(np.isfinite(v) for v in losses) and losses[-1] < losses[0]
+    assert st["applied"] + st["skipped"] == 12 and st["applied"] >= 8 and st["loss_scale"] >= 1.0
+    assert torch.isfinite(model.P).all()
