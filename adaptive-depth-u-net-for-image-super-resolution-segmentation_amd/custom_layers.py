@@ -169,15 +169,16 @@ class ClippedResidualAdd(Layer):
         inp, residual = inputs
         if inp.shape != residual.shape or inp.shape[-1] != 3:
             raise ValueError("ClippedResidualAdd expects two [N,H,W,3] tensors of equal shape")
-        n, h, w, _ = inp.shape
         dev = inp.device
-        ch = 16  # smallest head width the kernel supports in fp32: embed the residual in 16 channels
-        xh = torch.zeros((n, h, w, ch), dtype=torch.float32, device=dev)
-        xh[..., :3] = residual.to(torch.float32)
-        eye = torch.zeros((ch, 3), dtype=torch.float32, device=dev)
-        eye[0, 0] = eye[1, 1] = eye[2, 2] = 1.0
-        ws = ops.Workspace(dev, 1 << 20)
-        out, _, _ = ops.head_fwd(xh, eye, torch.zeros(3, device=dev), inp.to(torch.float32).contiguous(), None, ws)
+        ch = 16  # smallest head width the kernel supports in fp32: the residual is embedded in 16 channels
+        cache = self.__dict__.setdefault("_consts", {})
+        if dev not in cache:                                   # identity 1x1 kernel, zero bias, scratch: once per device
+            eye = torch.zeros((ch, 3), dtype=torch.float32, device=dev)
+            eye[0, 0] = eye[1, 1] = eye[2, 2] = 1.0
+            cache[dev] = (eye, torch.zeros(3, dtype=torch.float32, device=dev), ops.Workspace(dev, 1 << 20))
+        eye, zero_bias, ws = cache[dev]
+        xh = ops.pad_channels(residual.to(torch.float32).contiguous(), ch, torch.float32)
+        out, _, _ = ops.head_fwd(xh, eye, zero_bias, inp.to(torch.float32).contiguous(), None, ws)
         return out.to(inp.dtype)
 
 
