@@ -26,7 +26,7 @@ SIGNATURES = {
     "ad_conv3x3_pack": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp]),
     "ad_conv3x3_pack_elems": (_sz, [_i, _i, _i]),
     "ad_conv3x3_pack_job_bytes": (_sz, []),
-    "ad_conv3x3_pack_quantum": (_i, []),
+    "ad_conv3x3_pack_job_blocks": (_i, [_i, _i]),
     "ad_conv3x3_pack_batch": (_i, [_vp, _i, _i, _i, _vp]),
     "ad_conv3x3_fwd_ws_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "ad_conv3x3_fwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _sz, _i, _vp]),

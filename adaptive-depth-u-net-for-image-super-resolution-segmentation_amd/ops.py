@@ -159,7 +159,6 @@ class PackBatch:
         rec = np.dtype([("w", "<u8"), ("wf", "<u8"), ("wd", "<u8"), ("cin", "<i4"), ("cout", "<i4"), ("cin_pad", "<i4"),
                         ("first_block", "<i4")])
         assert rec.itemsize == lib.ad_conv3x3_pack_job_bytes()
-        quantum = lib.ad_conv3x3_pack_quantum()
         nblocks = 0
         self.packs = {}
         self._keep = []
@@ -173,7 +172,7 @@ class PackBatch:
             self.packs[name] = (wf, wd)
             self._keep.append(w)
             rows.append((w.data_ptr(), wf.data_ptr(), wd.data_ptr() if wd is not None else 0, cin, cout, cin_pad, nblocks))
-            nblocks += -(-(nf + nd) // quantum)
+            nblocks += lib.ad_conv3x3_pack_job_blocks(cin_pad, cout)
         self.njobs = len(rows)
         self.nblocks = nblocks
         self.dtype = dtype

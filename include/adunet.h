@@ -71,11 +71,10 @@ int ad_conv3x3_pack(const float* w_hwio, int cin, int cout, int cin_pad,
 
 /* The same for up to 64 layers of a model in ONE launch.  jobs_dev: device array of njobs records
  *   struct { const float* w_hwio; void* w_fwd; void* w_dgrad (or NULL); int cin, cout, cin_pad, first_block; }
- * (ad_conv3x3_pack_job_bytes() = 40).  A job owns ceil(elements / ad_conv3x3_pack_quantum()) consecutive blocks,
- * elements = 9*cin_pad*cout (x2 with w_dgrad); first_block is the running sum, nblocks the total.  All layers share
- * dtype.  The table is caller-owned and read at run time, so a captured hipGraph keeps using it. */
+ * (ad_conv3x3_pack_job_bytes() = 40).  A job owns ad_conv3x3_pack_job_blocks(cin_pad, cout) consecutive blocks (one per
+ * 64 x 64 channel tile of each tap); first_block is the running sum, nblocks the total.  All layers share dtype.  The table is caller-owned and read at run time, so a captured hipGraph keeps using it. */
 size_t ad_conv3x3_pack_job_bytes(void);
-int ad_conv3x3_pack_quantum(void);
+int ad_conv3x3_pack_job_blocks(int cin_pad, int cout);
 int ad_conv3x3_pack_batch(const void* jobs_dev, int njobs, int nblocks, int dtype, void* stream);
 
 /* ------------------------------------------------------------ convolution -- */

@@ -321,7 +321,8 @@ def test_pack_batch_equals_single_packs(device, dtype):
     from adunet_amd import ops
     g = torch.Generator(device=device).manual_seed(7)
     gran = ops.cin_granule(dtype)
-    specs = [("a", 3, 64, gran, False), ("b", 64, 64, 64, True), ("c", 128, 64, 128, True), ("d", 64, 192, 64, True)]
+    specs = [("a", 3, 64, gran, False), ("b", 64, 64, 64, True), ("c", 128, 64, 128, True), ("d", 64, 192, 64, True),
+             ("e", 96, 32, 96, True), ("f", 32, 96, 32, True), ("g", 5, 32, 2 * gran, True)]     # partial 64 x 64 tiles
     flat = torch.rand(sum(9 * ci * co for _, ci, co, _, _ in specs), device=device, generator=g) - 0.5
     layers, off = [], 0
     for name, ci, co, pad, dgrad in specs:
