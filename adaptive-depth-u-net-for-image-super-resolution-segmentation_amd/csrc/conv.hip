@@ -117,9 +117,12 @@ struct Pol16 {
     // pipe, not the MFMA, is what saturates first in this kernel.  abase0 = centre-tap offset of m-tile 0.
     // hook(st) is called after the MFMAs of step st (compile-time st): the caller spreads other work (the global
     // stores of the previous item's results) through the MFMA stream.
-    template <typename Hook>
+    // INIT: the first tap step starts the accumulators from c0[nt] (the bias of the lane's four channels of n-tile nt)
+    // instead of reading acc, which saves the 64 v_mov of a separate initialisation per item.
+    template <bool INIT = false, typename Hook>
     static __device__ __forceinline__ void mma_chunk_rows(f32x4 (&acc)[4][4], const char* xt, int abase0, int row_bytes,
-                                                          const char* wt, int lane, const Hook& hook) {
+                                                          const char* wt, int lane, const Hook& hook,
+                                                          const f32x4* c0 = nullptr) {
         v8 wf[2][4], xr[2][6];
         const char* wl = wt + (((lane >> 4) * BN) + (lane & 15)) * 16;
         const char* xl = xt + abase0 - row_bytes - PIXB;       // halo row -1, column -1 of m-tile 0
@@ -143,7 +146,7 @@ struct Pol16 {
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt)
-                    acc[mt][nt] = Half16<E>::mfma(wf[st & 1][nt], xr[dx & 1][mt + dy], acc[mt][nt]);
+                    acc[mt][nt] = Half16<E>::mfma(wf[st & 1][nt], xr[dx & 1][mt + dy], INIT && st == 0 ? c0[nt] : acc[mt][nt]);
             hook(st);
         }
 #undef AD_LOAD_W
@@ -585,6 +588,7 @@ static int pick_ksplit(int nitems, int nch) {
 // LDS: [X0][X1][W chunk0][W chunk1] = 135.9 KB.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int WR_T = 512;                      // threads: 4 MFMA waves + 4 loader waves
 constexpr int WR_XS = 6;                       // halo slots per loader thread (324 pixels x 4 parts / 256)
 constexpr int WR_XB = (324 * PIXB + 15) & ~15; // one halo buffer (31,104 B)
@@ -639,6 +643,10 @@ __device__ __forceinline__ WsOrder ws_order(int ntiles, int nblk) {
 // channels: 16-byte stores, two instructions per 128-byte NHWC row.  pend[0..7]: z (or relu(z), EPI 1) pieces
 // (mt, n-tile pair), pend[8..15]: activation pieces (EPI 2); pvo[mt]: byte offset of the piece, out of range past the
 // image edge.  mean / rstd are stored here (lane group 0).
+__device__ __forceinline__ f32x2 relu2(f32x2 v) {
+    return f32x2{__builtin_amdgcn_fmed3f(v.x, 0.f, __builtin_inff()), __builtin_amdgcn_fmed3f(v.y, 0.f, __builtin_inff())};
+}
+
 template <int EPI, typename E, typename RS>
 __device__ __forceinline__ void ws_pack_tile(const f32x4 (&acc)[4][4], const float* gb, float eps, int wave, int lane,
                                              int img_h, int img_w, int nn, int y0, int x0, int cy, const int (&soff)[4],
@@ -651,48 +659,55 @@ __device__ __forceinline__ void ws_pack_tile(const f32x4 (&acc)[4][4], const flo
     const bool xok = (lane & 15) < img_w - x0;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
+#ifdef AD_DROP_STORES      // diagnostic: how fast is the kernel when nothing is written?
+        const bool ok = false;
+#else
         const bool ok = xok && wave * 4 + mt < img_h - y0;
+#endif
         pvo[mt] = ok ? (unsigned)(tbase + soff[mt]) : WR_OOB;
+        // EPI 2 arithmetic is written on float pairs: v_pk_add / v_pk_mul / v_pk_fma_f32 do two channels per instruction,
+        // and this VALU work sits between the MFMA phases of two items (it is not hidden behind anything)
         float mean = 0.f, rstd = 0.f;
         if (EPI == 2) {
-            float s1 = 0.f, s2 = 0.f;
+            f32x2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { const float v = acc[mt][nt][q]; s1 += v; s2 += v * v; }
-            s1 = sum_lane_groups(s1);
-            s2 = sum_lane_groups(s2);
-            mean = s1 * (1.f / 64.f);
-            rstd = rsqrtf(fmaxf(s2 * (1.f / 64.f) - mean * mean, 0.f) + eps);
+            for (int nt = 0; nt < 4; ++nt) {
+                const f32x2 lo = acc[mt][nt].xy, hi = acc[mt][nt].zw;
+                s1 += lo; s1 += hi;
+                s2 = __builtin_elementwise_fma(lo, lo, s2);
+                s2 = __builtin_elementwise_fma(hi, hi, s2);
+            }
+            const float t1 = sum_lane_groups(s1.x + s1.y);
+            const float t2 = sum_lane_groups(s2.x + s2.y);
+            mean = t1 * (1.f / 64.f);
+            rstd = rsqrtf(fmaxf(t2 * (1.f / 64.f) - mean * mean, 0.f) + eps);
             const unsigned so = ok && grp == 0 ? (unsigned)((pixbase + (wave * 4 + mt) * img_w + (lane & 15)) * 4) : WR_OOB;
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, mean), rsm, so, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, rstd), rsr, so, 0, 0);
         }
+        const f32x2 mean2 = {mean, mean}, rstd2 = {rstd, rstd};
 #pragma unroll
         for (int np = 0; np < 2; ++np) {
             union { typename Half16<E>::v4 h; u32x2 u; } pa, pb, qa, qb;
-            float4 ga, gb4, ba, bb;
+            f32x4 ga = {}, gb4 = {}, ba = {}, bb = {};
             if (EPI == 2) {
-                ga = *reinterpret_cast<const float4*>(gb + (2 * np) * 16 + grp * 4);
-                gb4 = *reinterpret_cast<const float4*>(gb + (2 * np + 1) * 16 + grp * 4);
-                ba = *reinterpret_cast<const float4*>(gb + 64 + (2 * np) * 16 + grp * 4);
-                bb = *reinterpret_cast<const float4*>(gb + 64 + (2 * np + 1) * 16 + grp * 4);
+                ga = *reinterpret_cast<const f32x4*>(gb + (2 * np) * 16 + grp * 4);
+                gb4 = *reinterpret_cast<const f32x4*>(gb + (2 * np + 1) * 16 + grp * 4);
+                ba = *reinterpret_cast<const f32x4*>(gb + 64 + (2 * np) * 16 + grp * 4);
+                bb = *reinterpret_cast<const f32x4*>(gb + 64 + (2 * np + 1) * 16 + grp * 4);
             }
-            const float gaa[4] = {ga.x, ga.y, ga.z, ga.w}, gba[4] = {gb4.x, gb4.y, gb4.z, gb4.w};
-            const float baa[4] = {ba.x, ba.y, ba.z, ba.w}, bba[4] = {bb.x, bb.y, bb.z, bb.w};
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float va = acc[mt][2 * np][q], vb = acc[mt][2 * np + 1][q];
-                if (EPI == 1) {
-                    va = __builtin_amdgcn_fmed3f(va, 0.f, __builtin_inff());
-                    vb = __builtin_amdgcn_fmed3f(vb, 0.f, __builtin_inff());
-                }
-                pa.h[q] = (E)va;
-                pb.h[q] = (E)vb;
+            for (int h = 0; h < 2; ++h) {
+                f32x2 va = h ? acc[mt][2 * np].zw : acc[mt][2 * np].xy;
+                f32x2 vb = h ? acc[mt][2 * np + 1].zw : acc[mt][2 * np + 1].xy;
+                if (EPI == 1) { va = relu2(va); vb = relu2(vb); }
+                pa.h[2 * h] = (E)va.x; pa.h[2 * h + 1] = (E)va.y;
+                pb.h[2 * h] = (E)vb.x; pb.h[2 * h + 1] = (E)vb.y;
                 if (EPI == 2) {
-                    const float ya = (va - mean) * rstd * gaa[q] + baa[q], yb = (vb - mean) * rstd * gba[q] + bba[q];
-                    qa.h[q] = (E)__builtin_amdgcn_fmed3f(ya, 0.f, __builtin_inff());
-                    qb.h[q] = (E)__builtin_amdgcn_fmed3f(yb, 0.f, __builtin_inff());
+                    const f32x2 ya = relu2(__builtin_elementwise_fma((va - mean2) * rstd2, h ? ga.zw : ga.xy, h ? ba.zw : ba.xy));
+                    const f32x2 yb = relu2(__builtin_elementwise_fma((vb - mean2) * rstd2, h ? gb4.zw : gb4.xy, h ? bb.zw : bb.xy));
+                    qa.h[2 * h] = (E)ya.x; qa.h[2 * h + 1] = (E)ya.y;
+                    qb.h[2 * h] = (E)yb.x; qb.h[2 * h + 1] = (E)yb.y;
                 }
             }
             const u32x2 s0 = __builtin_amdgcn_permlane16_swap(pa.u[0], pb.u[0], false, false);
@@ -714,6 +729,12 @@ __device__ __forceinline__ void ws_pack_tile(const f32x4 (&acc)[4][4], const flo
 // beta are read from LDS (gb: [gamma 64][beta 64][bias 64] floats) to keep the wave under 256 registers.
 // Results leave the registers during the MFMA phases of the NEXT item: packed to bf16 they wait in pend[] and one
 // 16-byte store is pinned between two tap steps, so the store queue never backs up into the MFMA issue.
+// Measured and withdrawn (r02): deferring the EPI 2 ARITHMETIC as well (raw fp32 results kept in a second register
+// set, statistics / normalisation / packs done in twelve pieces between the tap steps of the next item, 233 VGPRs):
+// 397 -> 394 us per full-resolution launch.  The VALU work is not hidden by the MFMAs of the same SIMD (an MFMA holds
+// the vector issue port for half of its cycles; 590 VALU instructions per item need the other half entirely), so the
+// launch costs MFMA + arithmetic + what the two store streams add either way: 304 us with the stores dropped
+// (-DAD_DROP_STORES), 234 us for the plain epilogue.
 template <typename P, int EPI>
 __device__ __forceinline__ void ws_mma_role(const ConvArgs& a, const char* xb0, const char* xb1, const char* wt0,
                                             const char* wt1, const float* gb, int wave, int lane, const WsOrder& o,
@@ -800,31 +821,58 @@ __device__ __forceinline__ void ws_mma_role(const ConvArgs& a, const char* xb0, 
         else if (EPI == 3) { if (st < 8) WS_MASK_STORE(st); }
         else if ((st & 1) && st < 8) WS_PEND_STORE(4 + (st >> 1), rsy);
     };
+#ifdef AD_STAMP
+    unsigned long long wst[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long wt_last = clock64();
+    const unsigned long long wt_begin = wt_last, wall_begin = wall_clock64();
+#define WSTAMP(slot) do { unsigned long long now_ = clock64(); wst[slot] += now_ - wt_last; wt_last = now_; } while (0)
+#else
+#define WSTAMP(slot) do {} while (0)
+#endif
+    // tile coordinates advance by the (constant) stride without a division per item: (tx, ty, nn) += (sx, sy, sn) with carries
+    int tx, ty, nn, sx, sy, sn;
+    {
+        const int r0 = o.slot0 / g.tiles_x, rs = o.stride / g.tiles_x;
+        tx = o.slot0 - r0 * g.tiles_x; nn = r0 / g.tiles_y; ty = r0 - nn * g.tiles_y;
+        sx = o.stride - rs * g.tiles_x; sn = rs / g.tiles_y; sy = rs - sn * g.tiles_y;
+    }
     for (int k = 0; k < nloc; ++k) {
-        const int tile = o.slot0 + k * o.stride;
-        const int r = tile / g.tiles_x;
-        const int x0 = (tile - r * g.tiles_x) << 4;
-        const int nn = r / g.tiles_y;
-        const int y0 = (r - nn * g.tiles_y) << 4;
+        const int x0 = tx << 4, y0 = ty << 4;
+        const int nn_k = nn;
+        tx += sx;
+        if (tx >= g.tiles_x) { tx -= g.tiles_x; ++ty; }
+        ty += sy;
+        if (ty >= g.tiles_y) { ty -= g.tiles_y; ++nn; }
+        nn += sn;
         f32x4 acc[4][4];
+        f32x4 c0[4];                                    // bias: the accumulators start from it in the first tap step
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float4 b4 = EPI == 2 ? *reinterpret_cast<const float4*>(gb + 128 + j * 16 + grp * 4) : bv[j];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i][j] = f32x4{b4.x, b4.y, b4.z, b4.w};
+            c0[j] = f32x4{b4.x, b4.y, b4.z, b4.w};
         }
+        WSTAMP(0);                                      // item set-up
         lds_barrier();                                  // even stage (chunk 0) ready
-        P::mma_chunk_rows(acc, xb0, abase0, HWB, wt0, lane, hook0);
+        WSTAMP(1);                                      // barrier waits
+        P::template mma_chunk_rows<true>(acc, xb0, abase0, HWB, wt0, lane, hook0, c0);
+        WSTAMP(2);                                      // MFMA phases (with the deferred stores of the previous item)
         lds_barrier();                                  // odd stage (chunk 1) ready
+        WSTAMP(1);
         P::mma_chunk_rows(acc, xb1, abase0, HWB, wt1, lane, hook1);
+        WSTAMP(2);
         for (int cp = 2; cp < nch; cp += 2) {
             lds_barrier();
+            WSTAMP(1);
             P::mma_chunk_rows(acc, xb0, abase0, HWB, wt0, lane, [](int) {});
+            WSTAMP(2);
             lds_barrier();
+            WSTAMP(1);
             P::mma_chunk_rows(acc, xb1, abase0, HWB, wt1, lane, [](int) {});
+            WSTAMP(2);
         }
-        ws_pack_tile<(EPI == 3 ? 0 : EPI), typename P::T>(acc, gb, a.ln_eps, wave, lane, a.h, a.w, nn, y0, x0, cy, soff, rsm, rsr,
+        ws_pack_tile<(EPI == 3 ? 0 : EPI), typename P::T>(acc, gb, a.ln_eps, wave, lane, a.h, a.w, nn_k, y0, x0, cy, soff, rsm, rsr,
                                                           pend, pvo);
+        WSTAMP(3);                                      // pack (+ fused LayerNorm arithmetic)
         if (EPI == 3) {        // unconditional loads (zero records when this block is not masked): exact vmcnt bookkeeping
 #pragma unroll
             for (int i = 0; i < 8; ++i)
@@ -860,6 +908,16 @@ __device__ __forceinline__ void ws_mma_role(const ConvArgs& a, const char* xb0, 
     }
 #undef WS_PEND_STORE
 #undef WS_MASK_STORE
+#ifdef AD_STAMP
+    WSTAMP(4);                                          // drain of the last item
+    if (wave == 0 && lane == 0 && a.dbg) {
+        for (int i = 0; i < 5; ++i) a.dbg[blockIdx.x * 9 + i] = wst[i];
+        a.dbg[blockIdx.x * 9 + 5] = nloc;
+        a.dbg[blockIdx.x * 9 + 7] = wall_clock64() - wall_begin;      // 100 MHz
+        a.dbg[blockIdx.x * 9 + 8] = clock64() - wt_begin;
+    }
+#endif
+#undef WSTAMP
 }
 
 template <typename P, int EPI>
@@ -1116,6 +1174,162 @@ __global__ __launch_bounds__(WR_T, 1) void conv3x3_fwd_ws_kernel(ConvArgs a) {
 #undef WS_STORE_B
     } else {
         ws_mma_role<P, EPI>(a, xb0, xb1, wt0, wt1, gb, wave, lane, o, nch);
+    }
+}
+
+// ------------------------------------------------------------------ forward / dgrad on 4x4 feature maps (bf16 / fp16)
+// The 4x4 level of a deep model (K2': 64 images x 16 pixels, 256 ... 1024 channels) is a GEMM of only 1 024 rows with
+// K = 9 * Cin up to 9 216: 256-pixel tiles give 32 work items, which the generic kernel spreads over the chip by
+// splitting K 16 ways through fp32 slabs in memory (33 MB written and read back for 1 MB of output, plus the finalize
+// launch).  Here a workgroup owns 64 pixels (four whole images) x 16*NT output channels and the K split happens INSIDE
+// it: each of the four waves takes one 32-channel chunk of every 128-channel phase (all nine taps) and the four partial
+// tiles are added through LDS at the end, in a fixed order.  No slab, no second launch.
+//   * activations: the four images' 6x6 zero-bordered halos of the phase's 128 channels are staged in LDS (registers ->
+//     LDS, double buffered, one barrier per phase), one read of a fragment per tap and m-tile;
+//   * weights: no reuse inside a workgroup (every wave multiplies different channels), so the fragments go from L2
+//     straight into the registers that feed the MFMAs; the fragment of tap t is refilled with the next phase's tap t
+//     right after its last use: a prefetch distance of exactly one phase (9 tap steps) with static register indices.
+// Loads are issued unconditionally (the last phase re-fetches itself) so that every s_waitcnt vmcnt stays exact.
+constexpr int M4_T = 256;
+constexpr int M4_IMG = 4;                        // images per workgroup = m-tiles per wave
+constexpr int M4_NPH = M4_IMG * 36;              // halo pixels
+constexpr int M4_XCH = M4_NPH * PIXB;            // one 32-channel chunk of the halo tile (13 824 B)
+constexpr int M4_XB = 4 * M4_XCH;                // one phase
+constexpr int M4_XS = M4_NPH * 4 * 4 / M4_T;     // 16-byte staging slots per thread and phase (= 9)
+constexpr size_t M4_LDS = 2 * (size_t)M4_XB + M4_NPH * 4;
+
+template <typename P, int NT>
+__global__ __launch_bounds__(M4_T, 1) void conv3x3_map4_kernel(ConvArgs a) {
+    typedef typename P::T T;
+    typedef typename P::v8 v8;
+    static_assert(sizeof(T) == 2 && M4_XS == 9, "bf16 / fp16 path, nine staging slots per thread");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TSZ = 2;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int* gtab = reinterpret_cast<int*>(smem + 2 * M4_XB);
+    const int nbk = (a.cout_real + 16 * NT - 1) / (16 * NT);
+    const int mb = blockIdx.x / nbk, nb = blockIdx.x - mb * nbk;     // neighbours in the grid share the input tile
+    const int cin = a.c1 + a.c2;
+    const int nph = cin / 128;
+    const int kc_total = cin / P::KV;
+
+    // halo table: flat pixel index, or its complement where the halo pixel is padding / past the batch
+    for (int hp = tid; hp < M4_NPH; hp += M4_T) {
+        const int img = hp / 36, r = hp - img * 36, hy = r / 6, hx = r - hy * 6;
+        const int nn = mb * M4_IMG + img, y = hy - 1, x = hx - 1;
+        const bool ok = nn < a.n && (unsigned)y < 4u && (unsigned)x < 4u;
+        const int idx = (min(nn, a.n - 1) * 4 + min(max(y, 0), 3)) * 4 + min(max(x, 0), 3);
+        gtab[hp] = ok ? idx : ~idx;
+    }
+    __syncthreads();
+    // this thread's nine staging slots of a phase: slot s = tid + 256 i -> halo pixel s >> 4 (= tid / 16 + 16 i), 16-byte
+    // piece s & 15 of the pixel's 256 bytes (chunk (s >> 2) & 3, part s & 3): 16 lanes read one contiguous 256-byte run.
+    // The concat boundary is phase aligned (launcher), so source, row pitch and channel offset are uniform per phase.
+    int ix[M4_XS];
+#pragma unroll
+    for (int i = 0; i < M4_XS; ++i) ix[i] = gtab[(tid >> 4) + 16 * i];
+    const int ko = (tid & 15) * 16;
+    const int lds_slot = ((tid >> 2) & 3) * M4_XCH + (tid >> 4) * PIXB + (tid & 3) * 16;     // + i * 16 * PIXB
+    uint4 xs[M4_XS];
+    auto issue_x = [&](int ph) {
+        const int c0 = ph * 128;
+        const bool first = c0 < a.c1;
+        const char* src = (first ? a.x1 : a.x2) + (first ? c0 : c0 - a.c1) * TSZ;
+        const int rb = (first ? a.c1 : a.c2) * TSZ;
+#pragma unroll
+        for (int i = 0; i < M4_XS; ++i) {
+            const unsigned idx = ix[i] >= 0 ? ix[i] : ~ix[i];
+            xs[i] = *reinterpret_cast<const uint4*>(src + (idx * (unsigned)rb + (unsigned)ko));
+        }
+    };
+    auto store_x = [&](char* xb) {
+#pragma unroll
+        for (int i = 0; i < M4_XS; ++i)
+            *reinterpret_cast<uint4*>(xb + lds_slot + i * 16 * PIXB) = ix[i] >= 0 ? xs[i] : make_uint4(0, 0, 0, 0);
+    };
+    // weights: fragment (tap, n-tile) of chunk ch = lanes (l & 15) -> output channel, (l >> 4) -> 8-channel group;
+    // a uniform base per (phase, tap) plus one 32-bit lane offset
+    const unsigned wlo = (unsigned)(((lane >> 4) * a.cout + nb * 16 * NT + (lane & 15)) * 16);
+    v8 wq[9][NT];
+    auto issue_w = [&](int ph, int t) {
+        const char* wc = a.wp + ((size_t)(t * kc_total + (ph * 4 + wave) * 4) * a.cout) * 16;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) wq[t][nt] = *reinterpret_cast<const v8*>(wc + (wlo + nt * 256));
+    };
+    int abase[M4_IMG];
+#pragma unroll
+    for (int mt = 0; mt < M4_IMG; ++mt) {
+        const int pq = lane & 15;
+        abase[mt] = wave * M4_XCH + ((mt * 6 + (pq >> 2) + 1) * 6 + (pq & 3) + 1) * PIXB + P::a_lane_off(lane);
+    }
+    f32x4 acc[M4_IMG][NT];
+#pragma unroll
+    for (int i = 0; i < M4_IMG; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    issue_x(0);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) issue_w(0, t);
+    store_x(smem);
+    lds_barrier();
+    int cur = 0;
+    for (int ph = 0; ph < nph; ++ph) {
+        const int php = min(ph + 1, nph - 1);          // the last phase re-fetches itself: loads stay unconditional
+        const char* xb = smem + cur * M4_XB;
+        issue_x(php);
+        __builtin_amdgcn_sched_barrier(0);             // the X loads first, then one weight refill per tap: the waits
+        v8 xf[2][M4_IMG];                              // below count on this order (vmcnt is in-order)
+#pragma unroll
+        for (int mt = 0; mt < M4_IMG; ++mt) xf[0][mt] = *reinterpret_cast<const v8*>(xb + abase[mt] - 7 * PIXB);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            if (t + 1 < 9) {
+                const int toff = (((t + 1) / 3 - 1) * 6 + ((t + 1) % 3 - 1)) * PIXB;
+#pragma unroll
+                for (int mt = 0; mt < M4_IMG; ++mt) xf[(t + 1) & 1][mt] = *reinterpret_cast<const v8*>(xb + abase[mt] + toff);
+            }
+#pragma unroll
+            for (int mt = 0; mt < M4_IMG; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = Half16<T>::mfma(wq[t][nt], xf[t & 1][mt], acc[mt][nt]);
+            __builtin_amdgcn_sched_barrier(0);
+            issue_w(php, t);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        store_x(smem + (cur ^ 1) * M4_XB);
+        lds_barrier();
+        cur ^= 1;
+    }
+    // ---- add the four waves' partial tiles through LDS (both halo buffers are free now); wave w finishes m-tile w
+    float* red = reinterpret_cast<float*>(smem);        // [wave][mt][nt][lane][4]
+#pragma unroll
+    for (int mt = 0; mt < M4_IMG; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            *reinterpret_cast<f32x4*>(red + (((wave * M4_IMG + mt) * NT + nt) * 64 + lane) * 4) = acc[mt][nt];
+    lds_barrier();
+    const int nn = mb * M4_IMG + wave;
+    if (nn < a.n) {
+        const size_t gpix = (size_t)nn * 16 + (lane & 15);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int cg = (nb * NT + nt) * 16;                         // first channel of this n-tile
+            if (cg >= a.cout_real) continue;
+            f32x4 v = *reinterpret_cast<const f32x4*>(red + (((0 * M4_IMG + wave) * NT + nt) * 64 + lane) * 4);
+#pragma unroll
+            for (int w2 = 1; w2 < 4; ++w2) v += *reinterpret_cast<const f32x4*>(red + (((w2 * M4_IMG + wave) * NT + nt) * 64 + lane) * 4);
+            if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + cg + (lane >> 4) * 4);
+            if (a.epilogue == AD_EPI_RELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            T* dst = (cg < a.cy1 ? reinterpret_cast<T*>(a.y1) + gpix * a.cy1 + cg
+                                 : reinterpret_cast<T*>(a.y2) + gpix * (a.cout_real - a.cy1) + (cg - a.cy1)) + (lane >> 4) * 4;
+            typedef typename Half16<T>::v4 h4;
+            *reinterpret_cast<h4*>(dst) = h4{(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
+        }
     }
 }
 
@@ -2013,6 +2227,14 @@ static int images_per_launch(int n, int h, int w, int c1, int c2, int cout, bool
 template <typename P>
 int launch_fwd(ConvArgs a, void* ws, size_t ws_bytes, hipStream_t s);
 
+// conv3x3_map4_kernel: 4x4 maps, whole 128-channel phases, the concat boundary and the output split on 16-channel tiles
+static bool map4_ok(int n, int h, int w, int c1, int c2, int cout, int cy1) {
+    static const bool off = getenv("ADUNET_NO_MAP4") != nullptr;      // A/B switch
+    if (off) return false;
+    return h == 4 && w == 4 && n >= 1 && n <= (1 << 16) && (c1 + c2) % 128 == 0 && c1 % 128 == 0 && c1 + c2 <= 8192 &&
+           cout % 16 == 0 && cout <= 8192 && cy1 % 16 == 0;        // 32-bit offsets inside the kernel
+}
+
 template <typename P>
 int launch_fwd_runs(ConvArgs a, void* ws, size_t ws_bytes, hipStream_t s) {
     int chunk = a.n;
@@ -2066,6 +2288,22 @@ int launch_fwd(ConvArgs a, void* ws, size_t ws_bytes, hipStream_t s) {
     }
     if constexpr (sizeof(typename P::T) == 2) {
         a.ksplit = 1; a.slab = nullptr;
+        if (map4_ok(a.n, a.h, a.w, a.c1, a.c2, a.cout_real, a.cy1) && a.epilogue != AD_EPI_LN_RELU && a.epilogue != AD_EPI_MASK) {
+            static bool m4_attr = false;
+            if (!m4_attr) {
+                allow_big_lds(conv3x3_map4_kernel<P, 2>);
+                allow_big_lds(conv3x3_map4_kernel<P, 4>);
+                m4_attr = true;
+            }
+            const int mblk = (a.n + M4_IMG - 1) / M4_IMG;
+            // 64-channel blocks keep the LDS and L1 traffic per MFMA lowest; 32-channel blocks when that leaves CUs idle
+            if (mblk * ((a.cout_real + 63) / 64) >= 200 || a.cout_real % 32)
+                conv3x3_map4_kernel<P, 4><<<mblk * ((a.cout_real + 63) / 64), M4_T, M4_LDS, s>>>(a);
+            else
+                conv3x3_map4_kernel<P, 2><<<mblk * ((a.cout_real + 31) / 32), M4_T, M4_LDS, s>>>(a);
+            AD_LAUNCH_CHECK("conv3x3_map4");
+            return AD_OK;
+        }
         int kind = fwd_ws_kind(a.n, a.h, a.w, a.c1, a.c2, a.cout_real, a.epilogue == AD_EPI_LN_RELU);
         if (a.cy1 % BN && a.cy1 != a.cout_real) kind = 0;          // a split inside a 64-channel block: generic kernel
         // the ReLU-grad mask epilogue exists for the weights-resident kernel only (the streamed-weights variant would

@@ -70,6 +70,48 @@ def test_conv3x3_fwd(device, dtype, shape):
     assert relerr(y, np.maximum(want, 0)) < TOL[dtype]
 
 
+# 4x4 maps with whole 128-channel phases take conv3x3_map4_kernel (K split over the waves of a workgroup, VERDICT r01
+# item 7): ragged batch (n % 4), one / several phases, concat inputs, 16- / 32- / 64-channel ragged blocks
+MAP4_SHAPES = [
+    (1, 4, 4, 128, 0, 64),
+    (5, 4, 4, 256, 0, 96),
+    (7, 4, 4, 128, 128, 32),
+    (6, 4, 4, 128, 256, 48),     # concat of unequal halves (phase aligned)
+    (6, 4, 4, 96, 160, 64),      # concat boundary inside a phase: generic kernel
+    (64, 4, 4, 512, 0, 128),
+    (9, 4, 4, 128, 0, 512),      # enough blocks for the 64-channel variant
+]
+
+
+@pytest.mark.parametrize("dtype", [BF16, F16])
+@pytest.mark.parametrize("shape", MAP4_SHAPES)
+def test_conv3x3_map4(device, dtype, shape):
+    from adunet_amd import ops
+    n, h, w, c1, c2, cout = shape
+    cin = c1 + c2
+    rng = np.random.default_rng(hash(shape) % 2**31)
+    x = rnd(rng.standard_normal((n, h, w, cin)), dtype)
+    wk = rnd(rng.standard_normal((3, 3, cin, cout)) * 0.05, dtype)
+    b = rng.standard_normal(cout).astype(np.float32).astype(np.float64)
+    want = ref.conv2d_same_fwd(x, wk, b)
+    x1 = to_dev(x[..., :c1], dtype, device)
+    x2 = to_dev(x[..., c1:], dtype, device) if c2 else None
+    wf, wd = ops.conv3x3_pack(torch.tensor(wk, dtype=F32, device=device), cin, dtype, want_dgrad=cout % 32 == 0)
+    bias = torch.tensor(b, dtype=F32, device=device)
+    y = ops.conv3x3_fwd(x1, x2, wf, bias, cout, relu=False)
+    assert relerr(y, want) < TOL[dtype]
+    yr = ops.conv3x3_fwd(x1, x2, wf, bias, cout, relu=True)
+    assert relerr(yr, np.maximum(want, 0)) < TOL[dtype]
+    # the output split on a 16-channel boundary (dgrad of a concat input)
+    ya, yb = ops.conv3x3_fwd(x1, x2, wf, bias, cout, split=16)
+    assert torch.equal(torch.cat([ya, yb], dim=-1), y)
+    if wd is not None and cout % 128 == 0:       # dgrad through the same kernel: K = cout
+        dz = rnd(rng.standard_normal((n, h, w, cout)), dtype)
+        want_dx, _, _ = ref.conv2d_same_bwd(x, wk, dz)
+        got = ops.conv3x3_fwd(to_dev(dz, dtype, device), None, wd, None, cin)
+        assert relerr(got, want_dx) < TOL[dtype]
+
+
 @pytest.mark.parametrize("dtype", [F32, BF16])
 @pytest.mark.parametrize("shape", [(2, 16, 16, 64, 0, 64), (1, 21, 13, 64, 64, 128), (5, 4, 4, 128, 0, 64), (9, 1, 1, 64, 0, 64),
                                    (2, 16, 16, 32, 0, 32), (1, 11, 9, 32, 0, 64), (2, 8, 8, 96, 0, 32)])
