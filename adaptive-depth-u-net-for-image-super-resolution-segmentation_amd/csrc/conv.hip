@@ -1177,6 +1177,38 @@ __global__ __launch_bounds__(WR_T, 1) void conv3x3_fwd_ws_kernel(ConvArgs a) {
     }
 }
 
+// Epilogue shared by the small-map kernels below, whose four waves each hold a partial [4 m-tiles][NT n-tiles] result of
+// the same 64 pixels x 16*NT channels (K split): partials go through LDS (red: 4 * 4 * NT * 1 KB), wave w adds the four
+// partials of m-tile w in a fixed order, applies bias / ReLU and stores pixel gpix (lane's pixel of that m-tile) if valid.
+template <typename T, int NT>
+__device__ __forceinline__ void ksplit4_epilogue(float* red, const f32x4 (&acc)[4][NT], const ConvArgs& a, int wave, int lane,
+                                                 int nb, bool valid, size_t gpix) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            *reinterpret_cast<f32x4*>(red + (((wave * 4 + mt) * NT + nt) * 64 + lane) * 4) = acc[mt][nt];
+    lds_barrier();
+    if (!valid) return;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int cg = (nb * NT + nt) * 16;                         // first channel of this n-tile
+        if (cg >= a.cout_real) continue;
+        f32x4 v = *reinterpret_cast<const f32x4*>(red + (((0 * 4 + wave) * NT + nt) * 64 + lane) * 4);
+#pragma unroll
+        for (int w2 = 1; w2 < 4; ++w2) v += *reinterpret_cast<const f32x4*>(red + (((w2 * 4 + wave) * NT + nt) * 64 + lane) * 4);
+        if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + cg + (lane >> 4) * 4);
+        if (a.epilogue == AD_EPI_RELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        T* dst = (cg < a.cy1 ? reinterpret_cast<T*>(a.y1) + gpix * a.cy1 + cg
+                             : reinterpret_cast<T*>(a.y2) + gpix * (a.cout_real - a.cy1) + (cg - a.cy1)) + (lane >> 4) * 4;
+        typedef typename Half16<T>::v4 h4;
+        *reinterpret_cast<h4*>(dst) = h4{(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
+    }
+}
+
 // ------------------------------------------------------------------ forward / dgrad on 4x4 feature maps (bf16 / fp16)
 // The 4x4 level of a deep model (K2': 64 images x 16 pixels, 256 ... 1024 channels) is a GEMM of only 1 024 rows with
 // K = 9 * Cin up to 9 216: 256-pixel tiles give 32 work items, which the generic kernel spreads over the chip by
@@ -1302,35 +1334,73 @@ __global__ __launch_bounds__(M4_T, 1) void conv3x3_map4_kernel(ConvArgs a) {
         lds_barrier();
         cur ^= 1;
     }
-    // ---- add the four waves' partial tiles through LDS (both halo buffers are free now); wave w finishes m-tile w
-    float* red = reinterpret_cast<float*>(smem);        // [wave][mt][nt][lane][4]
+    // the four waves' partial tiles are added through LDS (both halo buffers are free now); wave w finishes m-tile w
+    ksplit4_epilogue<T, NT>(reinterpret_cast<float*>(smem), acc, a, wave, lane, nb, mb * M4_IMG + wave < a.n,
+                            (size_t)(mb * M4_IMG + wave) * 16 + (lane & 15));
+}
+
+// ------------------------------------------------------------------ forward / dgrad on 1x1 feature maps (bf16 / fp16)
+// With "same" padding only the centre tap of a 1x1 map sees data: the layer is a GEMM [N images] x [Cin] x [Cout] (K2':
+// 64 x 1024 x 1024, 134 MFLOP) whose cost is one memory round trip.  A workgroup owns 64 images x 16*NT channels; its four
+// waves split the 32-channel chunks, each issues ALL its fragment loads (activations and centre-tap weights, straight
+// from global memory in MFMA operand layout) before the first MFMA, eight chunk steps at a time, and the partial tiles
+// are added through LDS.  Steps past the end of K re-load the last chunk and multiply zeros: loads stay unconditional.
+constexpr int M1_T = 256;
+constexpr int M1_G = 8;                            // chunk steps in flight per wave
+
+template <typename P, int NT>
+__global__ __launch_bounds__(M1_T, 1) void conv3x3_map1_kernel(ConvArgs a) {
+    typedef typename P::T T;
+    typedef typename P::v8 v8;
+    static_assert(sizeof(T) == 2, "bf16 / fp16 path");
+    __shared__ __attribute__((aligned(16))) float red[4 * 4 * NT * 64 * 4];
+    constexpr int TSZ = 2;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nbk = (a.cout_real + 16 * NT - 1) / (16 * NT);
+    const int mb = blockIdx.x / nbk, nb = blockIdx.x - mb * nbk;
+    const int cin = a.c1 + a.c2;
+    const int nch = cin / P::CK;                   // multiple of 4 (launcher): every wave has nch / 4 steps
+    const int kc_total = cin / P::KV;
+    const int nsteps = nch / 4;
+    unsigned row[4];                               // image of this lane in each m-tile (clamped: rows past the batch are not stored)
 #pragma unroll
-    for (int mt = 0; mt < M4_IMG; ++mt)
+    for (int mt = 0; mt < 4; ++mt) row[mt] = (unsigned)min(mb * 64 + mt * 16 + (lane & 15), a.n - 1);
+    const unsigned klo = (unsigned)((lane >> 4) * P::KV * TSZ);
+    const unsigned wlo = (unsigned)(((lane >> 4) * a.cout + nb * 16 * NT + (lane & 15)) * 16);
+    const char* wc4 = a.wp + (size_t)4 * kc_total * a.cout * 16;          // centre tap
+    f32x4 acc[4][NT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-            *reinterpret_cast<f32x4*>(red + (((wave * M4_IMG + mt) * NT + nt) * 64 + lane) * 4) = acc[mt][nt];
-    lds_barrier();
-    const int nn = mb * M4_IMG + wave;
-    if (nn < a.n) {
-        const size_t gpix = (size_t)nn * 16 + (lane & 15);
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int cg = (nb * NT + nt) * 16;                         // first channel of this n-tile
-            if (cg >= a.cout_real) continue;
-            f32x4 v = *reinterpret_cast<const f32x4*>(red + (((0 * M4_IMG + wave) * NT + nt) * 64 + lane) * 4);
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j0 = 0; j0 < nsteps; j0 += M1_G) {
+        v8 xf[M1_G][4], wf[M1_G][NT];
 #pragma unroll
-            for (int w2 = 1; w2 < 4; ++w2) v += *reinterpret_cast<const f32x4*>(red + (((w2 * M4_IMG + wave) * NT + nt) * 64 + lane) * 4);
-            if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + cg + (lane >> 4) * 4);
-            if (a.epilogue == AD_EPI_RELU) {
+        for (int j = 0; j < M1_G; ++j) {
+            const int ch = wave + 4 * min(j0 + j, nsteps - 1);
+            const int c0 = ch * P::CK;
+            const bool first = c0 < a.c1;
+            const char* src = (first ? a.x1 : a.x2) + (first ? c0 : c0 - a.c1) * TSZ;
+            const unsigned rb = (unsigned)((first ? a.c1 : a.c2) * TSZ);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            for (int mt = 0; mt < 4; ++mt) xf[j][mt] = *reinterpret_cast<const v8*>(src + (row[mt] * rb + klo));
+            const char* wc = wc4 + (size_t)ch * 4 * a.cout * 16;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) wf[j][nt] = *reinterpret_cast<const v8*>(wc + (wlo + nt * 256));
+        }
+#pragma unroll
+        for (int j = 0; j < M1_G; ++j) {
+            if (j0 + j < nsteps) {                 // uniform
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = Half16<T>::mfma(wf[j][nt], xf[j][mt], acc[mt][nt]);
             }
-            T* dst = (cg < a.cy1 ? reinterpret_cast<T*>(a.y1) + gpix * a.cy1 + cg
-                                 : reinterpret_cast<T*>(a.y2) + gpix * (a.cout_real - a.cy1) + (cg - a.cy1)) + (lane >> 4) * 4;
-            typedef typename Half16<T>::v4 h4;
-            *reinterpret_cast<h4*>(dst) = h4{(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
         }
     }
+    ksplit4_epilogue<T, NT>(red, acc, a, wave, lane, nb, mb * 64 + wave * 16 + (lane & 15) < a.n,
+                            (size_t)(mb * 64 + wave * 16 + (lane & 15)));
 }
 
 // ------------------------------------------------------------------ wgrad
@@ -2227,6 +2297,14 @@ static int images_per_launch(int n, int h, int w, int c1, int c2, int cout, bool
 template <typename P>
 int launch_fwd(ConvArgs a, void* ws, size_t ws_bytes, hipStream_t s);
 
+// conv3x3_map1_kernel: 1x1 maps, four chunks per step group, the concat boundary on a chunk, the output split on 16-channel tiles
+static bool map1_ok(int n, int h, int w, int c1, int c2, int cout, int cy1) {
+    static const bool off = getenv("ADUNET_NO_MAP1") != nullptr;      // A/B switch
+    if (off) return false;
+    return h == 1 && w == 1 && n >= 1 && n <= (1 << 20) && (c1 + c2) % 128 == 0 && c1 % 32 == 0 && c1 + c2 <= 8192 &&
+           cout % 16 == 0 && cout <= 8192 && cy1 % 16 == 0;
+}
+
 // conv3x3_map4_kernel: 4x4 maps, whole 128-channel phases, the concat boundary and the output split on 16-channel tiles
 static bool map4_ok(int n, int h, int w, int c1, int c2, int cout, int cy1) {
     static const bool off = getenv("ADUNET_NO_MAP4") != nullptr;      // A/B switch
@@ -2302,6 +2380,12 @@ int launch_fwd(ConvArgs a, void* ws, size_t ws_bytes, hipStream_t s) {
             else
                 conv3x3_map4_kernel<P, 2><<<mblk * ((a.cout_real + 31) / 32), M4_T, M4_LDS, s>>>(a);
             AD_LAUNCH_CHECK("conv3x3_map4");
+            return AD_OK;
+        }
+        if (map1_ok(a.n, a.h, a.w, a.c1, a.c2, a.cout_real, a.cy1) && a.epilogue != AD_EPI_LN_RELU && a.epilogue != AD_EPI_MASK) {
+            const int mblk = (a.n + 63) / 64;
+            conv3x3_map1_kernel<P, 2><<<mblk * ((a.cout_real + 31) / 32), M1_T, 0, s>>>(a);
+            AD_LAUNCH_CHECK("conv3x3_map1");
             return AD_OK;
         }
         int kind = fwd_ws_kind(a.n, a.h, a.w, a.c1, a.c2, a.cout_real, a.epilogue == AD_EPI_LN_RELU);

@@ -83,9 +83,20 @@ MAP4_SHAPES = [
 ]
 
 
+# 1x1 maps with Cin % 128 == 0 take conv3x3_map1_kernel (centre tap only, all fragment loads in flight at once)
+MAP1_SHAPES = [
+    (1, 1, 1, 128, 0, 64),
+    (9, 1, 1, 256, 0, 96),
+    (70, 1, 1, 128, 128, 32),    # two image blocks, the second ragged
+    (5, 1, 1, 96, 160, 48),      # concat boundary on a chunk inside a step group
+    (3, 1, 1, 1152, 0, 64),      # nine steps per wave: a second group of loads
+    (64, 1, 1, 1024, 0, 1024),
+]
+
+
 @pytest.mark.parametrize("dtype", [BF16, F16])
-@pytest.mark.parametrize("shape", MAP4_SHAPES)
-def test_conv3x3_map4(device, dtype, shape):
+@pytest.mark.parametrize("shape", MAP4_SHAPES + MAP1_SHAPES)
+def test_conv3x3_small_maps(device, dtype, shape):
     from adunet_amd import ops
     n, h, w, c1, c2, cout = shape
     cin = c1 + c2
