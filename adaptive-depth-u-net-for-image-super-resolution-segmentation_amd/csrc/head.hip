@@ -329,7 +329,10 @@ __global__ __launch_bounds__(256) void rows_reduce5_kernel(const float* __restri
     const int i = blockIdx.x * 4 + cl;
     float s = 0.f;
     if (i < ncols)
+    {
+#pragma unroll 8
         for (int r = rg; r < nrows; r += 64) s += part[(size_t)r * ncols + i];
+    }
     sm[rg][cl] = s;
     __syncthreads();
     if (rg == 0 && i < ncols) {
@@ -350,7 +353,10 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const float* __restric
     const int i = blockIdx.x * 4 + cl;
     float s = 0.f;
     if (i < ncols)
+    {
+#pragma unroll 8
         for (int r = rg; r < nrows; r += 64) s += part[(size_t)r * ncols + i];
+    }
     sm[rg][cl] = s;
     __syncthreads();
     if (rg == 0 && i < ncols) {

@@ -200,7 +200,10 @@ __global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restr
     const int i = blockIdx.x * 4 + cl;
     float s = 0.f;
     if (i < 3 * c)
+    {
+#pragma unroll 8
         for (int b = rg; b < nblocks; b += 64) s += part[(size_t)b * 3 * c + i];
+    }
     sm[rg][cl] = s;
     __syncthreads();
     if (rg == 0 && i < 3 * c) {

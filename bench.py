@@ -314,8 +314,8 @@ def main():
                        "final_loss": float(last_loss), "final_psnr": float(last_psnr)},
             "roofline": {"bound": "mfma",
                          "kernel": "forward-conv / dgrad family: conv3x3_fwd_wres_kernel, conv3x3_fwd_ws_kernel, "
-                                   "conv3x3_fwd_kernel (+ splitk_finalize_kernel), launches without the fused "
-                                   "LayerNorm epilogue",
+                                   "conv3x3_map4_kernel, conv3x3_map1_kernel (conv3x3_fwd_kernel + splitk_finalize_kernel "
+                                   "for other shapes), launches without the fused LayerNorm epilogue",
                          "achieved": dom["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": dom["frac"],
                          "traffic": pmc_traffic(args.workload, args.dtype, batch),
                          "algorithmic_bytes_per_launch": timer.nbytes("conv3x3_fwd") / n_launch,

@@ -17,7 +17,7 @@ import sys
 
 FAMILIES = {       # kernel name -> op family used by bench.py's roofline ("_ln": launches with the fused LayerNorm epilogue)
     "conv3x3_fwd_wres_kernel": "conv3x3_fwd", "conv3x3_fwd_ws_kernel": "conv3x3_fwd", "conv3x3_fwd_kernel": "conv3x3_fwd",
-    "splitk_finalize_kernel": "conv3x3_fwd",
+    "splitk_finalize_kernel": "conv3x3_fwd", "conv3x3_map4_kernel": "conv3x3_fwd", "conv3x3_map1_kernel": "conv3x3_fwd",
     "conv3x3_fwd_wres_kernel_ln": "conv3x3_ln_relu_fwd", "conv3x3_fwd_ws_kernel_ln": "conv3x3_ln_relu_fwd",
     "conv3x3_fwd_wres_kernel_relugrad": "conv3x3_dgrad_relu",
     "conv3x3_wgrad_kernel": "conv3x3_wgrad", "conv3x3_wgrad_ws_kernel": "conv3x3_wgrad", "wgrad_reduce_kernel": "conv3x3_wgrad",
