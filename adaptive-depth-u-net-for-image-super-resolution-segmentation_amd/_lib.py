@@ -70,6 +70,7 @@ SIGNATURES = {
     "ad_seg_head_ws_bytes": (_sz, [_i, _i]),
     "ad_seg_head_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _sz, _i, _vp]),
     "ad_seg_head_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _f, _f, _f, _vp, _vp, _sz, _i, _vp]),
+    "ad_softmax_head_fwd": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
     "ad_comm_unique_id": (_i, [_vp]),
     "ad_comm_create": (_i, [_vp, _i, _i, C.POINTER(C.c_void_p)]),
     "ad_comm_destroy": (_i, [_vp]),

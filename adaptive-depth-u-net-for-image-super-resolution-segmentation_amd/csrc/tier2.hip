@@ -612,6 +612,41 @@ extern "C" int ad_pixel_shuffle2(const void* x, void* y, int n, int h, int w, in
     return AD_OK;
 }
 
+// Conv2D(num_classes, 1, activation="softmax") head (Segmenation/code/unet_vinillia.py:89-90, num_classes > 1): the G
+// lanes of a pixel each hold EPT channels; class k's logit is a dot product folded over the group, lane 0 writes it to
+// prob[pix][k], re-reads its own K logits for the running maximum and normalises in place.  Inference-only path (the
+// reference defines no loss for it), so one pass with K group reductions per pixel is all it needs.
+template <typename T, int G>
+__global__ __launch_bounds__(256) void softmax_head_fwd_kernel(const T* __restrict__ xh, const float* __restrict__ w,
+                                                               const float* __restrict__ b, float* __restrict__ prob,
+                                                               int64_t npix, int ch, int k_classes) {
+    constexpr int EPT = ElemTraits<T>::EPT;
+    constexpr int PPB = 256 / G;
+    const int tid = threadIdx.x, gl = tid % G, gp = tid / G;
+    for (int64_t pix = (int64_t)blockIdx.x * PPB + gp; pix < npix; pix += (int64_t)gridDim.x * PPB) {
+        Vec16<T> ld;
+        float x[EPT];
+        ld.load(xh + pix * ch + gl * EPT);
+        ld.to_f32(x);
+        float* out = prob + pix * k_classes;
+        float mx = -__builtin_inff();
+        for (int k = 0; k < k_classes; ++k) {
+            float r = 0.f;
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) r += x[e] * w[(size_t)(gl * EPT + e) * k_classes + k];     // kernel [ch][K]
+            r = gsum2<G>(r) + b[k];
+            mx = fmaxf(mx, r);
+            if (gl == 0) out[k] = r;
+        }
+        if (gl == 0) {
+            float sum = 0.f;
+            for (int k = 0; k < k_classes; ++k) { const float e = __expf(out[k] - mx); out[k] = e; sum += e; }
+            const float inv = 1.f / sum;
+            for (int k = 0; k < k_classes; ++k) out[k] *= inv;
+        }
+    }
+}
+
 #define SEG_DISPATCH(...)                                          \
     switch (g) {                                                   \
         case 4: { constexpr int G_ = 4; __VA_ARGS__ } break;       \
@@ -657,6 +692,22 @@ extern "C" int ad_seg_head_fwd(const void* xh, const float* w, const float* b, c
         seg_sums_kernel<<<(n * 3 + 255) / 256, 256, 0, s>>>(part, n, bpi, sums);
         AD_LAUNCH_CHECK("seg_sums");
     }
+    return AD_OK;
+}
+
+extern "C" int ad_softmax_head_fwd(const void* xh, const float* w, const float* b, float* prob, int64_t npix, int ch,
+                                   int num_classes, int dtype, void* stream) {
+    AD_REQUIRE(ad_dtype_ok(dtype), "ad_softmax_head_fwd: bad dtype %d", dtype);
+    int g;
+    AD_REQUIRE(npix > 0 && num_classes >= 2 && num_classes <= 1024 && seg_group(ch, ad_is_half(dtype) ? 8 : 4, &g),
+               "ad_softmax_head_fwd: unsupported shape ch=%d classes=%d", ch, num_classes);
+    const int ppb = 256 / g;
+    const int64_t nb = (npix + ppb - 1) / ppb;
+    const int blocks = (int)(nb < 4096 ? nb : 4096);
+    hipStream_t s = (hipStream_t)stream;
+    AD_DISPATCH_DTYPE(dtype, T_,
+        SEG_DISPATCH(softmax_head_fwd_kernel<T_, G_><<<blocks, 256, 0, s>>>((const T_*)xh, w, b, prob, npix, ch, num_classes);))
+    AD_LAUNCH_CHECK("ad_softmax_head_fwd");
     return AD_OK;
 }
 

@@ -613,6 +613,17 @@ def seg_head_fwd(xh, w, b, target, ws: Workspace):
     return prob, sums
 
 
+def softmax_head_fwd(xh, w, b):
+    """Conv2D(K, 1, softmax) head: xh [n,h,w,ch], w [ch,K] fp32, b [K] -> probabilities [n,h,w,K] fp32 (forward only)."""
+    n, h, wd, ch = xh.shape
+    k = w.shape[-1]
+    prob = torch.empty((n, h, wd, k), dtype=torch.float32, device=xh.device)
+    with _timed("softmax_head_fwd"):
+        check(_lib.load().ad_softmax_head_fwd(_p(xh), _p(w), _p(b), _p(prob), n * h * wd, ch, k, dt(xh.dtype), _stream()),
+              "ad_softmax_head_fwd")
+    return prob
+
+
 def seg_head_bwd(xh, w, target, prob, sums, dw, db, bce_weight: float, dice_weight: float, ws: Workspace,
                  smooth: float = 1e-6, loss_scale: Optional[torch.Tensor] = None):
     n, h, wd, ch = xh.shape

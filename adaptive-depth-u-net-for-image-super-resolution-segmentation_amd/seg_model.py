@@ -91,9 +91,12 @@ class SegModel(Model):
     """U-Net for binary masks; norm in {"bn", "ln"}, up in {"bilinear", "convT"}."""
 
     def __init__(self, input_size: int, base_channels: int, depth: int, norm: str, up: str, name: str, head_name: str,
-                 dtype: torch.dtype = torch.bfloat16, device=None, seed: int = 1234):
+                 dtype: torch.dtype = torch.bfloat16, device=None, seed: int = 1234, num_classes: int = 1):
         if depth < 1 or input_size <= 0:
             raise ValueError("depth and input_size must be positive")
+        if num_classes < 1:
+            raise ValueError("num_classes must be positive")
+        self.num_classes = num_classes
         if input_size % (2 ** depth):
             raise ValueError(f"input_size {input_size} must be divisible by 2**depth = {2 ** depth}")
         self.input_size, self.base, self.depth, self.norm, self.up = input_size, base_channels, depth, norm, up
@@ -169,9 +172,10 @@ class SegModel(Model):
                 cat_c = 3 * nf
             self.layers.append(LayerRow(_uname(cnt, "concatenate"), "Concatenate", (hw, hw, cat_c), 0, []))
             block(cat_c, nf, hw)
-        self._register(self.head_name + "/kernel", (1, 1, nf, 1))
-        self._register(self.head_name + "/bias", (1,))
-        self.layers.append(LayerRow(self.head_name, "Conv2D", (hw, hw, 1), nf + 1, []))
+        k = self.num_classes
+        self._register(self.head_name + "/kernel", (1, 1, nf, k))
+        self._register(self.head_name + "/bias", (k,))
+        self.layers.append(LayerRow(self.head_name, "Conv2D", (hw, hw, k), nf * k + k, []))
         self.head_channels = nf
 
     def count_params(self) -> int:
@@ -301,6 +305,14 @@ class SegModel(Model):
             if keep:
                 tape.append(("concat", lvl))
             x = self._block_fwd(self.blocks[self.depth + 1 + i], x, skips[lvl], training, tape, keep)
+        if self.num_classes > 1:           # softmax head (unet_vinillia.py:89): probabilities only
+            if keep or mask is not None:
+                self._no_softmax_training()
+            prob = ops.softmax_head_fwd(x, self.param(self.head_name + "/kernel").view(self.head_channels, self.num_classes),
+                                        self.param(self.head_name + "/bias"))
+            if self.audit is not None:
+                self.audit.append(("fwd_softmax_head", self.head_name, x, prob))
+            return prob, None, tape
         w = self.param(self.head_name + "/kernel").view(self.head_channels)
         prob, sums = ops.seg_head_fwd(x, w, self.param(self.head_name + "/bias"), mask, self._ws)
         if keep:
@@ -394,9 +406,18 @@ class SegModel(Model):
         prob, _, _ = self._forward_seg(self._to_dev(x), None, training=training, keep=False)
         return prob.cpu().numpy() if as_numpy else prob
 
+    @staticmethod
+    def _no_softmax_training():
+        raise NotImplementedError(
+            "num_classes > 1: the softmax head is built for inference (model(x) / predict); the reference defines no "
+            "loss or metric for it -- every loss in Segmenation/code is binary (BCE / Dice on one channel) and every "
+            "entry point passes num_classes=1 (unet_vinillia.py:263, unet_vinillia_optuna.py:142)")
+
     def compile(self, optimizer=None, loss=None, metrics=None, jit_compile: bool = False):
         if jit_compile:
             raise ValueError("jit_compile=True is not supported (the reference disables XLA as well)")
+        if self.num_classes > 1:
+            self._no_softmax_training()
         if loss is None or not hasattr(loss, "bce_weight"):
             raise ValueError("loss must come from make_hybrid_ce_dice_loss / make_bce_dice_loss / binary_crossentropy")
         self.optimizer = self._wrap_optimizer(optimizer if optimizer is not None else Adam())
@@ -452,12 +473,13 @@ def build_adaptive_depth_unet(input_size: int = DEFAULT_IMAGE_SIZE, base_channel
 def build_unet(input_size: int, num_classes: int = 1, base_channels: int = 32, depth: int = 4, *,
                dtype: torch.dtype = torch.bfloat16, device=None, seed: int = 1234) -> SegModel:
     """Segmenation/code/unet_vinillia.py:72-91 (name unet_isic_baseline), reference default base_channels=32.
-    num_classes > 1 (a softmax head) is not built: none of the reference's entry points passes anything but 1
-    (unet_vinillia.py:263, unet_vinillia_optuna.py) and its losses / metrics are binary."""
-    if num_classes != 1:
-        raise NotImplementedError("softmax heads (num_classes > 1) are not built; the reference only trains binary masks")
+    num_classes > 1 gives the Conv2D(num_classes, 1, softmax) head of :89-90 for inference (`model(x)`, `predict`,
+    weight loading); compile / train_on_batch / fit raise for it: the reference's losses and metrics are binary and
+    none of its entry points passes anything but 1 (unet_vinillia.py:263, unet_vinillia_optuna.py:142)."""
+    if num_classes < 1:
+        raise ValueError("num_classes must be positive")
     gran = ops.cin_granule(dtype) if base_channels > 0 else 1
     if base_channels <= 0 or base_channels % gran:
         raise ValueError(f"base_channels must be a positive multiple of {gran} for {dtype} (MFMA contraction granule)")
     return SegModel(input_size, base_channels, depth, "ln", "convT", "unet_isic_baseline", "mask_logits",
-                    dtype=dtype, device=device, seed=seed)
+                    dtype=dtype, device=device, seed=seed, num_classes=num_classes)

@@ -267,6 +267,12 @@ int ad_seg_head_bwd(const void* xh, const float* w, const float* target, const f
                     const float* loss_scale /* NULL or device float, as ad_head_bwd */,
                     void* ws, size_t ws_bytes, int dtype, void* stream);
 
+/* Conv2D(num_classes, 1, activation="softmax") head of build_unet(num_classes > 1)
+ * (Segmenation/code/unet_vinillia.py:89-90).  w: [ch][num_classes] fp32 (Keras kernel (1,1,ch,K)), b: [num_classes];
+ * prob: [npix][num_classes] fp32.  Forward only: the reference defines no loss or metric for this head. */
+int ad_softmax_head_fwd(const void* xh, const float* w, const float* b, float* prob, int64_t npix, int ch,
+                        int num_classes, int dtype, void* stream);
+
 /* Same update with the step-dependent factor alpha = lr*sqrt(1-b2^t)/(1-b1^t) read from DEVICE memory, so that a
  * train step captured in a hipGraph can be replayed with a new learning rate / step index (the host writes
  * ad_adam_alpha(lr, b1, b2, t) into alpha_dev before each replay). */

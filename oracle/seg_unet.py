@@ -16,9 +16,11 @@ from . import ops
 
 
 class SegUNetOracle:
-    def __init__(self, input_size: int, base_channels: int = 64, depth: int = 4, norm: str = "bn", up: str = "bilinear"):
+    def __init__(self, input_size: int, base_channels: int = 64, depth: int = 4, norm: str = "bn", up: str = "bilinear",
+                 num_classes: int = 1):
         if input_size % (2 ** depth):
             raise ValueError("input_size must be divisible by 2**depth")
+        self.num_classes = num_classes       # > 1: softmax head (unet_vinillia.py:89-90), forward only
         self.p, self.base, self.depth, self.norm, self.up = input_size, base_channels, depth, norm, up
         self.param_shapes: Dict[str, tuple] = {}
         self.state_shapes: Dict[str, tuple] = {}
@@ -63,8 +65,8 @@ class SegUNetOracle:
                 self.ups.append(None)
                 block(3 * nf, nf)      # concat([upsampled 2nf, skip nf])
         self.head = "lesion_mask" if norm == "bn" else "mask_logits"
-        self.param_shapes[self.head + "/kernel"] = (1, 1, nf, 1)
-        self.param_shapes[self.head + "/bias"] = (1,)
+        self.param_shapes[self.head + "/kernel"] = (1, 1, nf, num_classes)
+        self.param_shapes[self.head + "/bias"] = (num_classes,)
 
     def count_params(self):
         return sum(int(np.prod(s)) for s in self.param_shapes.values())
@@ -132,6 +134,10 @@ class SegUNetOracle:
             x = np.concatenate([x, skips[lvl]], axis=-1)
             x = self._block_fwd(x, self.blocks[self.depth + 1 + i], params, state, training, tape, st)
         logit = ops.conv2d_same_fwd(x, params[self.head + "/kernel"], params[self.head + "/bias"])
+        if self.num_classes > 1:             # activation="softmax" over the class axis; no loss is defined for it
+            e = np.exp(logit - logit.max(axis=-1, keepdims=True))
+            self._tape, self._storage = None, st
+            return e / e.sum(axis=-1, keepdims=True)
         p = ops.sigmoid(logit)
         tape.append(("head", x, p))
         self._tape = tape

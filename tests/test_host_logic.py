@@ -171,3 +171,18 @@ def test_experiment_2_sweep_table_matches_the_reference_launcher():
     assert all(t["batch_size"] >= r["batch_size"] for t, r in zip(R.plan(), table))
     args = R.parse_args(["--high_res_dir", "/x", "--scales", "0.30", "0.50"])
     assert args.scales == ["0.30", "0.50"] and args.patch_size == 256 and args.epochs == 100
+
+
+def test_oracle_softmax_head_of_build_unet():
+    """oracle restatement of build_unet(num_classes > 1) (unet_vinillia.py:89-90): class probabilities per pixel."""
+    from oracle.seg_unet import SegUNetOracle
+    o = SegUNetOracle(16, 8, 2, "ln", "convT", num_classes=4)
+    assert o.param_shapes["mask_logits/kernel"] == (1, 1, 8, 4) and o.param_shapes["mask_logits/bias"] == (4,)
+    rng = np.random.default_rng(0)
+    params, state = o.init_params(rng)
+    params["mask_logits/kernel"] = rng.standard_normal((1, 1, 8, 4))
+    prob = o.forward(params, state, rng.random((2, 16, 16, 3)))
+    assert prob.shape == (2, 16, 16, 4) and np.allclose(prob.sum(-1), 1.0) and (prob > 0).all()
+    # one class: unchanged sigmoid head
+    o1 = SegUNetOracle(16, 8, 2, "ln", "convT")
+    assert o1.param_shapes["mask_logits/kernel"] == (1, 1, 8, 1)

@@ -218,3 +218,36 @@ def test_segmentation_under_mixed_float16(device):
     assert all(np.isfinite(v) for v in losses) and losses[-1] < losses[0]
     assert st["applied"] + st["skipped"] == 12 and st["applied"] >= 8 and st["loss_scale"] >= 1.0
     assert torch.isfinite(model.P).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_build_unet_softmax_head_forward(device, dtype):
+    """build_unet(num_classes > 1): Conv2D(K, 1, softmax) head (Segmenation/code/unet_vinillia.py:89-90), inference only.
+    The reference defines no loss for it and never passes num_classes != 1, so training entry points must refuse."""
+    from adunet_amd import seg_model as S
+    p, depth, k, batch = 32, 2, 5, 3
+    model = S.build_unet(p, k, 32 if dtype == torch.bfloat16 else 16, depth, dtype=dtype, device=device)
+    base = model.base
+    oracle = SegUNetOracle(p, base, depth, "ln", "convT", num_classes=k)
+    rng = np.random.default_rng(5)
+    params, state = oracle.init_params(rng)
+    params[oracle.head + "/kernel"] = rng.standard_normal(oracle.param_shapes[oracle.head + "/kernel"]) * 0.7
+    params[oracle.head + "/bias"] = rng.standard_normal(k) * 0.3
+    params = {n: v.astype(np.float32).astype(np.float64) for n, v in params.items()}
+    assert list(model.index) == list(oracle.param_shapes)
+    assert model.count_params() == oracle.count_params()
+    model.set_weights({n: v.astype(np.float32) for n, v in params.items()})
+    img = rng.random((batch, p, p, 3), dtype=np.float32)
+    storage = storage_of(model, batch) if dtype == torch.bfloat16 else None
+    want = oracle.forward(params, state, img.astype(np.float64), training=False, storage=storage)
+    got = model(img)
+    assert got.shape == (batch, p, p, k) and got.dtype == np.float32
+    assert np.abs(got.sum(axis=-1) - 1.0).max() < 1e-5
+    assert np.abs(got - want).max() < (2e-4 if dtype == torch.float32 else 2e-2)
+    assert (got.argmax(-1) == want.argmax(-1)).mean() > (0.999 if dtype == torch.float32 else 0.97)
+    proto = S.PROTOCOLS["A"]
+    with pytest.raises(NotImplementedError):
+        model.compile(optimizer=S.build_optimizer(proto, 10, 2), loss=proto.loss_builder())
+    with pytest.raises(NotImplementedError):
+        model._forward_seg(model._to_dev(img), None, training=True, keep=True)
