@@ -174,8 +174,12 @@ def test_seg_builders_contract():
     assert S.build_unet(128, 1, 32, 4).convs["conv2d"].cout == 32       # the reference's default width (unet_vinillia.py:72)
     with pytest.raises(ValueError):
         S.build_unet(128, 1, 40, 4)                       # not a multiple of the bf16 contraction granule
+    m19 = S.build_unet(128, 19, 64, 4)                    # softmax head: built for inference, training entry points refuse
+    assert m19.index["mask_logits/kernel"][1] == (1, 1, 64, 19)
     with pytest.raises(NotImplementedError):
-        S.build_unet(128, 19, 64, 4)
+        m19.compile(loss=S.PROTOCOLS["A"].loss_builder())
+    with pytest.raises(ValueError):
+        S.build_unet(128, 0, 64, 4)
     assert S.PROTOCOLS["B"].loss_builder().dice_weight == 1.0 and S.PROTOCOLS["B"].batch_size == 16
 
 
