@@ -2308,7 +2308,8 @@ int launch_fwd(ConvArgs a, void* ws, size_t ws_bytes, hipStream_t s);
 static bool map1_ok(int n, int h, int w, int c1, int c2, int cout, int cy1) {
     static const bool off = getenv("ADUNET_NO_MAP1") != nullptr;      // A/B switch
     if (off) return false;
-    return h == 1 && w == 1 && n >= 1 && n <= (1 << 20) && (c1 + c2) % 128 == 0 && c1 % 32 == 0 && c1 + c2 <= 8192 &&
+    const long long in_bytes = (long long)n * (c1 > c2 ? c1 : c2) * 2;        // 32-bit offsets inside the kernel
+    return h == 1 && w == 1 && n >= 1 && in_bytes <= WR_MAX_BYTES && (c1 + c2) % 128 == 0 && c1 % 32 == 0 && c1 + c2 <= 8192 &&
            cout % 16 == 0 && cout <= 8192 && cy1 % 16 == 0;
 }
 
@@ -2316,8 +2317,9 @@ static bool map1_ok(int n, int h, int w, int c1, int c2, int cout, int cy1) {
 static bool map4_ok(int n, int h, int w, int c1, int c2, int cout, int cy1) {
     static const bool off = getenv("ADUNET_NO_MAP4") != nullptr;      // A/B switch
     if (off) return false;
-    return h == 4 && w == 4 && n >= 1 && n <= (1 << 16) && (c1 + c2) % 128 == 0 && c1 % 128 == 0 && c1 + c2 <= 8192 &&
-           cout % 16 == 0 && cout <= 8192 && cy1 % 16 == 0;        // 32-bit offsets inside the kernel
+    const long long in_bytes = (long long)n * 16 * (c1 > c2 ? c1 : c2) * 2;   // 32-bit offsets inside the kernel
+    return h == 4 && w == 4 && n >= 1 && in_bytes <= WR_MAX_BYTES && (c1 + c2) % 128 == 0 && c1 % 128 == 0 && c1 + c2 <= 8192 &&
+           cout % 16 == 0 && cout <= 8192 && cy1 % 16 == 0;
 }
 
 template <typename P>
