@@ -114,6 +114,9 @@ template <> struct Vec16<f16_t> {
     }
 };
 
+template <typename A, typename B> struct ad_same_type { static constexpr bool value = false; };
+template <typename A> struct ad_same_type<A, A> { static constexpr bool value = true; };
+
 static inline int ad_ilog2(int v) {
     int l = 0;
     while ((1 << l) < v) ++l;

@@ -282,6 +282,7 @@ __device__ __forceinline__ uint4 load_w_slot(const char* wp, int kc_total, int c
 
 #define AD_EPI_LN_RELU 2        // internal: ad_conv3x3_ln_relu_fwd
 #define AD_EPI_MASK 3           // internal: ad_conv3x3_dgrad_relu (ReLU-grad of the producer fused into this dgrad)
+#define AD_EPI_LNBWD 4          // internal: ad_conv3x3_dgrad_ln_bwd (LayerNorm + ReLU backward of the producer fused into this dgrad)
 #define AD_ERR_UNFUSED 1000     // internal: no fused kernel for this shape, run the two launches
 
 struct ConvArgs {
@@ -300,6 +301,10 @@ struct ConvArgs {
     // AD_EPI_MASK: outputs of y1's blocks are zeroed where mask1 (the producer's stored ReLU output, laid out like y1)
     // is not positive; dbias_part[workgroup][64] receives the column sums of what the workgroup stored into y1
     const char* mask1; float* dbias_part;
+    // AD_EPI_LNBWD: the dgrad's 64 output channels are the gradient of a LayerNorm + ReLU output; lnb_z is that layer's
+    // stored conv output (laid out like y1), ln_mean / ln_rstd / ln_gamma / ln_beta its statistics and parameters (inputs
+    // here); y1 receives dz of that layer, dbias_part[workgroup][wave][3][64] the column sums for dgamma / dbeta / dbias
+    const char* lnb_z;
     Geo g;
 };
 
@@ -920,6 +925,171 @@ __device__ __forceinline__ void ws_mma_role(const ConvArgs& a, const char* xb0, 
 #undef WSTAMP
 }
 
+// ---- the MFMA-wave role of a dgrad whose output is the gradient of a Conv2D -> LayerNorm -> ReLU layer (EPI 4) ------------
+// conv_block's second conv (and the layer after the decoder) takes the previous LayerNorm's activation as input, so the
+// dgrad's 64 output channels are d(activation) of that layer and the very next thing is its LayerNorm / ReLU backward
+// (norm.hip ln_bwd_kernel: read d and z, write dz: 1.6 GB per full-resolution layer).  Here the wave that holds a pixel's
+// 64 gradient values in its fp32 accumulators does that arithmetic itself: z (8-byte pieces in accumulator layout),
+// mean and rstd of the item's pixels are fetched during the MFMA phases, the masks are re-derived from z as the
+// stand-alone kernel does, the two per-pixel sums are lane-swap butterflies, dz leaves as 16-byte pieces and the three
+// per-channel sums (dgamma, dbeta and the conv bias gradient = column sums of dz AS STORED) stay in 48 registers per
+// lane until the end of the launch.  The gradient of the activation never goes to memory.
+template <typename P>
+__device__ __forceinline__ void ws_mma_role_lnb(const ConvArgs& a, const char* xb0, const char* xb1, const char* wt0,
+                                                const char* wt1, const float* gb, int wave, int lane, const WsOrder& o) {
+    typedef typename P::T E;
+    typedef typename Half16<E>::v4 h4;
+    constexpr int TSZ = 2;
+    constexpr int HWB = 18 * PIXB;
+    constexpr int CY = BN;
+    const Geo& g = a.g;
+    const int nloc = o.nloc;
+    const int npix = a.n * a.h * a.w;
+    const int grp = lane >> 4;
+    const auto rsy = wave_uniform_rsrc(a.y1, npix * CY * TSZ);
+    const auto rsz = wave_uniform_rsrc(a.lnb_z, npix * CY * TSZ);
+    const auto rsm = wave_uniform_rsrc(a.ln_mean, npix * 4);
+    const auto rsr = wave_uniform_rsrc(a.ln_rstd, npix * 4);
+    const int abase0 = ((wave * 4 + 1) * 18 + (lane & 15) + 1) * PIXB + P::a_lane_off(lane);
+    // byte offsets inside y1 / lnb_z of this lane's pixel of m-tile mt: px(mt) = (4 wave + mt) * w + (lane & 15);
+    //   store layout (after the row swap, ws_pack_tile):  px * 128 + scst,  scst = ((grp & 1) * 16 + (grp >> 1) * 8) * 2
+    //   accumulator layout (z pieces of n-tile nt):       px * 128 + grp * 8 (+ nt * 32)
+    // kept as one register each (px0s, zdiff) and re-derived per item: this role is register bound
+    const int scst = ((grp & 1) * 16 + (grp >> 1) * 8) * TSZ;
+    const int px0s = ((wave * 4) * a.w + (lane & 15)) * CY * TSZ + scst;
+    const int zdiff = grp * 4 * TSZ - scst;
+    float cg[16], cb[16], cz[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) cg[j] = cb[j] = cz[j] = 0.f;
+    u32x2 zq[16];
+    float mu[4], rs[4];
+    int pixbase = 0, ylim = 0;                  // of the current item (wave uniform)
+    bool xok = false;
+    // store offset of this lane's pixel of m-tile mt, out of range past the image edge; re-derived where it is needed
+    // instead of being kept through the MFMA phases
+    auto pvo_of = [&](int mt) -> unsigned {
+        return xok && wave * 4 + mt < ylim ? (unsigned)((pixbase + mt * a.w) * CY * TSZ + px0s) : WR_OOB;
+    };
+    // mean / rstd / z of m-tiles mt0, mt0 + 1 (out of range where the pixel is: zeros, rstd = 0 -> dz = 0)
+    auto fetch = [&](int mt0) {
+#pragma unroll
+        for (int mt = mt0; mt < mt0 + 2; ++mt) {
+            const unsigned pv = pvo_of(mt);
+            const unsigned so = pv != WR_OOB ? (pv - scst) >> 5 : WR_OOB;            // (pixel index) * 4
+            mu[mt] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsm, so, 0, 0));
+            rs[mt] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsr, so, 0, 0));
+        }
+#pragma unroll
+        for (int mt = mt0; mt < mt0 + 2; ++mt) {
+            const unsigned pv = pvo_of(mt);
+            const unsigned zo = pv != WR_OOB ? pv + zdiff : WR_OOB;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) zq[mt * 4 + nt] = __builtin_amdgcn_raw_buffer_load_b64(rsz, zo, nt * 16 * TSZ, 0);
+        }
+    };
+    // the first two m-tiles' operands are fetched during the MFMA phases, the other two at the start of the epilogue,
+    // behind the arithmetic of the first two: everything in flight through the MFMA phases would need ~20 more live
+    // registers than there are
+    auto hook0 = [&](int st) {
+        if (st != 0) return;
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    int tx, ty, nn, sx, sy, sn;
+    {
+        const int r0 = o.slot0 / g.tiles_x, rs0 = o.stride / g.tiles_x;
+        tx = o.slot0 - r0 * g.tiles_x; nn = r0 / g.tiles_y; ty = r0 - nn * g.tiles_y;
+        sx = o.stride - rs0 * g.tiles_x; sn = rs0 / g.tiles_y; sy = rs0 - sn * g.tiles_y;
+    }
+    for (int k = 0; k < nloc; ++k) {
+        const int x0 = tx << 4, y0 = ty << 4;
+        pixbase = (nn * a.h + y0) * a.w + x0;
+        ylim = a.h - y0;
+        xok = (lane & 15) < a.w - x0;
+        tx += sx;
+        if (tx >= g.tiles_x) { tx -= g.tiles_x; ++ty; }
+        ty += sy;
+        if (ty >= g.tiles_y) { ty -= g.tiles_y; ++nn; }
+        nn += sn;
+        f32x4 acc[4][4];
+        f32x4 c0[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c0[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        lds_barrier();                                  // even stage (chunk 0) ready
+        P::template mma_chunk_rows<true>(acc, xb0, abase0, HWB, wt0, lane, hook0, c0);
+        lds_barrier();                                  // odd stage (chunk 1) ready
+        P::mma_chunk_rows(acc, xb1, abase0, HWB, wt1, lane, [](int) {});
+        // ---- LayerNorm + ReLU backward of the 64 values per pixel this wave holds
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(2);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const unsigned pvo_mt = pvo_of(mt);
+            const bool valid = pvo_mt != WR_OOB;
+            const float mean = mu[mt], rstd = rs[mt];
+            float xh[16], gg[16];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const float4 ga = *reinterpret_cast<const float4*>(gb + nt * 16 + grp * 4);
+                const float4 be = *reinterpret_cast<const float4*>(gb + 64 + nt * 16 + grp * 4);
+                const float gaa[4] = {ga.x, ga.y, ga.z, ga.w}, bea[4] = {be.x, be.y, be.z, be.w};
+                union { h4 h; u32x2 u; } zz;
+                zz.u = zq[mt * 4 + nt];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float h = ((float)zz.h[q] - mean) * rstd;
+                    const float yv = h * gaa[q] + bea[q];
+                    const float dl = (valid && yv > 0.f) ? acc[mt][nt][q] : 0.f;
+                    cg[nt * 4 + q] += dl * h;
+                    cb[nt * 4 + q] += dl;
+                    const float gv = dl * gaa[q];
+                    s1 += gv;
+                    s2 += gv * h;
+                    xh[nt * 4 + q] = h;
+                    gg[nt * 4 + q] = gv;
+                }
+            }
+            s1 = sum_lane_groups(s1) * (1.f / 64.f);
+            s2 = sum_lane_groups(s2) * (1.f / 64.f);
+#pragma unroll
+            for (int np = 0; np < 2; ++np) {
+                union { h4 h; u32x2 u; } pa, pb;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int ja = (2 * np) * 4 + q, jb = (2 * np + 1) * 4 + q;
+                    pa.h[q] = (E)(rstd * (gg[ja] - s1 - xh[ja] * s2));
+                    pb.h[q] = (E)(rstd * (gg[jb] - s1 - xh[jb] * s2));
+                    cz[ja] += (float)pa.h[q];           // the conv bias gradient sums dz as stored (what wgrad sees)
+                    cz[jb] += (float)pb.h[q];
+                }
+                const u32x2 w0 = __builtin_amdgcn_permlane16_swap(pa.u[0], pb.u[0], false, false);
+                const u32x2 w1 = __builtin_amdgcn_permlane16_swap(pa.u[1], pb.u[1], false, false);
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{w0[0], w1[0], w0[1], w1[1]}, rsy, pvo_mt, np * 32 * TSZ, 0);
+            }
+        }
+    }
+    // column sums: fold the 16 pixel lanes of each lane group; one row of 3 x 64 per MFMA wave goes to
+    // dbias_part[workgroup][wave][dgamma | dbeta | dbias][64], lnb_reduce_kernel adds the rows in a fixed order
+    float* row = a.dbias_part + ((size_t)blockIdx.x * 4 + wave) * (3 * BN);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        float v0 = cg[j], v1 = cb[j], v2 = cz[j];
+#pragma unroll
+        for (int of = 1; of < 16; of <<= 1) {
+            v0 += __shfl_xor(v0, of, 64);
+            v1 += __shfl_xor(v1, of, 64);
+            v2 += __shfl_xor(v2, of, 64);
+        }
+        if ((lane & 15) == 0) {
+            const int ch = (j >> 2) * 16 + grp * 4 + (j & 3);
+            row[ch] = v0; row[BN + ch] = v1; row[2 * BN + ch] = v2;
+        }
+    }
+}
+
 template <typename P, int EPI>
 __global__ __launch_bounds__(WR_T, 1) void conv3x3_fwd_wres_kernel(ConvArgs a) {
     typedef typename P::T T;
@@ -948,7 +1118,7 @@ __global__ __launch_bounds__(WR_T, 1) void conv3x3_fwd_wres_kernel(ConvArgs a) {
     }
 
     float* gb = reinterpret_cast<float*>(wt + 2 * WT_BYTES);
-    if (EPI == 2) {       // [gamma][beta][bias] of the 64 output channels; visible to the MFMA waves after this barrier
+    if (EPI == 2 || EPI == 4) {       // [gamma][beta][bias] of the 64 output channels; visible to the MFMA waves after this barrier
         if (tid < 64) {
             gb[tid] = a.ln_gamma[tid]; gb[64 + tid] = a.ln_beta[tid]; gb[128 + tid] = a.bias ? a.bias[tid] : 0.f;
         }
@@ -1033,7 +1203,8 @@ __global__ __launch_bounds__(WR_T, 1) void conv3x3_fwd_wres_kernel(ConvArgs a) {
 #undef WR_ISSUE_B
 #undef WR_STORE
     } else {
-        ws_mma_role<P, EPI>(a, xb0, xb1, wt, wt + WT_BYTES, gb, wave, lane, o, 2);
+        if constexpr (EPI == 4) ws_mma_role_lnb<P>(a, xb0, xb1, wt, wt + WT_BYTES, gb, wave, lane, o);
+        else ws_mma_role<P, EPI>(a, xb0, xb1, wt, wt + WT_BYTES, gb, wave, lane, o, 2);
     }
 }
 
@@ -1066,7 +1237,7 @@ __global__ __launch_bounds__(WR_T, 1) void conv3x3_fwd_ws_kernel(ConvArgs a) {
     const int npix = a.n * a.h * a.w;
     const int nloc = o.nloc;                        // items of this workgroup (>= 1)
     float* gb = reinterpret_cast<float*>(wt1 + WT_BYTES);
-    if (EPI == 2) {       // [gamma][beta][bias] of the 64 output channels; visible to the MFMA waves after this barrier
+    if (EPI == 2 || EPI == 4) {       // [gamma][beta][bias] of the 64 output channels; visible to the MFMA waves after this barrier
         if (tid < 64) {
             gb[tid] = a.ln_gamma[tid]; gb[64 + tid] = a.ln_beta[tid]; gb[128 + tid] = a.bias ? a.bias[tid] : 0.f;
         }
@@ -2166,6 +2337,26 @@ __global__ __launch_bounds__(1024) void mask_dbias_reduce_kernel(const float* __
     }
 }
 
+// dgamma / dbeta / dbias of ad_conv3x3_dgrad_ln_bwd: part[workgroup][wave][3][64]; block q sums quantity q over the
+// 4 * nwg rows: 16 row groups in ascending order with eight loads in flight, folded in a fixed order (deterministic).
+__global__ __launch_bounds__(1024) void lnb_reduce_kernel(const float* __restrict__ part, int nrows, float* __restrict__ o0,
+                                                          float* __restrict__ o1, float* __restrict__ o2) {
+    __shared__ float sm[16][BN];
+    const int q = blockIdx.x, col = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    float s = 0.f;
+#pragma unroll 8
+    for (int r = rg; r < nrows; r += 16) s += part[(size_t)r * (3 * BN) + q * BN + col];
+    sm[rg][col] = s;
+    __syncthreads();
+    if (rg == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += sm[r][col];
+        float* dst = q == 0 ? o0 : q == 1 ? o1 : o2;
+        if (dst) dst[col] = t;
+    }
+}
+
 // ------------------------------------------------------------------ weight packing
 // w_fwd[tap][kc][co][kv] = W[tap][kc*KV+kv][co]; w_dgrad[tap'][kc][ci][kv] = W[8-tap'][ci][kc*KV+kv].
 // The output-channel dimension of each pack (co of w_fwd, ci of w_dgrad) is padded with zeros to whole 64-channel
@@ -2370,12 +2561,13 @@ int launch_fwd(ConvArgs a, void* ws, size_t ws_bytes, hipStream_t s) {
             allow_big_lds(conv3x3_fwd_ws_kernel<P, 1>);
             allow_big_lds(conv3x3_fwd_ws_kernel<P, 2>);
             allow_big_lds(conv3x3_fwd_wres_kernel<P, 3>);
+            if constexpr (!ad_same_type<typename P::T, f16_t>::value) allow_big_lds(conv3x3_fwd_wres_kernel<P, 4>);
         }
         attr_set = true;
     }
     if constexpr (sizeof(typename P::T) == 2) {
         a.ksplit = 1; a.slab = nullptr;
-        if (map4_ok(a.n, a.h, a.w, a.c1, a.c2, a.cout_real, a.cy1) && a.epilogue != AD_EPI_LN_RELU && a.epilogue != AD_EPI_MASK) {
+        if (map4_ok(a.n, a.h, a.w, a.c1, a.c2, a.cout_real, a.cy1) && a.epilogue <= AD_EPI_RELU) {
             static bool m4_attr = false;
             if (!m4_attr) {
                 allow_big_lds(conv3x3_map4_kernel<P, 2>);
@@ -2391,7 +2583,7 @@ int launch_fwd(ConvArgs a, void* ws, size_t ws_bytes, hipStream_t s) {
             AD_LAUNCH_CHECK("conv3x3_map4");
             return AD_OK;
         }
-        if (map1_ok(a.n, a.h, a.w, a.c1, a.c2, a.cout_real, a.cy1) && a.epilogue != AD_EPI_LN_RELU && a.epilogue != AD_EPI_MASK) {
+        if (map1_ok(a.n, a.h, a.w, a.c1, a.c2, a.cout_real, a.cy1) && a.epilogue <= AD_EPI_RELU) {
             const int mblk = (a.n + 63) / 64;
             conv3x3_map1_kernel<P, 2><<<mblk * ((a.cout_real + 31) / 32), M1_T, 0, s>>>(a);
             AD_LAUNCH_CHECK("conv3x3_map1");
@@ -2407,6 +2599,17 @@ int launch_fwd(ConvArgs a, void* ws, size_t ws_bytes, hipStream_t s) {
             AD_LAUNCH_CHECK("conv3x3_fwd_wres (relu-grad)");
             return AD_OK;
         }
+        if (a.epilogue == AD_EPI_LNBWD) {
+            // bf16 only: the fp16 instantiation does not fit 256 registers (9 spills); fp16 runs the two launches
+            if constexpr (sizeof(typename P::T) == 2 && !ad_same_type<typename P::T, f16_t>::value) {
+                if (kind != 1 || a.cout_real != BN) return AD_ERR_UNFUSED;
+                conv3x3_fwd_wres_kernel<P, 4><<<NUM_CU, WR_T, WR_LDS, s>>>(a);
+                AD_LAUNCH_CHECK("conv3x3_fwd_wres (layernorm-bwd)");
+                return AD_OK;
+            } else {
+                return AD_ERR_UNFUSED;
+            }
+        }
 #define AD_WS_LAUNCH(KERN, NAME)                                                                     \
     {                                                                                                \
         if (a.epilogue == AD_EPI_LN_RELU) KERN<P, 2><<<NUM_CU, WR_T, WR_LDS, s>>>(a);                \
@@ -2419,7 +2622,7 @@ int launch_fwd(ConvArgs a, void* ws, size_t ws_bytes, hipStream_t s) {
         if (kind == 2) AD_WS_LAUNCH(conv3x3_fwd_ws_kernel, "conv3x3_fwd_ws")
 #undef AD_WS_LAUNCH
     }
-    if (a.epilogue == AD_EPI_LN_RELU || a.epilogue == AD_EPI_MASK) return AD_ERR_UNFUSED;     // the caller runs two launches
+    if (a.epilogue == AD_EPI_LN_RELU || a.epilogue == AD_EPI_MASK || a.epilogue == AD_EPI_LNBWD) return AD_ERR_UNFUSED;     // the caller runs two launches
     size_t lds = 2 * (size_t)g.NPHP * 4 + 2 * BN * 4 + (((size_t)g.NPH * PIXB + 15) & ~15) + (size_t)FWS * FT * 16;
     if (lds > 160 * 1024) return ad_set_error(AD_ERR_ARG, "conv3x3_fwd: LDS %zu too large", lds);
     const int per_cu = lds <= 80 * 1024 ? 2 : 1;
@@ -2581,7 +2784,7 @@ extern "C" int ad_conv3x3_fwd(const void* x1, int c1, const void* x2, int c2, co
     a.dbg = g_dbg;
     a.ksplit = 1; a.slab = nullptr;
     a.ln_gamma = a.ln_beta = nullptr; a.ln_eps = 0.f; a.a_out = nullptr; a.ln_mean = a.ln_rstd = nullptr;
-    a.mask1 = nullptr; a.dbias_part = nullptr;
+    a.mask1 = nullptr; a.dbias_part = nullptr; a.lnb_z = nullptr;
     pick_geo(n, h, w, &a.g);
     a.ntiles = a.g.tiles_x * a.g.tiles_y * a.g.tiles_i;
     hipStream_t s = (hipStream_t)stream;
@@ -2617,7 +2820,7 @@ extern "C" int ad_conv3x3_ln_relu_fwd(const void* x1, int c1, const void* x2, in
     a.ksplit = 1; a.slab = nullptr;
     a.ln_gamma = gamma; a.ln_beta = beta; a.ln_eps = eps;
     a.a_out = (char*)act; a.ln_mean = mean; a.ln_rstd = rstd;
-    a.mask1 = nullptr; a.dbias_part = nullptr;
+    a.mask1 = nullptr; a.dbias_part = nullptr; a.lnb_z = nullptr;
     pick_geo(n, h, w, &a.g);
     a.ntiles = a.g.tiles_x * a.g.tiles_y * a.g.tiles_i;
     hipStream_t s = (hipStream_t)stream;
@@ -2666,7 +2869,7 @@ extern "C" int ad_conv3x3_dgrad_relu(const void* dz, int c1, const void* w_dgrad
     a.dbg = g_dbg;
     a.ksplit = 1; a.slab = nullptr;
     a.ln_gamma = a.ln_beta = nullptr; a.ln_eps = 0.f; a.a_out = nullptr; a.ln_mean = a.ln_rstd = nullptr;
-    a.mask1 = (const char*)relu_out; a.dbias_part = (float*)ws;
+    a.mask1 = (const char*)relu_out; a.dbias_part = (float*)ws; a.lnb_z = nullptr;
     pick_geo(n, h, w, &a.g);
     a.ntiles = a.g.tiles_x * a.g.tiles_y * a.g.tiles_i;
     hipStream_t s = (hipStream_t)stream;
@@ -2674,6 +2877,48 @@ extern "C" int ad_conv3x3_dgrad_relu(const void* dz, int c1, const void* w_dgrad
     if (rc) return rc == AD_ERR_UNFUSED ? ad_set_error(AD_ERR_ARG, "ad_conv3x3_dgrad_relu: launch not specialised") : rc;
     mask_dbias_reduce_kernel<<<(cy1 + BN - 1) / BN, 1024, 0, s>>>((const float*)ws, NUM_CU, cout / BN, cy1, dbias);
     AD_LAUNCH_CHECK("mask_dbias_reduce");
+    return AD_OK;
+}
+
+// ---- dgrad with the producer's LayerNorm + ReLU backward fused (conv_block's second conv, Super_resolution/code/
+// train_adaptive_unet.py:200-210: its input is the first LayerNorm's activation)
+extern "C" int ad_conv3x3_dgrad_ln_bwd_is_fused(int n, int h, int w, int c1, int cout, int dtype) {
+    static const bool off = getenv("ADUNET_NO_DGRAD_LN") != nullptr;      // A/B switch
+    if (off || dtype != AD_BF16 || n <= 0 || h <= 0 || w <= 0 || c1 <= 0 || cout != BN) return 0;      // (fp16: see launch_fwd)
+    if (images_per_launch(n, h, w, c1, 0, cout, false, false) < n) return 0;        // image runs: plain path
+    return fwd_ws_kind(n, h, w, c1, 0, cout, false) == 1;      // weights-resident kernel (contraction over 64 channels)
+}
+
+extern "C" size_t ad_conv3x3_dgrad_ln_bwd_ws_bytes(void) { return (size_t)NUM_CU * 4 * 3 * BN * sizeof(float); }
+
+extern "C" int ad_conv3x3_dgrad_ln_bwd(const void* dz, int c1, const void* w_dgrad, const void* z_prev, const float* mean,
+                                       const float* rstd, const float* gamma, const float* beta, void* dz_prev,
+                                       float* dgamma, float* dbeta, float* dbias, int n, int h, int w, int cout, void* ws,
+                                       size_t ws_bytes, int dtype, void* stream) {
+    AD_REQUIRE(ad_conv3x3_dgrad_ln_bwd_is_fused(n, h, w, c1, cout, dtype),
+               "ad_conv3x3_dgrad_ln_bwd: no fused kernel for n=%d %dx%d c1=%d cout=%d dtype=%d (ask _is_fused first)", n, h, w, c1,
+               cout, dtype);
+    AD_REQUIRE(dz && w_dgrad && z_prev && mean && rstd && gamma && beta && dz_prev, "ad_conv3x3_dgrad_ln_bwd: bad operands");
+    if (!ws || ws_bytes < ad_conv3x3_dgrad_ln_bwd_ws_bytes())
+        return ad_set_error(AD_ERR_WS, "ad_conv3x3_dgrad_ln_bwd: workspace %zu < %zu bytes", ws_bytes,
+                            ad_conv3x3_dgrad_ln_bwd_ws_bytes());
+    ConvArgs a;
+    a.x1 = (const char*)dz; a.x2 = nullptr; a.c1 = c1; a.c2 = 0;
+    a.wp = (const char*)w_dgrad; a.bias = nullptr;
+    a.y1 = (char*)dz_prev; a.y2 = nullptr; a.cy1 = cout;
+    a.n = n; a.h = h; a.w = w; a.cout = cout; a.cout_real = cout; a.epilogue = AD_EPI_LNBWD;
+    a.dbg = g_dbg;
+    a.ksplit = 1; a.slab = nullptr;
+    a.ln_gamma = gamma; a.ln_beta = beta; a.ln_eps = 0.f; a.a_out = nullptr;
+    a.ln_mean = const_cast<float*>(mean); a.ln_rstd = const_cast<float*>(rstd);
+    a.mask1 = nullptr; a.dbias_part = (float*)ws; a.lnb_z = (const char*)z_prev;
+    pick_geo(n, h, w, &a.g);
+    a.ntiles = a.g.tiles_x * a.g.tiles_y * a.g.tiles_i;
+    hipStream_t s = (hipStream_t)stream;
+    const int rc = launch_fwd_dtype(dtype, a, nullptr, 0, s);
+    if (rc) return rc == AD_ERR_UNFUSED ? ad_set_error(AD_ERR_ARG, "ad_conv3x3_dgrad_ln_bwd: launch not specialised") : rc;
+    lnb_reduce_kernel<<<3, 1024, 0, s>>>((const float*)ws, NUM_CU * 4, dgamma, dbeta, dbias);
+    AD_LAUNCH_CHECK("lnb_reduce");
     return AD_OK;
 }
 

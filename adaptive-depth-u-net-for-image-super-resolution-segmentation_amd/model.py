@@ -603,7 +603,23 @@ class Model:
                         d, dsk = ops.conv3x3_fwd(dz, None, self._packs[cs.name][1], None, cs.cin, split=x1.shape[-1])
                     dskips[lvl] = dsk
                 else:
-                    d = ops.conv3x3_fwd(dz, None, self._packs[cs.name][1], None, self._cin_pad(cs))
+                    nxt = tape[-1] if tape else None
+                    if (nxt is not None and nxt[0] == "cla" and nxt[4].shape == x1.shape and nxt[4].shape[-1] == cs.cin
+                            and os.environ.get("ADUNET_NO_DGRAD_LN_FUSION") != "1"
+                            and ops.conv3x3_dgrad_ln_bwd_is_fused(dz, cs.cin)):
+                        # x1 is the activation of the Conv2D -> LayerNorm -> ReLU layer right below (conv_block's second
+                        # conv, :200-210): that layer's LayerNorm / ReLU backward runs in this dgrad's epilogue, the
+                        # gradient of the activation never goes to memory
+                        _, hcs, _, _, hz, hmean, hrstd, _ = nxt
+                        dz_ready = ops.conv3x3_dgrad_ln_bwd(dz, self._packs[cs.name][1], hz, hmean, hrstd,
+                                                            self.param(hcs.ln + "/gamma"), self.param(hcs.ln + "/beta"),
+                                                            self.grad(hcs.ln + "/gamma"), self.grad(hcs.ln + "/beta"),
+                                                            self.grad(hcs.name + "/bias"), ws)
+                        d = None
+                        if audit is not None:
+                            audit.append(("bwd_dgrad_ln", cs.name, dz, hcs.name, hz, hmean, hrstd, dz_ready))
+                    else:
+                        d = ops.conv3x3_fwd(dz, None, self._packs[cs.name][1], None, self._cin_pad(cs))
                 relu_done = fused_relu
                 if audit is not None:
                     # (the skip half is accumulated into in place later on: record a copy)
@@ -790,7 +806,10 @@ class Model:
             g = torch.cuda.CUDAGraph()
             if cap["pool"] is None:
                 cap["pool"] = torch.cuda.graph_pool_handle()
-            g.capture_begin(pool=cap["pool"])       # one pool: later segments see (and keep alive) the earlier ones' tensors
+            # one pool: later segments see (and keep alive) the earlier ones' tensors.  thread_local: the process group's
+            # watchdog thread polls events while we capture; in the default "global" mode its hipEventQuery fails with
+            # hipErrorStreamCaptureUnsupported and takes the process down
+            g.capture_begin(pool=cap["pool"], capture_error_mode="thread_local")
             cap["g"] = g
 
         def seg_end(buckets, sync=False):
@@ -842,7 +861,7 @@ class Model:
         set_alpha()
         if dp is None:
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):      # (a process group may exist: see seg_begin)
                 outputs = body(True)
             segs.append((graph, [], False))
         else:

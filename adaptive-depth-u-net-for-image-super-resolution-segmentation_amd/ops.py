@@ -216,6 +216,28 @@ def conv3x3_fwd(x1: torch.Tensor, x2: Optional[torch.Tensor], w_packed: torch.Te
     return (y1, y2) if split is not None else y1
 
 
+def conv3x3_dgrad_ln_bwd_is_fused(dz: torch.Tensor, cout: int) -> bool:
+    n, h, w, c1 = dz.shape
+    return bool(_lib.load().ad_conv3x3_dgrad_ln_bwd_is_fused(n, h, w, c1, cout, dt(dz.dtype)))
+
+
+def conv3x3_dgrad_ln_bwd(dz: torch.Tensor, w_dgrad: torch.Tensor, z_prev: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor,
+                         gamma: torch.Tensor, beta: torch.Tensor, dgamma: torch.Tensor, dbeta: torch.Tensor, dbias: torch.Tensor,
+                         ws: Workspace) -> torch.Tensor:
+    """dgrad of a conv whose input was a Conv2D -> LayerNorm -> ReLU activation, with that layer's LayerNorm / ReLU backward
+    fused: returns dz of the layer below, writes its dgamma / dbeta / dbias."""
+    n, h, w, c1 = dz.shape
+    cout = z_prev.shape[-1]
+    out = torch.empty_like(z_prev)
+    lib = _lib.load()
+    ws.ensure(lib.ad_conv3x3_dgrad_ln_bwd_ws_bytes())
+    with _timed("conv3x3_dgrad_ln_bwd", 2.0 * n * h * w * 9 * c1 * cout, float(n * h * w * (c1 + 2 * cout) * dz.element_size())):
+        check(lib.ad_conv3x3_dgrad_ln_bwd(_p(dz), c1, _p(w_dgrad), _p(z_prev), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(out),
+                                          _p(dgamma), _p(dbeta), _p(dbias), n, h, w, cout, ws.ptr, ws.nbytes, dt(dz.dtype),
+                                          _stream()), "ad_conv3x3_dgrad_ln_bwd")
+    return out
+
+
 def conv3x3_dgrad_relu_is_fused(dz: torch.Tensor, cout: int, cy1: int) -> bool:
     n, h, w, c1 = dz.shape
     return bool(_lib.load().ad_conv3x3_dgrad_relu_is_fused(n, h, w, c1, cout, cy1, dt(dz.dtype)))

@@ -291,6 +291,9 @@ def main():
             # dgrad launches that also apply the up-conv's ReLU gradient and sum its bias gradient in their epilogue (an extra
             # 128 B/pixel stream through the MFMA waves; replaces a separate relu_bwd pass)
             "dgrad_relu_fused": family(["conv3x3_dgrad_relu"]),
+            # dgrad launches whose epilogue is the LayerNorm / ReLU backward of the layer below (z, mean, rstd streamed in,
+            # ~900 VALU instructions per tile and wave; replaces a separate 1.6 GB layernorm_relu_bwd pass)
+            "dgrad_ln_bwd_fused": family(["conv3x3_dgrad_ln_bwd"]),
         }
         conv_ms = sum(f["ms_per_step"] for f in fam.values())
         conv_gf = sum(f["gflop_per_step"] for f in fam.values())

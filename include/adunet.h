@@ -313,6 +313,21 @@ size_t ad_conv3x3_dgrad_relu_ws_bytes(void);
 int ad_conv3x3_dgrad_relu(const void* dz, int c1, const void* w_dgrad, const void* relu_out, void* y1, int cy1, void* y2,
                           float* dbias, int n, int h, int w, int cout, void* ws, size_t ws_bytes, int dtype, void* stream);
 
+/* dgrad of a 64 -> 64 conv whose INPUT was the activation of a Conv2D -> LayerNormalization -> ReLU layer (conv_block's
+ * second conv, Super_resolution/code/train_adaptive_unet.py:200-210; replaces Conv2DBackpropInput followed by ReluGrad,
+ * the LayerNormalization gradient and BiasAddGrad of the layer below).  dz [n,h,w,c1]: gradient of this conv's output;
+ * w_dgrad: its dgrad pack (cout = 64 input channels); z_prev / mean / rstd / gamma / beta: what the layer below stored
+ * in the forward pass.  Writes dz_prev [n,h,w,64] (gradient of the lower conv's output) and dgamma / dbeta / dbias [64]
+ * of the lower layer; the gradient of the activation itself never goes to memory (it is NOT rounded to the storage
+ * type on the way, unlike the two-launch path).  Only where _is_fused() says so (bf16, weights-resident kernel);
+ * ws: ad_conv3x3_dgrad_ln_bwd_ws_bytes(). */
+int ad_conv3x3_dgrad_ln_bwd_is_fused(int n, int h, int w, int c1, int cout, int dtype);
+size_t ad_conv3x3_dgrad_ln_bwd_ws_bytes(void);
+int ad_conv3x3_dgrad_ln_bwd(const void* dz, int c1, const void* w_dgrad, const void* z_prev, const float* mean,
+                            const float* rstd, const float* gamma, const float* beta, void* dz_prev, float* dgamma,
+                            float* dbeta, float* dbias, int n, int h, int w, int cout, void* ws, size_t ws_bytes, int dtype,
+                            void* stream);
+
 /* The skip connection's gradient junction (train_adaptive_unet.py:247-250: `skips.append(x); x = enc_down(x)`) fused
  * with the LayerNorm + ReLU backward of the conv_block that produced the skip:
  *   d(act) = dskip + ResizeByScale^T d_low       (= ad_resample(..., accumulate = 1) into dskip)

@@ -185,6 +185,23 @@ def audit_sr_step(model, lr, hr):
                 check_stored(d[..., :c1] if dsk is None else d, want_d, name + " dgrad", bf16)
                 if dsk is not None:
                     check_stored(dsk, dx[..., c1:], name + " dgrad (skip half)", bf16)
+        elif kind == "bwd_dgrad_ln":
+            # dgrad of conv `name` + LayerNorm/ReLU backward of the layer below it (whose activation was this conv's input)
+            # in one kernel: the oracle chains the two steps without rounding the activation gradient in between
+            _, _, dz_up, cname, z, mean, rstd, dz = rec
+            da, _, _ = ref.conv2d_same_bwd(np.zeros(z.shape), q(W[name + "/kernel"]), f64(dz_up))
+            ln = model.convs[cname].ln
+            gam, bet = W[ln + "/gamma"], W[ln + "/beta"]
+            zs = f64(z)
+            mu = mean.cpu().numpy().astype(np.float64).reshape(zs.shape[:-1] + (1,))
+            rs = rstd.cpu().numpy().astype(np.float64).reshape(zs.shape[:-1] + (1,))
+            xhat = (zs - mu) * rs
+            y = xhat * gam + bet
+            res = [ref.layernorm_bwd(da * (y > thr), gam, (xhat, rs)) for thr in (0.0, KINK, -KINK)]
+            ok = ~(np.abs(y) <= KINK).any(axis=-1)
+            check_stored_masked(f64(dz), res[0][0], ok, cname + " dz (fused with the dgrad of " + name + ")", bf16)
+            for j, pname in ((1, ln + "/gamma"), (2, ln + "/beta")):
+                check_f32(G[pname], res[0][j], pname + " grad", slack=np.abs(res[1][j] - res[2][j]))
         elif kind == "bwd_ca":
             _, _, xin, u, d_in, dz, d = rec
             want_dz = f64(d_in) * (f64(u) > 0)
@@ -217,9 +234,10 @@ def audit_sr_step(model, lr, hr):
             if before is not None:
                 want = want + f64(before)
             check_stored(d, want, name + " bwd", bf16)
-    assert seen - {"fused_relu_grad", "bwd_head_ln", "bwd_resize_ln"} == {"fwd_cla", "fwd_resize", "fwd_ca", "fwd_head", "bwd_head", "bwd_cla", "bwd_ca",
+    assert seen - {"fused_relu_grad", "bwd_head_ln", "bwd_resize_ln", "bwd_dgrad_ln"} == {"fwd_cla", "fwd_resize", "fwd_ca", "fwd_head", "bwd_head", "bwd_cla", "bwd_ca",
                                                         "bwd_resize"}
-    return len(records), "fused_relu_grad" in seen
+    # (a fused dgrad + LayerNorm backward adds a record of its own next to the two "bwd_cla" records it spans)
+    return sum(r[0] != "bwd_dgrad_ln" for r in records), ("fused_relu_grad" in seen, "bwd_dgrad_ln" in seen)
 
 
 def check_stored_masked(got, want, ok_pixels, what, store_bf16):
@@ -260,9 +278,9 @@ def test_every_step_of_the_model_against_the_oracle(device, cfg, dtype):
     _, scale, depth, p, n = cfg
     model = build(scale, depth, p, dtype, device)
     lr, hr = synth(np.random.default_rng(4321), n, p)
-    nrec, fused_relu = audit_sr_step(model, lr, hr)
-    if cfg[0] == "K2p-b8":
-        assert fused_relu == (dtype == torch.bfloat16)       # batch 8 reaches the weights-resident kernels at full resolution
+    nrec, (fused_relu, fused_ln) = audit_sr_step(model, lr, hr)
+    if cfg[0] == "K2p-b8":           # batch 8 reaches the weights-resident kernels at full resolution
+        assert fused_relu == (dtype == torch.bfloat16) and fused_ln == (dtype == torch.bfloat16)
     # forward: 2 convs per block (2 depth + 2 blocks), depth up-convs, 2 depth resizes, head; backward: the same again
     assert nrec == 2 * (2 * (2 * depth + 2) + depth + 2 * depth + 1)
 

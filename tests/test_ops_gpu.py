@@ -710,3 +710,45 @@ def test_dgrad_with_fused_relu_grad_equals_dgrad_then_relu_bwd(device, ws, dtype
     db2 = torch.empty_like(dbias)
     y1b, _ = ops.conv3x3_dgrad_relu(dz, wd, u, db2, cout, ws)
     assert torch.equal(y1, y1b) and torch.equal(dbias, db2)          # deterministic
+
+
+@pytest.mark.parametrize("dtype", [BF16])
+@pytest.mark.parametrize("shape", [(6, 256, 256), (20, 128, 128), (5, 250, 243)])
+def test_dgrad_with_fused_layernorm_bwd(device, ws, dtype, shape):
+    """ad_conv3x3_dgrad_ln_bwd (dgrad of a 64 -> 64 conv + LayerNorm / ReLU backward of the layer that produced its input, in
+    the dgrad epilogue) against the fp32 kernels run as the two steps it replaces, on the same stored operands.  The
+    fused path keeps the activation gradient in fp32 (the two half-precision launches round it to the storage type in
+    between), so the fp32 two-step result is the tighter reference.  A ReLU decision within float32 rounding of zero may
+    land on either side in the two paths (different fma contraction): a handful of pixels are allowed to differ."""
+    from adunet_amd import ops
+    n, h, w = shape
+    c = 64
+    g = torch.Generator().manual_seed(13)
+    dz = (torch.rand((n, h, w, c), generator=g) * 2 - 1).to(device=device, dtype=dtype)
+    zprev = ((torch.rand((n, h, w, c), generator=g) * 2 - 1) * 1.5 + 0.2).to(device=device, dtype=dtype)
+    wk = ((torch.rand((3, 3, c, c), generator=g) * 2 - 1) * 0.05).to(device)
+    gamma = (torch.rand(c, generator=g) + 0.5).to(device)
+    beta = (torch.rand(c, generator=g) - 0.5).to(device)
+    zf = zprev.float()
+    mean = zf.mean(-1).reshape(-1).contiguous()
+    rstd = torch.rsqrt(zf.var(-1, unbiased=False) + 1e-3).reshape(-1).contiguous()
+    _, wd = ops.conv3x3_pack(wk, c, dtype)
+    assert ops.conv3x3_dgrad_ln_bwd_is_fused(dz, c) and not ops.conv3x3_dgrad_ln_bwd_is_fused(dz.to(F16), c)
+    outs = [torch.full((c,), float("nan"), dtype=F32, device=device) for _ in range(3)]
+    got = ops.conv3x3_dgrad_ln_bwd(dz, wd, zprev, mean, rstd, gamma, beta, outs[0], outs[1], outs[2], ws)
+    # reference: fp32 dgrad, fp32 LayerNorm backward (both parity-tested against the oracle above)
+    _, wd32 = ops.conv3x3_pack(wk.to(dtype).float(), c, F32)        # the same operand values the half pack holds
+    d32 = ops.conv3x3_fwd(dz.float(), None, wd32, None, c)
+    refs = [torch.empty(c, dtype=F32, device=device) for _ in range(3)]
+    want = ops.layernorm_relu_bwd(d32, zf, mean, rstd, gamma, beta, refs[0], refs[1], refs[2], ws)
+    err = (got.float() - want).abs().amax(-1).reshape(-1)           # per pixel
+    scale = float(want.abs().max())
+    tol = (6e-3 if dtype == BF16 else 1e-3) * scale
+    bad = int((err > tol).sum())
+    assert bad <= 8, f"{bad} pixels off by more than {tol:.3g} (max {float(err.max()):.3g}, scale {scale:.3g})"
+    for gq, wq, name in zip(outs, refs, ("dgamma", "dbeta", "dbias")):
+        rel = float((gq - wq).abs().max() / wq.abs().max())
+        assert rel < (3e-3 if name == "dbias" else 1e-3), (name, rel)     # dbias sums dz AS STORED (half precision)
+    outs2 = [torch.empty(c, dtype=F32, device=device) for _ in range(3)]
+    got2 = ops.conv3x3_dgrad_ln_bwd(dz, wd, zprev, mean, rstd, gamma, beta, outs2[0], outs2[1], outs2[2], ws)
+    assert torch.equal(got, got2) and all(torch.equal(a, b) for a, b in zip(outs, outs2))       # deterministic

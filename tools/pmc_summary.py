@@ -19,7 +19,7 @@ FAMILIES = {       # kernel name -> op family used by bench.py's roofline ("_ln"
     "conv3x3_fwd_wres_kernel": "conv3x3_fwd", "conv3x3_fwd_ws_kernel": "conv3x3_fwd", "conv3x3_fwd_kernel": "conv3x3_fwd",
     "splitk_finalize_kernel": "conv3x3_fwd", "conv3x3_map4_kernel": "conv3x3_fwd", "conv3x3_map1_kernel": "conv3x3_fwd",
     "conv3x3_fwd_wres_kernel_ln": "conv3x3_ln_relu_fwd", "conv3x3_fwd_ws_kernel_ln": "conv3x3_ln_relu_fwd",
-    "conv3x3_fwd_wres_kernel_relugrad": "conv3x3_dgrad_relu",
+    "conv3x3_fwd_wres_kernel_relugrad": "conv3x3_dgrad_relu", "conv3x3_fwd_wres_kernel_lnbwd": "conv3x3_dgrad_ln_bwd",
     "conv3x3_wgrad_kernel": "conv3x3_wgrad", "conv3x3_wgrad_ws_kernel": "conv3x3_wgrad", "wgrad_reduce_kernel": "conv3x3_wgrad",
 }
 
@@ -29,6 +29,8 @@ def short(name):
         return re.search(r"conv3x3_fwd_w(?:res|s)_kernel", name).group(0) + "_ln"
     if re.search(r"conv3x3_fwd_wres_kernel", name) and ("Li3EEE" in name or re.search(r", 3>", name)):
         return "conv3x3_fwd_wres_kernel_relugrad"
+    if re.search(r"conv3x3_fwd_wres_kernel", name) and ("Li4EEE" in name or re.search(r", 4>", name)):
+        return "conv3x3_fwd_wres_kernel_lnbwd"
     name = re.sub(r"^void ", "", name).replace("(anonymous namespace)::", "")
     m = re.match(r"_ZN12_GLOBAL__N_1\d+([a-z0-9_]+?_kernel)", name)
     if m:
