@@ -318,7 +318,10 @@ def main():
             "roofline": {"bound": "mfma",
                          "kernel": "forward-conv / dgrad family: conv3x3_fwd_wres_kernel, conv3x3_fwd_ws_kernel, "
                                    "conv3x3_map4_kernel, conv3x3_map1_kernel (conv3x3_fwd_kernel + splitk_finalize_kernel "
-                                   "for other shapes), launches without the fused LayerNorm epilogue",
+                                   "for other shapes), launches with the plain bias / ReLU epilogue only; launches that carry "
+                                   "a LayerNorm forward, a ReLU-grad or (bf16, since r02: the four full-resolution 64->64 "
+                                   "dgrads, this family's fastest members until then) a LayerNorm backward in their epilogue "
+                                   "are the other entries of `families`",
                          "achieved": dom["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": dom["frac"],
                          "traffic": pmc_traffic(args.workload, args.dtype, batch),
                          "algorithmic_bytes_per_launch": timer.nbytes("conv3x3_fwd") / n_launch,
