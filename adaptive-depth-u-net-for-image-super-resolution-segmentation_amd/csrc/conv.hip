@@ -51,12 +51,16 @@ struct Geo {
     int tiles_x, tiles_y, tiles_i;
 };
 
-static bool pick_geo(int n, int h, int w, Geo* g) {
+// max_nph: most halo pixels a tile may have (the fp32 wgrad kernel's dz tile leaves room for 576, not for the 1024 of
+// 64 images x 4 x 4)
+static bool pick_geo(int n, int h, int w, Geo* g, int max_nph = 1 << 30) {
     static const int cand[5][3] = {{0, 4, 4}, {2, 3, 3}, {4, 2, 2}, {6, 1, 1}, {8, 0, 0}};
     long best = -1;
+    const int pad = (h > 1 || w > 1) ? 2 : 0;
     for (int i = 0; i < 5; ++i) {
         int ti = 1 << cand[i][0], th = 1 << cand[i][1], tw = 1 << cand[i][2];
         if (i == 4 && !(h == 1 && w == 1)) continue;
+        if (ti * (th + pad) * (tw + pad) > max_nph) continue;
         long cnt = (long)((n + ti - 1) / ti) * ((h + th - 1) / th) * ((w + tw - 1) / tw);
         if (best < 0 || cnt < best) {
             best = cnt;
@@ -64,7 +68,7 @@ static bool pick_geo(int n, int h, int w, Geo* g) {
         }
     }
     int ti = 1 << g->lti, th = 1 << g->lth, tw = 1 << g->ltw;
-    g->ph = h > 1; g->pw = w > 1;
+    g->ph = g->pw = h > 1 || w > 1;     // a 1 x W / H x 1 map keeps both halos: the rows / columns that do not exist are zero-filled
     g->HH = th + 2 * g->ph; g->HW = tw + 2 * g->pw;
     g->NPH = ti * g->HH * g->HW;
     g->NPHP = g->NPH;
@@ -2659,7 +2663,7 @@ struct WgradPlan {
 
 static void plan_wgrad(int n, int h, int w, int c1, int c2, int cout, int dtype, WgradPlan* p) {
     const int cin = c1 + c2;
-    pick_geo(n, h, w, &p->g);
+    pick_geo(n, h, w, &p->g, ad_is_half(dtype) ? 1 << 30 : 576);
     p->ntiles = p->g.tiles_x * p->g.tiles_y * p->g.tiles_i;
     p->ncob = (cout + BN - 1) / BN;
     const long long widest = (long long)n * h * w * (c1 > c2 ? (c1 > cout ? c1 : cout) : (c2 > cout ? c2 : cout)) * 2;

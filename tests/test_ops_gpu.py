@@ -47,6 +47,10 @@ CONV_SHAPES = [
     (3, 9, 7, 32, 32, 32),
     (1, 12, 12, 64, 0, 96),     # ragged LAST block after a full one
     (6, 4, 4, 32, 0, 32),
+    # maps with exactly one unit extent (never produced by the reference's square inputs, accepted all the same)
+    (3, 1, 9, 64, 0, 64),
+    (5, 7, 1, 32, 32, 64),
+    (70, 1, 2, 64, 0, 64),
 ]
 
 
@@ -173,8 +177,6 @@ def _random_conv_shapes(count):
     for _ in range(count):
         n = int(rng.integers(1, 6))
         h, w = int(rng.integers(1, 40)), int(rng.integers(1, 40))
-        if (h == 1) != (w == 1):           # maps with exactly one unit extent are rejected by the library (documented)
-            h = w = 1
         c1 = 32 * int(rng.integers(1, 4))
         c2 = 32 * int(rng.integers(0, 3))
         cout = 64 * int(rng.integers(1, 3))
