@@ -1025,11 +1025,22 @@ __device__ __forceinline__ void ws_mma_role_lnb(const ConvArgs& a, const char* x
         lds_barrier();                                  // odd stage (chunk 1) ready
         P::mma_chunk_rows(acc, xb1, abase0, HWB, wt1, lane, [](int) {});
         // ---- LayerNorm + ReLU backward of the 64 values per pixel this wave holds
-        __builtin_amdgcn_sched_barrier(0);
-        fetch(2);
-        __builtin_amdgcn_sched_barrier(0);
+        // bf16: the second half's operands are fetched here, behind the arithmetic of the first two m-tiles (471 us per
+        // full-resolution launch; fetched after the first m-tile: 488 us).  fp16 needs more conversion temporaries and
+        // spills with that many registers live: it fetches after the first m-tile (234 registers, no spill).
+        constexpr bool FETCH_EARLY = !ad_same_type<E, f16_t>::value;
+        if (FETCH_EARLY) {
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
+            if (!FETCH_EARLY && mt == 1) {
+                __builtin_amdgcn_sched_barrier(0);
+                fetch(2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             const unsigned pvo_mt = pvo_of(mt);
             const bool valid = pvo_mt != WR_OOB;
             const float mean = mu[mt], rstd = rs[mt];
@@ -2565,7 +2576,7 @@ int launch_fwd(ConvArgs a, void* ws, size_t ws_bytes, hipStream_t s) {
             allow_big_lds(conv3x3_fwd_ws_kernel<P, 1>);
             allow_big_lds(conv3x3_fwd_ws_kernel<P, 2>);
             allow_big_lds(conv3x3_fwd_wres_kernel<P, 3>);
-            if constexpr (!ad_same_type<typename P::T, f16_t>::value) allow_big_lds(conv3x3_fwd_wres_kernel<P, 4>);
+            allow_big_lds(conv3x3_fwd_wres_kernel<P, 4>);
         }
         attr_set = true;
     }
@@ -2604,15 +2615,10 @@ int launch_fwd(ConvArgs a, void* ws, size_t ws_bytes, hipStream_t s) {
             return AD_OK;
         }
         if (a.epilogue == AD_EPI_LNBWD) {
-            // bf16 only: the fp16 instantiation does not fit 256 registers (9 spills); fp16 runs the two launches
-            if constexpr (sizeof(typename P::T) == 2 && !ad_same_type<typename P::T, f16_t>::value) {
-                if (kind != 1 || a.cout_real != BN) return AD_ERR_UNFUSED;
-                conv3x3_fwd_wres_kernel<P, 4><<<NUM_CU, WR_T, WR_LDS, s>>>(a);
-                AD_LAUNCH_CHECK("conv3x3_fwd_wres (layernorm-bwd)");
-                return AD_OK;
-            } else {
-                return AD_ERR_UNFUSED;
-            }
+            if (kind != 1 || a.cout_real != BN) return AD_ERR_UNFUSED;
+            conv3x3_fwd_wres_kernel<P, 4><<<NUM_CU, WR_T, WR_LDS, s>>>(a);
+            AD_LAUNCH_CHECK("conv3x3_fwd_wres (layernorm-bwd)");
+            return AD_OK;
         }
 #define AD_WS_LAUNCH(KERN, NAME)                                                                     \
     {                                                                                                \
@@ -2888,7 +2894,7 @@ extern "C" int ad_conv3x3_dgrad_relu(const void* dz, int c1, const void* w_dgrad
 // train_adaptive_unet.py:200-210: its input is the first LayerNorm's activation)
 extern "C" int ad_conv3x3_dgrad_ln_bwd_is_fused(int n, int h, int w, int c1, int cout, int dtype) {
     static const bool off = getenv("ADUNET_NO_DGRAD_LN") != nullptr;      // A/B switch
-    if (off || dtype != AD_BF16 || n <= 0 || h <= 0 || w <= 0 || c1 <= 0 || cout != BN) return 0;      // (fp16: see launch_fwd)
+    if (off || !ad_is_half(dtype) || n <= 0 || h <= 0 || w <= 0 || c1 <= 0 || cout != BN) return 0;
     if (images_per_launch(n, h, w, c1, 0, cout, false, false) < n) return 0;        // image runs: plain path
     return fwd_ws_kind(n, h, w, c1, 0, cout, false) == 1;      // weights-resident kernel (contraction over 64 channels)
 }

@@ -319,7 +319,7 @@ int ad_conv3x3_dgrad_relu(const void* dz, int c1, const void* w_dgrad, const voi
  * w_dgrad: its dgrad pack (cout = 64 input channels); z_prev / mean / rstd / gamma / beta: what the layer below stored
  * in the forward pass.  Writes dz_prev [n,h,w,64] (gradient of the lower conv's output) and dgamma / dbeta / dbias [64]
  * of the lower layer; the gradient of the activation itself never goes to memory (it is NOT rounded to the storage
- * type on the way, unlike the two-launch path).  Only where _is_fused() says so (bf16, weights-resident kernel);
+ * type on the way, unlike the two-launch path).  Only where _is_fused() says so (half types, weights-resident kernel);
  * ws: ad_conv3x3_dgrad_ln_bwd_ws_bytes(). */
 int ad_conv3x3_dgrad_ln_bwd_is_fused(int n, int h, int w, int c1, int cout, int dtype);
 size_t ad_conv3x3_dgrad_ln_bwd_ws_bytes(void);

@@ -714,7 +714,7 @@ def test_dgrad_with_fused_relu_grad_equals_dgrad_then_relu_bwd(device, ws, dtype
     assert torch.equal(y1, y1b) and torch.equal(dbias, db2)          # deterministic
 
 
-@pytest.mark.parametrize("dtype", [BF16])
+@pytest.mark.parametrize("dtype", [BF16, F16])
 @pytest.mark.parametrize("shape", [(6, 256, 256), (20, 128, 128), (5, 250, 243)])
 def test_dgrad_with_fused_layernorm_bwd(device, ws, dtype, shape):
     """ad_conv3x3_dgrad_ln_bwd (dgrad of a 64 -> 64 conv + LayerNorm / ReLU backward of the layer that produced its input, in
@@ -735,7 +735,7 @@ def test_dgrad_with_fused_layernorm_bwd(device, ws, dtype, shape):
     mean = zf.mean(-1).reshape(-1).contiguous()
     rstd = torch.rsqrt(zf.var(-1, unbiased=False) + 1e-3).reshape(-1).contiguous()
     _, wd = ops.conv3x3_pack(wk, c, dtype)
-    assert ops.conv3x3_dgrad_ln_bwd_is_fused(dz, c) and not ops.conv3x3_dgrad_ln_bwd_is_fused(dz.to(F16), c)
+    assert ops.conv3x3_dgrad_ln_bwd_is_fused(dz, c) and not ops.conv3x3_dgrad_ln_bwd_is_fused(dz.float(), c)
     outs = [torch.full((c,), float("nan"), dtype=F32, device=device) for _ in range(3)]
     got = ops.conv3x3_dgrad_ln_bwd(dz, wd, zprev, mean, rstd, gamma, beta, outs[0], outs[1], outs[2], ws)
     # reference: fp32 dgrad, fp32 LayerNorm backward (both parity-tested against the oracle above)
