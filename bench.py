@@ -170,7 +170,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="K2p", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch override")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"],
+                    help="f16 = the reference's mixed_float16 policy (fp16 kernels + dynamic loss scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-micro", action="store_true", help="skip the 64->64 @256x256 N=32 micro-kernel measurement")
     ap.add_argument("--breakdown", action="store_true", help="print the per-op-family time table to stderr")
@@ -204,7 +205,7 @@ def main():
     scale, depth, patch, batch = WORKLOADS[args.workload]
     if args.batch:
         batch = args.batch
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
     model, info = build_super_resolution_unet(scale, depth_override=depth, input_size=patch, dtype=dtype, device=device)
     loss, metrics = build_losses_and_metrics("charbonnier")
     model.compile(optimizer=Adam(learning_rate=1e-4), loss=loss, metrics=metrics, jit_compile=False)
