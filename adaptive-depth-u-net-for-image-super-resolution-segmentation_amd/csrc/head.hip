@@ -45,10 +45,14 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ xh,
     const int64_t step = (int64_t)gridDim.x * PPB;
     for (int64_t q0 = (int64_t)blockIdx.x * PPB + gp; q0 < ppi; q0 += U * step) {
         Vec16<T> ld[U];
+        float inp_v[U], tgt_v[U];     // fetched with the activations, not after the reductions that need them last
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t q = q0 + u * step;
             if (q < ppi) ld[u].load(xh + ((int64_t)img * ppi + q) * ch + gl * EPT); else ld[u].zero();
+            const int64_t pixl = (int64_t)img * ppi + (q < ppi ? q : q0);
+            inp_v[u] = gl < 3 ? inp[pixl * 3 + gl] : 0.f;
+            tgt_v[u] = gl < 3 && target ? target[pixl * 3 + gl] : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -67,11 +71,11 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ xh,
             r0 = gsum<G>(r0); r1 = gsum<G>(r1); r2 = gsum<G>(r2);
             if (gl < 3) {
                 float r = (gl == 0 ? r0 : (gl == 1 ? r1 : r2)) + bo;
-                float pre = inp[pix * 3 + gl] + r;
+                float pre = inp_v[u] + r;
                 float o = fminf(fmaxf(pre, 0.f), 1.f);
                 out[pix * 3 + gl] = o;
                 if (target) {
-                    float d = target[pix * 3 + gl] - o;
+                    float d = tgt_v[u] - o;
                     lsum += loss_kind == 0 ? sqrtf(d * d + eps * eps) : fabsf(d);
                     qsum += d * d;
                 }
@@ -210,6 +214,9 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ xh,
 // never goes to memory (it stays fp32 in registers), so the pair "write dxh, read dxh + z, write dz" becomes "read z,
 // write dz".  Same lane layout as both kernels: G = ch / EPT lanes own a pixel's channels.
 // part[block][ch*3 + 3 + 3*ch] = { dW head, db head, dgamma, dbeta, dbias of the conv in front of the LayerNorm }
+#ifndef AD_HEAD_LN_U
+#define AD_HEAD_LN_U 1
+#endif
 template <typename T, int G>
 __global__ __launch_bounds__(256) void head_ln_bwd_kernel(const T* __restrict__ xh, const float* __restrict__ w,
                                                           const float* __restrict__ b, const float* __restrict__ inp,
@@ -241,15 +248,32 @@ __global__ __launch_bounds__(256) void head_ln_bwd_kernel(const T* __restrict__ 
     }
     const float b0 = b[0], b1 = b[1], b2 = b[2];
     const float inv_c = 1.0f / (float)ch;
-    for (int64_t q = (int64_t)blockIdx.x * PPB + gp; q < ppi; q += (int64_t)gridDim.x * PPB) {
+    // U pixels per thread and pass with every load issued before the first use: at one pixel the kernel's 166 registers
+    // allow three waves per SIMD = 6 MB in flight on the chip, which bounds it at ~3.9 TB/s (latency x bandwidth)
+    constexpr int U = AD_HEAD_LN_U;
+    const int64_t qstep = (int64_t)gridDim.x * PPB;
+    for (int64_t q0 = (int64_t)blockIdx.x * PPB + gp; q0 < ppi; q0 += U * qstep) {
+        Vec16<T> lxs[U], lzs[U];
+        float mus[U], rss[U], inps[U][3], tgts[U][3];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t qq = q0 + u * qstep < ppi ? q0 + u * qstep : q0;        // past the end: re-read, never stored
+            const int64_t pix = (int64_t)img * ppi + qq;
+            lxs[u].load(xh + pix * ch + gl * EPT);
+            lzs[u].load(z + pix * ch + gl * EPT);
+            mus[u] = mean[pix]; rss[u] = rstd[pix];
+#pragma unroll
+            for (int o = 0; o < 3; ++o) { inps[u][o] = inp[pix * 3 + o]; tgts[u][o] = target[pix * 3 + o]; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+        const int64_t q = q0 + u * qstep;
+        if (q >= ppi) break;
         const int64_t pix = (int64_t)img * ppi + q;
-        Vec16<T> lx, lz;
-        lx.load(xh + pix * ch + gl * EPT);
-        lz.load(z + pix * ch + gl * EPT);
-        const float mu = mean[pix], rs = rstd[pix];
+        const float mu = mus[u], rs = rss[u];
         float x[EPT], zz[EPT];
-        lx.to_f32(x);
-        lz.to_f32(zz);
+        lxs[u].to_f32(x);
+        lzs[u].to_f32(zz);
         float r[3] = {0.f, 0.f, 0.f};
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
@@ -261,9 +285,9 @@ __global__ __launch_bounds__(256) void head_ln_bwd_kernel(const T* __restrict__ 
         float g[3];
 #pragma unroll
         for (int o = 0; o < 3; ++o) {
-            float pre = inp[pix * 3 + o] + r[o];
+            float pre = inps[u][o] + r[o];
             float ov = fminf(fmaxf(pre, 0.f), 1.f);
-            float d = target[pix * 3 + o] - ov;
+            float d = tgts[u][o] - ov;
             float dl = loss_kind == 0 ? -d * rsqrtf(d * d + eps * eps) : (d > 0.f ? -1.f : (d < 0.f ? 1.f : 0.f));
             g[o] = (pre >= 0.f && pre <= 1.f) ? dl * gscale : 0.f;
         }
@@ -297,6 +321,7 @@ __global__ __launch_bounds__(256) void head_ln_bwd_kernel(const T* __restrict__ 
         st.to_f32(back);
 #pragma unroll
         for (int e = 0; e < EPT; ++e) a_z[e] += back[e];
+        }
     }
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {

@@ -859,23 +859,35 @@ class Model:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         set_alpha()
-        if dp is None:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, capture_error_mode="thread_local"):      # (a process group may exist: see seg_begin)
-                outputs = body(True)
-            segs.append((graph, [], False))
-        else:
-            saved = self.grad_ready
-            self.grad_ready = ready_while_capturing
-            try:
-                with torch.cuda.stream(side):
-                    seg_begin()
+        # No cyclic garbage collection while a capture is open: a collector run that happens to fall into the capture
+        # destroys whatever unreachable cycles earlier code left behind (old hipGraphs with their memory pools, RCCL
+        # communicators, streams), their destructors call APIs that are illegal during capture, and the exception inside a
+        # destructor aborts the process (seen once as "Fatal Python error: Aborted ... Garbage-collecting").
+        import gc
+        gc_was_enabled = gc.isenabled()
+        gc.collect()
+        gc.disable()
+        try:
+            if dp is None:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):      # (a process group may exist: see seg_begin)
                     outputs = body(True)
-                    seg_end([])
-            finally:
-                self.grad_ready = saved
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
+                segs.append((graph, [], False))
+            else:
+                saved = self.grad_ready
+                self.grad_ready = ready_while_capturing
+                try:
+                    with torch.cuda.stream(side):
+                        seg_begin()
+                        outputs = body(True)
+                        seg_end([])
+                finally:
+                    self.grad_ready = saved
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+        finally:
+            if gc_was_enabled:
+                gc.enable()
 
         def run():
             for g, buckets, sync in segs:
