@@ -2515,8 +2515,11 @@ static bool map1_ok(int n, int h, int w, int c1, int c2, int cout, int cy1) {
     static const bool off = getenv("ADUNET_NO_MAP1") != nullptr;      // A/B switch
     if (off) return false;
     const long long in_bytes = (long long)n * (c1 > c2 ? c1 : c2) * 2;        // 32-bit offsets inside the kernel
-    return h == 1 && w == 1 && n >= 1 && in_bytes <= WR_MAX_BYTES && (c1 + c2) % 128 == 0 && c1 % 32 == 0 && c1 + c2 <= 8192 &&
-           cout % 16 == 0 && cout <= 8192 && cy1 % 16 == 0;
+    // small batches of 1x1 maps only (a bottleneck level): every workgroup re-reads its 64 images' activations from
+    // L2, which is the right trade for a few hundred images and the wrong one for the 1x1 GEMM over 262 144 "images"
+    // that a Conv2DTranspose becomes (seg_model: those stay on the generic kernel, weights staged in LDS per tile)
+    return h == 1 && w == 1 && n >= 1 && n <= 1024 && in_bytes <= WR_MAX_BYTES && (c1 + c2) % 128 == 0 && c1 % 32 == 0 &&
+           c1 + c2 <= 8192 && cout % 16 == 0 && cout <= 8192 && cy1 % 16 == 0;
 }
 
 // conv3x3_map4_kernel: 4x4 maps, whole 128-channel phases, the concat boundary and the output split on 16-channel tiles

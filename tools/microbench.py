@@ -16,6 +16,12 @@ SHAPES = {
             (64, 64, 64, 0, 128), (64, 64, 128, 0, 128), (64, 64, 256, 0, 128), (64, 64, 128, 128, 128),
             (64, 16, 128, 0, 256), (64, 16, 256, 0, 256), (64, 16, 512, 0, 256),
             (64, 4, 256, 0, 512), (64, 4, 512, 0, 512), (64, 4, 1024, 0, 512), (64, 1, 512, 0, 1024), (64, 1, 1024, 0, 1024)],
+    # the LayerNorm / Conv2DTranspose segmentation model at batch 16 (conv blocks, decoder concat convs, transposed convs as
+    # 1x1 GEMMs run through the same kernels)
+    "seg": [(16, 256, 64, 0, 64), (16, 128, 64, 0, 128), (16, 128, 128, 0, 128), (16, 64, 128, 0, 256), (16, 64, 256, 0, 256),
+            (16, 32, 256, 0, 512), (16, 32, 512, 0, 512), (16, 16, 512, 0, 1024), (16, 16, 1024, 0, 1024),
+            (16, 16, 1024, 0, 2048), (16, 32, 512, 0, 1024), (16, 64, 256, 0, 512), (16, 128, 128, 0, 256),
+            (16, 32, 512, 512, 512), (16, 64, 256, 256, 256), (16, 128, 128, 128, 128), (16, 256, 64, 64, 64)],
     # the 4x4 and 1x1 levels of K2' 
     "small": [(64, 4, 256, 0, 512), (64, 4, 512, 0, 512), (64, 4, 1024, 0, 512), (64, 4, 512, 512, 512),
               (64, 1, 512, 0, 1024), (64, 1, 1024, 0, 1024)],
