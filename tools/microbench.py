@@ -22,6 +22,8 @@ SHAPES = {
             (16, 32, 256, 0, 512), (16, 32, 512, 0, 512), (16, 16, 512, 0, 1024), (16, 16, 1024, 0, 1024),
             (16, 16, 1024, 0, 2048), (16, 32, 512, 0, 1024), (16, 64, 256, 0, 512), (16, 128, 128, 0, 256),
             (16, 32, 512, 512, 512), (16, 64, 256, 256, 256), (16, 128, 128, 128, 128), (16, 256, 64, 64, 64)],
+    # 4x4 maps at larger batches (where does conv3x3_map4_kernel stop paying?)
+    "small_n": [(256, 4, 512, 0, 512), (1024, 4, 512, 0, 512), (4096, 4, 512, 0, 512), (1024, 4, 1024, 0, 512), (4096, 4, 256, 0, 512)],
     # the 4x4 and 1x1 levels of K2' 
     "small": [(64, 4, 256, 0, 512), (64, 4, 512, 0, 512), (64, 4, 1024, 0, 512), (64, 4, 512, 512, 512),
               (64, 1, 512, 0, 1024), (64, 1, 1024, 0, 1024)],
