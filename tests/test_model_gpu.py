@@ -332,6 +332,41 @@ def test_graph_replayed_step_equals_eager_step(device):
     assert torch.equal(results[0][1], results[1][1])
 
 
+def test_graph_capture_is_not_interrupted_by_the_garbage_collector(device):
+    """An unreachable cycle that still owns an older hipGraph (with its memory pool) is destroyed whenever the cyclic
+    collector next runs.  If that falls into an open capture, the destructor calls APIs that are illegal during capture
+    and the exception inside a destructor aborts the process (seen once in the full suite).  make_graphed_train_step
+    collects first and keeps the collector off while capturing: with the collector set to run at every opportunity the
+    second capture must go through and train."""
+    import gc
+    from adunet_amd.model import Adam, build_losses_and_metrics, build_super_resolution_unet
+    rng = np.random.default_rng(3)
+    batch = synth(rng, 2, 32)
+
+    def graphed_model():
+        model, _ = build_super_resolution_unet(0.5, depth_override=2, input_size=32, dtype=torch.bfloat16, device=device)
+        loss, metrics = build_losses_and_metrics("charbonnier")
+        model.compile(optimizer=Adam(1e-3), loss=loss, metrics=metrics)
+        model._require_device()
+        model.set_weights(model.initial_weights(np.random.default_rng(1), head_uniform=0.05))
+        return model, model.make_graphed_train_step(*batch)
+
+    old_model, old_step = graphed_model()
+    cycle = {"step": old_step, "model": old_model}
+    cycle["self"] = cycle                         # reachable only through itself once the names are gone
+    del old_model, old_step, cycle
+    thresholds = gc.get_threshold()
+    gc.set_threshold(1, 1, 1)                     # a collection at (almost) every allocation
+    try:
+        model, step = graphed_model()
+        first = float(step(*batch)[0])
+        for _ in range(5):
+            last = float(step(*batch)[0])
+    finally:
+        gc.set_threshold(*thresholds)
+    assert gc.isenabled() and np.isfinite(last) and last < first
+
+
 @pytest.mark.parametrize("native", [False, True], ids=["torch.distributed", "ad_allreduce_bucket"])
 def test_segmented_graph_step_under_data_parallel(device, native):
     """DataParallel (world size 1 on RCCL): the step is captured as several graph segments with the bucket all-reduces
