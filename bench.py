@@ -30,6 +30,9 @@ WORKLOADS = {
     "R3": (0.5, 3, 256, 64),
     "K2": (0.25, 4, 512, 16),
     "K1": (0.5, 2, 128, 4),
+    # the reference's own Experiment-2 shapes (Super_resolution/sbatch_scripts/run_experiment_adaptive_depth.sh:36-66)
+    "E2s06": (0.6, 4, 256, 32),     # 256/154/93/56/34
+    "E2s07": (0.7, 5, 256, 8),      # 256/180/126/89/63/45, 2048-channel bottleneck
 }
 
 

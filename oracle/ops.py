@@ -44,18 +44,20 @@ def fp16_round(x: np.ndarray) -> np.ndarray:
 
 
 def conv2d_same_fwd(x: np.ndarray, w: np.ndarray, b: np.ndarray | None) -> np.ndarray:
+    """One [pixels, Cin] x [Cin, Cout] product per tap (the shifted view is copied to a dense matrix first, so that the
+    product is a single multi-threaded GEMM: the layer-wise audits convolve whole BASELINE-size batches)."""
     kh, kw, cin, cout = w.shape
     n, h, wd, c = x.shape
     assert c == cin, (x.shape, w.shape)
     ph, pw = kh // 2, kw // 2
     xp = np.pad(x, ((0, 0), (ph, ph), (pw, pw), (0, 0)))
-    y = np.zeros((n, h, wd, cout), dtype=x.dtype)
+    y = np.zeros((n * h * wd, cout), dtype=x.dtype)
     for i in range(kh):
         for j in range(kw):
-            y += xp[:, i:i + h, j:j + wd, :] @ w[i, j]
+            y += np.ascontiguousarray(xp[:, i:i + h, j:j + wd, :]).reshape(-1, cin) @ w[i, j]
     if b is not None:
         y += b
-    return y
+    return y.reshape(n, h, wd, cout)
 
 
 def conv2d_same_bwd(x: np.ndarray, w: np.ndarray, dy: np.ndarray, need_dx: bool = True):
@@ -66,13 +68,13 @@ def conv2d_same_bwd(x: np.ndarray, w: np.ndarray, dy: np.ndarray, need_dx: bool 
     xp = np.pad(x, ((0, 0), (ph, ph), (pw, pw), (0, 0)))
     dw = np.zeros_like(w)
     dxp = np.zeros_like(xp) if need_dx else None
-    dy2 = dy.reshape(-1, cout)
+    dy2 = np.ascontiguousarray(dy).reshape(-1, cout)
     for i in range(kh):
         for j in range(kw):
-            patch = xp[:, i:i + h, j:j + wd, :].reshape(-1, cin)
+            patch = np.ascontiguousarray(xp[:, i:i + h, j:j + wd, :]).reshape(-1, cin)
             dw[i, j] = patch.T @ dy2
             if need_dx:
-                dxp[:, i:i + h, j:j + wd, :] += dy @ w[i, j].T
+                dxp[:, i:i + h, j:j + wd, :] += (dy2 @ w[i, j].T).reshape(n, h, wd, cin)
     db = dy2.sum(axis=0)
     dx = dxp[:, ph:ph + h, pw:pw + wd, :] if need_dx else None
     return dx, dw, db
@@ -176,20 +178,25 @@ def aa_matrix(in_size: int, out_size: int, dtype=np.float64) -> np.ndarray:
     return m
 
 
+def _apply_axis(m: np.ndarray, x: np.ndarray, axis: int) -> np.ndarray:
+    """y = m applied along `axis` of x (a GEMM on the axis moved to the front)."""
+    xm = np.moveaxis(x, axis, 0)
+    y = m @ np.ascontiguousarray(xm).reshape(xm.shape[0], -1)
+    return np.moveaxis(y.reshape((m.shape[0],) + xm.shape[1:]), 0, axis)
+
+
 def resize_aa_fwd(x: np.ndarray, oh: int, ow: int) -> np.ndarray:
     n, h, w, c = x.shape
     my = aa_matrix(h, oh, x.dtype)
     mx = aa_matrix(w, ow, x.dtype)
-    t = np.einsum("oh,nhwc->nowc", my, x)
-    return np.einsum("pw,nowc->nopc", mx, t)
+    return np.ascontiguousarray(_apply_axis(mx, _apply_axis(my, x, 1), 2))      # separable: H, then W
 
 
 def resize_aa_bwd(dy: np.ndarray, h: int, w: int) -> np.ndarray:
     n, oh, ow, c = dy.shape
     my = aa_matrix(h, oh, dy.dtype)
     mx = aa_matrix(w, ow, dy.dtype)
-    t = np.einsum("pw,nopc->nowc", mx, dy)
-    return np.einsum("oh,nowc->nhwc", my, t)
+    return np.ascontiguousarray(_apply_axis(my.T, _apply_axis(mx.T, dy, 2), 1))  # the transposed map
 
 
 # --------------------------------------------------------------------------- #

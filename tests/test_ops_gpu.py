@@ -754,3 +754,113 @@ def test_dgrad_with_fused_layernorm_bwd(device, ws, dtype, shape):
     outs2 = [torch.empty(c, dtype=F32, device=device) for _ in range(3)]
     got2 = ops.conv3x3_dgrad_ln_bwd(dz, wd, zprev, mean, rstd, gamma, beta, outs2[0], outs2[1], outs2[2], ws)
     assert torch.equal(got, got2) and all(torch.equal(a, b) for a, b in zip(outs, outs2))       # deterministic
+
+
+# ---- the two fused dgrad epilogues against the ORACLE (windows), not against the launches they replace.  dz is non-zero
+# only inside the windows, so the gradient is non-zero only inside the windows grown by one pixel: the oracle needs
+# those crops alone, everything outside must come out as exact zeros, and the per-channel sums (bias / gamma / beta
+# gradients, which run over the whole tensor) are the sums over the crops.
+def _sparse_dz(rng, cout, dtype):
+    n, h, w = BIG
+    dz = np.zeros((n, h, w, cout))
+    regions = []
+    for img, y0, x0 in WINDOWS:
+        y1, x1 = min(y0 + WIN, h), min(x0 + WIN, w)
+        dz[img, y0:y1, x0:x1] = rnd(rng.standard_normal((y1 - y0, x1 - x0, cout)), dtype)
+        regions.append((img, max(y0 - 1, 0), max(x0 - 1, 0), min(y1 + 1, h), min(x1 + 1, w)))
+    return dz, regions
+
+
+@pytest.mark.parametrize("dtype", [BF16, F16])
+@pytest.mark.parametrize("cy1", [64, 128])
+def test_dgrad_with_fused_relu_grad_against_the_oracle(device, ws, dtype, cy1):
+    """ad_conv3x3_dgrad_relu on the ragged BIG shape (decoder step, train_adaptive_unet.py:259-262: dgrad of the block's
+    first conv 64 <- [up-conv output (cy1 of 128) | skip], ReLU-grad of the up-conv and its bias gradient in the epilogue)."""
+    from adunet_amd import ops
+    n, h, w = BIG
+    c1, cout = 64, 128
+    rng = np.random.default_rng(41 + cy1)
+    wk = rnd(rng.standard_normal((3, 3, cout, c1)) * 0.1, dtype)                 # HWIO of the forward conv: 128 -> 64
+    dz, regions = _sparse_dz(rng, c1, dtype)
+    u = np.maximum(rnd(rng.standard_normal((n, h, w, cy1)), dtype), 0)           # the up-conv's ReLU output, ~half zeros
+    _, wd = ops.conv3x3_pack(torch.tensor(wk, dtype=F32, device=device), cout, dtype)
+    dzd, ud = to_dev(dz, dtype, device), to_dev(u, dtype, device)
+    assert ops.conv3x3_dgrad_relu_is_fused(dzd, cout, cy1)
+    dbias = torch.full((cy1,), float("nan"), dtype=F32, device=device)
+    y1, y2 = ops.conv3x3_dgrad_relu(dzd, wd, ud, dbias, cout, ws)
+    got = torch.cat([y1, y2], dim=-1) if y2 is not None else y1
+    got = got.to(torch.float64).cpu().numpy()
+    wt = np.ascontiguousarray(np.transpose(wk[::-1, ::-1], (0, 1, 3, 2)))        # dgrad = conv with the rotated, transposed kernel
+    outside = np.ones((n, h, w), bool)
+    want_db = np.zeros(cy1)
+    scale = 0.0
+    checks = []
+    for img, ya, xa, yb, xb in regions:
+        want = ref.conv2d_same_fwd(dz[img:img + 1, ya:yb, xa:xb], wt, None)[0]   # zero padding = the zeros around the window
+        want[..., :cy1] *= u[img, ya:yb, xa:xb] > 0
+        want_db += want[..., :cy1].reshape(-1, cy1).sum(0)
+        outside[img, ya:yb, xa:xb] = False
+        scale = max(scale, np.abs(want).max())
+        checks.append((got[img, ya:yb, xa:xb], want))
+    for g, want in checks:
+        assert np.abs(g - want).max() / scale < TOL[dtype]
+    assert not got[outside].any(), "gradient outside the support of dz"
+    assert relerr(dbias, want_db) < 3e-3                                         # sums the masked gradient AS STORED
+
+
+@pytest.mark.parametrize("dtype", [BF16, F16])
+def test_dgrad_with_fused_layernorm_bwd_against_the_oracle(device, ws, dtype):
+    """ad_conv3x3_dgrad_ln_bwd on the ragged BIG shape: dgrad of conv_block's second conv chained, without rounding in
+    between, with the LayerNorm / ReLU backward of the first (train_adaptive_unet.py:200-210), restated by
+    ref.layernorm_bwd on the float64 dgrad."""
+    from adunet_amd import ops
+    n, h, w = BIG
+    c = 64
+    rng = np.random.default_rng(43)
+    wk = rnd(rng.standard_normal((3, 3, c, c)) * 0.1, dtype)
+    dz, regions = _sparse_dz(rng, c, dtype)
+    zprev = rnd(rng.standard_normal((n, h, w, c)) * 1.5 + 0.2, dtype)
+    gam = rng.uniform(0.5, 1.5, c).astype(np.float32).astype(np.float64)
+    bet = (0.3 * rng.standard_normal(c)).astype(np.float32).astype(np.float64)
+    zd = to_dev(zprev, dtype, device)
+    zf = zd.float()
+    mean = zf.mean(-1).reshape(-1).contiguous()
+    rstd = torch.rsqrt(zf.var(-1, unbiased=False) + 1e-3).reshape(-1).contiguous()
+    mu64 = mean.view(n, h, w, 1).to(torch.float64).cpu().numpy()                 # the statistics the kernel is handed
+    rs64 = rstd.view(n, h, w, 1).to(torch.float64).cpu().numpy()
+    f = lambda v: torch.tensor(v, dtype=F32, device=device)
+    _, wd = ops.conv3x3_pack(torch.tensor(wk, dtype=F32, device=device), c, dtype)
+    dzd = to_dev(dz, dtype, device)
+    assert ops.conv3x3_dgrad_ln_bwd_is_fused(dzd, c)
+    outs = [torch.full((c,), float("nan"), dtype=F32, device=device) for _ in range(3)]
+    got = ops.conv3x3_dgrad_ln_bwd(dzd, wd, zd, mean, rstd, f(gam), f(bet), outs[0], outs[1], outs[2], ws)
+    got = got.to(torch.float64).cpu().numpy()
+    wt = np.ascontiguousarray(np.transpose(wk[::-1, ::-1], (0, 1, 3, 2)))
+    outside = np.ones((n, h, w), bool)
+    sums = [np.zeros(c) for _ in range(3)]
+    slack = [np.zeros(c) for _ in range(3)]
+    checks, scale, kinks = [], 0.0, 0
+    for img, ya, xa, yb, xb in regions:
+        da = ref.conv2d_same_fwd(dz[img:img + 1, ya:yb, xa:xb], wt, None)
+        xhat = (zprev[img:img + 1, ya:yb, xa:xb] - mu64[img:img + 1, ya:yb, xa:xb]) * rs64[img:img + 1, ya:yb, xa:xb]
+        y = xhat * gam + bet
+        res = [ref.layernorm_bwd(da * (y > thr), gam, (xhat, rs64[img:img + 1, ya:yb, xa:xb])) for thr in (0.0, 1e-5, -1e-5)]
+        ok = ~(np.abs(y) <= 1e-5).any(axis=-1)[0]                                # a ReLU decision within rounding of zero
+        kinks += int((~ok).sum())
+        sums[0] += res[0][1]
+        sums[1] += res[0][2]
+        sums[2] += res[0][0].reshape(-1, c).sum(0)
+        slack[0] += np.abs(res[1][1] - res[2][1])
+        slack[1] += np.abs(res[1][2] - res[2][2])
+        slack[2] += np.abs(res[1][0] - res[2][0]).reshape(-1, c).sum(0)
+        outside[img, ya:yb, xa:xb] = False
+        scale = max(scale, np.abs(res[0][0]).max())
+        checks.append((got[img, ya:yb, xa:xb], res[0][0][0], ok))
+    assert kinks <= 8
+    for g, want, ok in checks:
+        assert (np.abs(g - want) * ok[..., None]).max() / scale < TOL[dtype]
+    assert not got[outside].any(), "gradient outside the support of dz"
+    for gq, wq, sl, name in zip(outs, sums, slack, ("dgamma", "dbeta", "dbias")):
+        err = np.abs(gq.to(torch.float64).cpu().numpy() - wq)
+        lim = (3e-3 if name == "dbias" else 1e-3) * np.abs(wq).max() + sl       # dbias sums dz AS STORED (16 bits)
+        assert (err <= lim).all(), (name, float((err / np.abs(wq).max()).max()))
