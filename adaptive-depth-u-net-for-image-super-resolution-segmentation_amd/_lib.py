@@ -74,6 +74,14 @@ SIGNATURES = {
     "ad_seg_head_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _sz, _i, _vp]),
     "ad_seg_head_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _f, _f, _f, _vp, _vp, _sz, _i, _vp]),
     "ad_softmax_head_fwd": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
+    "ad_pw_supported": (_i, [_i64, _i, _i, _i]),
+    "ad_pw_bank_elems": (_sz, [_i, _i]),
+    "ad_pw_bank_pack": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp]),
+    "ad_pw_gemm": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
+    "ad_pw_bank_grad": (_i, [_vp, _i, _i, _vp, _vp]),
+    "ad_upconv_gather_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "ad_upconv_gather_bwd_supported": (_i, [_i]),
+    "ad_upconv_gather_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "ad_comm_unique_id": (_i, [_vp]),
     "ad_comm_create": (_i, [_vp, _i, _i, C.POINTER(C.c_void_p)]),
     "ad_comm_destroy": (_i, [_vp]),

@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.normpath(os.path.join(HERE, "..", "include"))
 LIB = os.path.join(CSRC, "libadunet_hip.so")
-SOURCES = ["api.hip", "conv.hip", "norm.hip", "resize.hip", "head.hip", "optim.hip", "tier2.hip", "metrics.hip", "comm.hip"]
+SOURCES = ["api.hip", "conv.hip", "norm.hip", "resize.hip", "head.hip", "optim.hip", "tier2.hip", "metrics.hip", "comm.hip", "upconv.hip"]
 ARCH = "gfx950"
 
 

@@ -1,0 +1,483 @@
+// The decoder step "dec_up -> Conv2D(nf, 3, padding='same', activation='relu')" without the up-resized tensor.
+//
+//   Super_resolution/code/train_adaptive_unet.py:258-259   x = dec_up([x, skip]); x = L.Conv2D(nf, 3, ...)(x)
+//   shared/custom_layers.py:121-125                        ResizeToMatch (tf.image.resize, bilinear, antialias)
+//
+// The resize mixes pixels, the convolution's contraction mixes channels, so they commute:
+//     conv3x3(U x)[p] = b + sum_tap (U x)[p + tap] W_tap = b + sum_tap (U (x W_tap))[p + tap]     (zero outside the image)
+// The step therefore runs as
+//   1. a bank of nine 1x1 convolutions on the LOW-resolution map, Y[q][tap][co] = sum_ci x[q][ci] W[tap][ci][co]:
+//      one GEMM [pixels] x [Cin] x [9 Cout] on the matrix cores with 1 / ratio^2 of the 3x3 convolution's FLOPs
+//      (pw_gemm_kernel);
+//   2. a gather at the high resolution that interpolates and shifts, out[p] = relu(b + sum_tap (U Y_tap)[p + tap])
+//      (upconv_gather_fwd_kernel: fp32 arithmetic, HBM-bound: reads Y through the L2, writes the activation once);
+// and backwards as the transposes: dY = gather^T(dz) (upconv_gather_bwd_kernel), dx = dY Bank^T (pw_gemm_kernel again)
+// and dBank = x^T dY (the 1x1 case of conv3x3_wgrad), re-ordered into the Keras kernel gradient by bank_grad_kernel.
+// Neither the up-resized activation (K2' level 0: 1.07 GB per step in bf16) nor its gradient exists in memory: five
+// passes over a full-resolution 2 nf-channel tensor and 15/16 of the up-conv's FLOPs (ratio 4) are gone.
+// Restated tap by tap in oracle/ops.py (upconv_bank_* / upconv_gather_*), whose equality with
+// relu(conv2d(resize(x))) and its gradients is tests/test_oracle_factored_upconv.py.
+#include "common.h"
+
+namespace {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+constexpr unsigned PW_OOB = 0x80000000u;
+constexpr long long PW_MAX_BYTES = 0x7fffffffLL;
+
+__device__ __forceinline__ auto pw_rsrc(const void* p, long long bytes) {
+    const unsigned long long u = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0,
+                                             __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+}
+
+// ------------------------------------------------------------------ pointwise GEMM on the matrix cores
+// Y[m][n] = sum_k X[m][k] B[k][n], X / Y row-major activations ([pixels][channels], NHWC with the pixels flattened),
+// B pre-packed to [K / KV][N][KV] (KV = 16 bytes of k), so that an MFMA weight fragment is one 16-byte load.
+// Orientation as in conv.hip: D[n][m] = B^T X^T, a lane ends up with 4 consecutive output channels of one pixel.
+// A wave owns 64 pixels x 64 output channels (4 x 4 accumulator tiles) and walks K in chunks of 64; fragments come
+// straight from global memory (the bank is L2 resident, the pixel rows are re-read per 64-channel block from L1 / L2):
+// these GEMMs are 1 / ratio^2 of the step's up-conv FLOPs, so the kernel is kept simple rather than LDS-tiled.
+// Every access is a buffer load / store with out-of-range offsets past the last pixel (zeros in, store dropped).
+template <typename T> struct PwPol;
+template <typename E> struct PwPol16 {
+    typedef typename Half16<E>::v8 frag;
+    static constexpr int KV = 8;          // k per 16 bytes
+    static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) { return Half16<E>::mfma(a, b, c); }
+    static __device__ __forceinline__ u32x2 pack4(f32x4 v) {
+        union { typename Half16<E>::v4 h; u32x2 u; } p;
+        p.h[0] = (E)v.x; p.h[1] = (E)v.y; p.h[2] = (E)v.z; p.h[3] = (E)v.w;
+        return p.u;
+    }
+};
+template <> struct PwPol<bf16_t> : PwPol16<bf16_t> {};
+template <> struct PwPol<f16_t> : PwPol16<f16_t> {};
+template <> struct PwPol<float> {
+    typedef f32x4 frag;
+    static constexpr int KV = 4;
+    static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, c, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, c, 0, 0, 0);
+    }
+};
+
+struct PwArgs {
+    const char* x; const char* bp; char* y;
+    int m, k, n;               // pixels, contraction, output channels (n % 64 == 0, k % 64 == 0)
+    int nb_per_wg;             // 64-channel output blocks per workgroup
+};
+
+constexpr int PW_T = 256;      // 4 waves, 64 pixels each
+
+template <typename T>
+__global__ __launch_bounds__(PW_T, 2) void pw_gemm_kernel(PwArgs a) {
+    typedef PwPol<T> P;
+    typedef typename P::frag frag;
+    constexpr int TSZ = (int)sizeof(T);
+    constexpr int KV = P::KV;
+    constexpr int KSTEP = 4 * KV;              // k covered by one fragment pair (4 lane groups x KV)
+    constexpr int NKS = 64 / KSTEP;            // fragment steps per 64-k chunk: 2 (16-bit), 4 (fp32)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane >> 4, l15 = lane & 15;
+    const int nblk = a.n / 64;
+    const int wg_per_mt = (nblk + a.nb_per_wg - 1) / a.nb_per_wg;
+    const int mtile = blockIdx.x / wg_per_mt;
+    const int nb0 = (blockIdx.x - mtile * wg_per_mt) * a.nb_per_wg;
+    const int nb1 = min(nb0 + a.nb_per_wg, nblk);
+    const int m0 = mtile * 256 + wave * 64;
+    const auto rsx = pw_rsrc(a.x, (long long)a.m * a.k * TSZ);
+    const auto rsb = pw_rsrc(a.bp, (long long)a.k * a.n * TSZ);
+    const auto rsy = pw_rsrc(a.y, (long long)a.m * a.n * TSZ);
+    // pixel-row fragment of m-tile mt, k-step ks of chunk kc: X[m0 + 16 mt + l15][kc*64 + ks*KSTEP + grp*KV ..]
+    unsigned xo[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int mrow = m0 + mt * 16 + l15;
+        xo[mt] = mrow < a.m ? (unsigned)((mrow * a.k + grp * KV) * TSZ) : PW_OOB;
+    }
+    const int nkc = a.k / 64;
+    for (int nb = nb0; nb < nb1; ++nb) {
+        // bank fragment of n-tile nt: Bp[(kc*64 + ks*KSTEP) / KV + grp][nb*64 + 16 nt + l15][KV]
+        const unsigned bo = (unsigned)(((grp * a.n) + nb * 64 + l15) * 16);
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        frag xf[NKS][4], bf[NKS][4];
+#define PW_LOAD(KC)                                                                                              \
+    _Pragma("unroll") for (int ks = 0; ks < NKS; ++ks) {                                                         \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                          \
+            const unsigned koff_ = (unsigned)(((KC) * 64 + ks * KSTEP) * TSZ);                                   \
+            xf[ks][t] = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(rsx, xo[t], koff_, 0));   \
+            const unsigned brow_ = (unsigned)((((KC) * 64 + ks * KSTEP) / KV) * a.n * 16);                       \
+            bf[ks][t] = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(rsb, bo + t * 256, brow_, 0)); \
+        }                                                                                                        \
+    }
+        for (int kc = 0; kc < nkc; ++kc) {
+            PW_LOAD(kc)
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = P::mma(bf[ks][nt], xf[ks][mt], acc[mt][nt]);
+        }
+#undef PW_LOAD
+        // lane holds channels nb*64 + 16 nt + 4 grp .. +3 of pixel m0 + 16 mt + l15
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int mrow = m0 + mt * 16 + l15;
+            if constexpr (TSZ == 2) {
+                // 16-byte stores: v_permlane16_swap trades the odd 16-lane rows of one n-tile with the even rows of the
+                // next, after which lane group g holds channels (g & 1) * 16 + (g >> 1) * 8 .. + 7 of the n-tile pair
+                const unsigned yo = mrow < a.m ? (unsigned)((mrow * a.n + nb * 64 + (grp & 1) * 16 + (grp >> 1) * 8) * TSZ) : PW_OOB;
+#pragma unroll
+                for (int np = 0; np < 2; ++np) {
+                    const u32x2 pa = P::pack4(acc[mt][2 * np]), pb = P::pack4(acc[mt][2 * np + 1]);
+                    const u32x2 s0 = __builtin_amdgcn_permlane16_swap(pa[0], pb[0], false, false);
+                    const u32x2 s1 = __builtin_amdgcn_permlane16_swap(pa[1], pb[1], false, false);
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, rsy, yo, np * 32 * TSZ, 0);
+                }
+            } else {
+                const unsigned yo = mrow < a.m ? (unsigned)((mrow * a.n + nb * 64 + grp * 4) * TSZ) : PW_OOB;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[mt][nt]), rsy, yo, nt * 16 * TSZ, 0);
+            }
+        }
+    }
+}
+
+// Bank operands from the fp32 Keras kernel W[3][3][Cin][Cout] (HWIO):
+//   forward  bank  B[k = ci][n = tap * Cout + co]  -> bf[ci / KV][tap * Cout + co][KV]
+//   backward bank  B^T[k = tap * Cout + co][n = ci] -> bd[(tap * Cout + co) / KV][ci][KV]
+template <typename T>
+__global__ __launch_bounds__(256) void pw_bank_pack_kernel(const float* __restrict__ w, int cin, int cout, T* __restrict__ bf,
+                                                           T* __restrict__ bd) {
+    constexpr int KV = 16 / (int)sizeof(T);
+    const int n9 = 9 * cout;
+    const int total = cin * n9;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < 2 * total; e += gridDim.x * 256) {
+        if (e < total) {
+            const int kv = e % KV, r = e / KV;
+            const int nn = r % n9, kc = r / n9;
+            const int ci = kc * KV + kv, tap = nn / cout, co = nn - tap * cout;
+            bf[e] = (T)w[((size_t)tap * cin + ci) * cout + co];
+        } else {
+            const int i = e - total;
+            const int kv = i % KV, r = i / KV;
+            const int ci = r % cin, kc = r / cin;
+            const int kk = kc * KV + kv, tap = kk / cout, co = kk - tap * cout;
+            bd[i] = (T)w[((size_t)tap * cin + ci) * cout + co];
+        }
+    }
+}
+
+// dW[tap][ci][co] (Keras HWIO gradient) = dBank[ci][tap * Cout + co], the centre tap of the [3][3][Cin][9 Cout] tensor
+// that the 1x1 case of ad_conv3x3_wgrad writes.
+__global__ __launch_bounds__(256) void bank_grad_kernel(const float* __restrict__ dw9, int cin, int cout, float* __restrict__ dw) {
+    const int n9 = 9 * cout;
+    const float* centre = dw9 + (size_t)4 * cin * n9;
+    const int total = 9 * cin * cout;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+        const int co = e % cout, r = e / cout;
+        const int ci = r % cin, tap = r / cin;
+        dw[e] = centre[(size_t)ci * n9 + tap * cout + co];
+    }
+}
+
+// ------------------------------------------------------------------ gather (forward)
+// out[n][oy][ox][c] = act(bias[c] + sum_{dy,dx} [row oy+dy, column ox+dx inside the image]
+//                         sum_{a,b < 2} wy[oy+dy][a] wx[ox+dx][b] Y[n][sy[oy+dy]+a][sx[ox+dx]+b][tap(dy,dx)][c])
+// Tables: two taps per output index (an up-resize never has more), the second index clamped and weighted 0 where the
+// source has no such row / column.  A thread owns one (output column, 16-byte channel vector) for R consecutive output
+// rows and walks down the low-resolution rows those rows (and their +-1 neighbours) interpolate from; per low-resolution
+// row it forms the three horizontally interpolated and shifted sums (one per dy: 3 dx x 2 taps = 6 loads each) and adds
+// them to the row accumulators with the rows' vertical weights, which are uniform over the workgroup (scalar branches).
+struct GatherArgs {
+    const char* y; const float* bias; char* out;
+    const int* sy; const float* wy; const int* sx; const float* wx;
+    int h, w, oh, ow, c, relu;
+};
+
+template <typename T, int R>
+__global__ __launch_bounds__(256) void upconv_gather_fwd_kernel(GatherArgs a) {
+    constexpr int EPT = ElemTraits<T>::EPT;
+    const int vecs = a.c / EPT;
+    const int oy0 = blockIdx.y * R, nn = blockIdx.z;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool live = i < a.ow * vecs;
+    const int ox = live ? i / vecs : 0, v = live ? i - ox * vecs : 0;
+    // horizontal taps of the three shifted columns
+    float fx[3][2];
+    int xoff[3][2];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const int cc = ox + d - 1;
+        const bool ok = cc >= 0 && cc < a.ow;
+        const int ccl = min(max(cc, 0), a.ow - 1);
+        const int x0 = a.sx[ccl];
+        fx[d][0] = ok ? a.wx[2 * ccl] : 0.f;
+        fx[d][1] = ok ? a.wx[2 * ccl + 1] : 0.f;
+        xoff[d][0] = x0 * 9 * a.c + v * EPT;
+        xoff[d][1] = min(x0 + 1, a.w - 1) * 9 * a.c + v * EPT;
+    }
+    const int rlo = max(oy0 - 1, 0), rhi = min(oy0 + R, a.oh - 1);
+    int qlo = a.h - 1, qhi = 0;                        // low-resolution rows the strip reads (workgroup-uniform)
+    for (int rr = rlo; rr <= rhi; ++rr) {
+        qlo = min(qlo, a.sy[rr]);
+        qhi = max(qhi, min(a.sy[rr] + 1, a.h - 1));
+    }
+    float acc[R][EPT];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) acc[r][e] = 0.f;
+    const T* yn = reinterpret_cast<const T*>(a.y) + (size_t)nn * a.h * a.w * 9 * a.c;
+    for (int q = qlo; q <= qhi; ++q) {
+        const T* row = yn + (size_t)q * a.w * 9 * a.c;
+        float hs[3][EPT];
+#pragma unroll
+        for (int dyi = 0; dyi < 3; ++dyi) {
+            Vec16<T> ld[3][2];
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) ld[d][b].load(row + xoff[d][b] + (dyi * 3 + d) * a.c);
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) hs[dyi][e] = 0.f;
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    float t[EPT];
+                    ld[d][b].to_f32(t);
+#pragma unroll
+                    for (int e = 0; e < EPT; ++e) hs[dyi][e] += fx[d][b] * t[e];
+                }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+#pragma unroll
+            for (int dyi = 0; dyi < 3; ++dyi) {
+                const int rr = oy0 + r + dyi - 1;                   // workgroup-uniform
+                if (rr < 0 || rr >= a.oh) continue;
+                const int k = q - a.sy[rr];
+                if (k != 0 && k != 1) continue;
+                const float fy = a.wy[2 * rr + k];
+                if (fy == 0.f) continue;
+#pragma unroll
+                for (int e = 0; e < EPT; ++e) acc[r][e] += fy * hs[dyi][e];
+            }
+        }
+    }
+    if (!live) return;
+    float bv[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) bv[e] = a.bias ? a.bias[v * EPT + e] : 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (oy0 + r >= a.oh) break;
+        float o[EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            o[e] = acc[r][e] + bv[e];
+            if (a.relu) o[e] = fmaxf(o[e], 0.f);
+        }
+        Vec16<T> st;
+        st.from_f32(o);
+        st.store(reinterpret_cast<T*>(a.out) + (((size_t)nn * a.oh + oy0 + r) * a.ow + ox) * a.c + v * EPT);
+    }
+}
+
+// ------------------------------------------------------------------ gather (backward): the transpose
+// dY[n][qy][qx][tap(dy,dx)][c] = sum_{r, cc} wyt[qy][r] wxt[qx][cc] g[n][r - dy][cc - dx][c]     (r - dy, cc - dx inside)
+// with the TRANSPOSED tables of the resize (first hi-res row / column that reads low-res index q, and the weights of the
+// KYT / KXT rows / columns from there on).  A thread owns one (low-resolution column, channel vector) of one
+// low-resolution row: it walks the KYT + 2 gradient rows that reach that row, forms per row the three horizontally
+// contracted sums (one per dx, from KXT + 2 loads) and adds them to the 3 x 3 tap accumulators with the rows' vertical
+// weights (workgroup-uniform).  KX2 >= kxt + 2 bounds the column window in registers.
+struct GatherBwdArgs {
+    const char* g; char* dy;
+    const int* ryt; const float* wyt; int kyt;      // [h], [h][kyt]
+    const int* cxt; const float* wxt; int kxt;      // [w], [w][kxt]
+    int h, w, oh, ow, c;
+};
+
+template <typename T, int KX2>
+__global__ __launch_bounds__(256) void upconv_gather_bwd_kernel(GatherBwdArgs a) {
+    constexpr int EPT = ElemTraits<T>::EPT;
+    const int vecs = a.c / EPT;
+    const int qy = blockIdx.y, nn = blockIdx.z;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.w * vecs) return;
+    const int qx = i / vecs, v = i - qx * vecs;
+    const int c0 = a.cxt[qx] - 1;                      // first column of the window
+    // weight of window column j for shift d: wxt[qx][j - 1 + (d - 1)] = wxt[qx][j + d - 2]
+    float wj[3][KX2];
+    int coff[KX2];
+    bool cok[KX2];
+#pragma unroll
+    for (int j = 0; j < KX2; ++j) {
+        const int cc = c0 + j;
+        cok[j] = cc >= 0 && cc < a.ow && j < a.kxt + 2;
+        coff[j] = min(max(cc, 0), a.ow - 1) * a.c + v * EPT;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const int k = j + d - 2;
+            wj[d][j] = (cok[j] && k >= 0 && k < a.kxt) ? a.wxt[qx * a.kxt + k] : 0.f;
+        }
+    }
+    float acc[3][3][EPT];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) acc[s][d][e] = 0.f;
+    const T* gn = reinterpret_cast<const T*>(a.g) + (size_t)nn * a.oh * a.ow * a.c;
+    const int r0 = a.ryt[qy];
+    for (int p = max(r0 - 1, 0); p <= min(r0 + a.kyt, a.oh - 1); ++p) {
+        const T* row = gn + (size_t)p * a.ow * a.c;
+        float hs[3][EPT];
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) hs[d][e] = 0.f;
+#pragma unroll
+        for (int j = 0; j < KX2; ++j) {
+            Vec16<T> ld;
+            float t[EPT];
+            ld.load(row + coff[j]);
+            ld.to_f32(t);
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+#pragma unroll
+                for (int e = 0; e < EPT; ++e) hs[d][e] += wj[d][j] * t[e];
+        }
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {                  // dy = s - 1: gradient row p belongs to hi-res row r = p + dy
+            const int k = p + s - 1 - r0;              // workgroup-uniform
+            if (k < 0 || k >= a.kyt) continue;
+            const float fy = a.wyt[qy * a.kyt + k];
+            if (fy == 0.f) continue;
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+#pragma unroll
+                for (int e = 0; e < EPT; ++e) acc[s][d][e] += fy * hs[d][e];
+        }
+    }
+    T* dst = reinterpret_cast<T*>(a.dy) + ((((size_t)nn * a.h + qy) * a.w + qx) * 9) * a.c + v * EPT;
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            Vec16<T> st;
+            st.from_f32(acc[s][d]);
+            st.store(dst + (s * 3 + d) * a.c);
+        }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------- C ABI
+extern "C" int ad_pw_supported(int64_t m, int k, int n, int dtype) {
+    if (!ad_dtype_ok(dtype) || m <= 0 || k <= 0 || n <= 0 || k % 64 || n % 64) return 0;
+    const long long tsz = ad_is_half(dtype) ? 2 : 4;
+    const long long widest = k > n ? k : n;
+    return m * widest * tsz <= PW_MAX_BYTES && (long long)k * n * tsz <= PW_MAX_BYTES;
+}
+
+extern "C" size_t ad_pw_bank_elems(int cin, int cout) { return (size_t)9 * cin * cout; }
+
+extern "C" int ad_pw_bank_pack(const float* w_hwio, int cin, int cout, void* bank_fwd, void* bank_bwd, int dtype, void* stream) {
+    AD_REQUIRE(ad_dtype_ok(dtype), "ad_pw_bank_pack: bad dtype %d", dtype);
+    AD_REQUIRE(w_hwio && bank_fwd && bank_bwd && cin > 0 && cout > 0 && cin % 64 == 0 && cout % 64 == 0,
+               "ad_pw_bank_pack: cin=%d cout=%d must be positive multiples of 64", cin, cout);
+    const long long total = 2LL * 9 * cin * cout;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    AD_DISPATCH_DTYPE(dtype, T_, pw_bank_pack_kernel<T_><<<blocks, 256, 0, (hipStream_t)stream>>>(w_hwio, cin, cout, (T_*)bank_fwd,
+                                                                                            (T_*)bank_bwd);)
+    AD_LAUNCH_CHECK("ad_pw_bank_pack");
+    return AD_OK;
+}
+
+extern "C" int ad_pw_gemm(const void* x, const void* bank, void* y, int64_t m, int k, int n, int dtype, void* stream) {
+    AD_REQUIRE(ad_pw_supported(m, k, n, dtype), "ad_pw_gemm: unsupported m=%lld k=%d n=%d dtype=%d (ask ad_pw_supported)",
+               (long long)m, k, n, dtype);
+    AD_REQUIRE(x && bank && y, "ad_pw_gemm: NULL operand");
+    PwArgs a;
+    a.x = (const char*)x; a.bp = (const char*)bank; a.y = (char*)y;
+    a.m = (int)m; a.k = k; a.n = n;
+    const int mtiles = (int)((m + 255) / 256), nblk = n / 64;
+    // all output blocks of a pixel tile in one workgroup (its pixel rows stay in L1) unless that leaves CUs idle
+    int per = nblk;
+    while (per > 1 && (long long)mtiles * ((nblk + per - 1) / per) < 1024) per = (per + 1) / 2;
+    a.nb_per_wg = per;
+    const int grid = mtiles * ((nblk + per - 1) / per);
+    AD_DISPATCH_DTYPE(dtype, T_, pw_gemm_kernel<T_><<<grid, PW_T, 0, (hipStream_t)stream>>>(a);)
+    AD_LAUNCH_CHECK("ad_pw_gemm");
+    return AD_OK;
+}
+
+extern "C" int ad_pw_bank_grad(const float* dw9, int cin, int cout, float* dw_hwio, void* stream) {
+    AD_REQUIRE(dw9 && dw_hwio && cin > 0 && cout > 0, "ad_pw_bank_grad: bad operands");
+    const int total = 9 * cin * cout;
+    const int blocks = (total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048;
+    bank_grad_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(dw9, cin, cout, dw_hwio);
+    AD_LAUNCH_CHECK("ad_pw_bank_grad");
+    return AD_OK;
+}
+
+extern "C" int ad_upconv_gather_fwd(const void* ybank, const float* bias, void* out, const int* sy, const float* wy,
+                                    const int* sx, const float* wx, int n, int h, int w, int oh, int ow, int c, int relu,
+                                    int dtype, void* stream) {
+    AD_REQUIRE(ad_dtype_ok(dtype), "ad_upconv_gather_fwd: bad dtype %d", dtype);
+    const int ept = ad_is_half(dtype) ? 8 : 4;
+    AD_REQUIRE(ybank && out && sy && wy && sx && wx, "ad_upconv_gather_fwd: NULL operand");
+    AD_REQUIRE(n > 0 && h > 0 && w > 0 && oh >= h && ow >= w && c > 0 && c % ept == 0,
+               "ad_upconv_gather_fwd: bad shape n=%d %dx%d -> %dx%d c=%d", n, h, w, oh, ow, c);
+    AD_REQUIRE((long long)h * w * 9 * c < (1LL << 31) && (long long)oh * ow * c < (1LL << 31),
+               "ad_upconv_gather_fwd: an image of more than 2^31 elements");
+    GatherArgs a;
+    a.y = (const char*)ybank; a.bias = bias; a.out = (char*)out;
+    a.sy = sy; a.wy = wy; a.sx = sx; a.wx = wx;
+    a.h = h; a.w = w; a.oh = oh; a.ow = ow; a.c = c; a.relu = relu;
+    constexpr int R = 8;
+    dim3 grid((ow * (c / ept) + 255) / 256, (oh + R - 1) / R, n);
+    AD_DISPATCH_DTYPE(dtype, T_, upconv_gather_fwd_kernel<T_, R><<<grid, 256, 0, (hipStream_t)stream>>>(a);)
+    AD_LAUNCH_CHECK("ad_upconv_gather_fwd");
+    return AD_OK;
+}
+
+extern "C" int ad_upconv_gather_bwd_supported(int kxt) { return kxt >= 1 && kxt + 2 <= 16; }
+
+extern "C" int ad_upconv_gather_bwd(const void* g, void* dybank, const int* ryt, const float* wyt, int kyt, const int* cxt,
+                                    const float* wxt, int kxt, int n, int h, int w, int oh, int ow, int c, int dtype,
+                                    void* stream) {
+    AD_REQUIRE(ad_dtype_ok(dtype), "ad_upconv_gather_bwd: bad dtype %d", dtype);
+    const int ept = ad_is_half(dtype) ? 8 : 4;
+    AD_REQUIRE(g && dybank && ryt && wyt && cxt && wxt, "ad_upconv_gather_bwd: NULL operand");
+    AD_REQUIRE(n > 0 && h > 0 && w > 0 && oh >= h && ow >= w && c > 0 && c % ept == 0 && kyt >= 1,
+               "ad_upconv_gather_bwd: bad shape n=%d %dx%d <- %dx%d c=%d", n, h, w, oh, ow, c);
+    AD_REQUIRE(ad_upconv_gather_bwd_supported(kxt), "ad_upconv_gather_bwd: %d horizontal taps (at most 14)", kxt);
+    AD_REQUIRE((long long)h * w * 9 * c < (1LL << 31) && (long long)oh * ow * c < (1LL << 31),
+               "ad_upconv_gather_bwd: an image of more than 2^31 elements");
+    GatherBwdArgs a;
+    a.g = (const char*)g; a.dy = (char*)dybank;
+    a.ryt = ryt; a.wyt = wyt; a.kyt = kyt; a.cxt = cxt; a.wxt = wxt; a.kxt = kxt;
+    a.h = h; a.w = w; a.oh = oh; a.ow = ow; a.c = c;
+    dim3 grid((w * (c / ept) + 255) / 256, h, n);
+    hipStream_t s = (hipStream_t)stream;
+    if (kxt + 2 <= 6) { AD_DISPATCH_DTYPE(dtype, T_, upconv_gather_bwd_kernel<T_, 6><<<grid, 256, 0, s>>>(a);) }
+    else if (kxt + 2 <= 10) { AD_DISPATCH_DTYPE(dtype, T_, upconv_gather_bwd_kernel<T_, 10><<<grid, 256, 0, s>>>(a);) }
+    else { AD_DISPATCH_DTYPE(dtype, T_, upconv_gather_bwd_kernel<T_, 16><<<grid, 256, 0, s>>>(a);) }
+    AD_LAUNCH_CHECK("ad_upconv_gather_bwd");
+    return AD_OK;
+}

@@ -196,6 +196,7 @@ class Model:
         # runtime state (allocated on first use)
         self.P = self.G = self.M = self.V = None
         self._packs: Dict[str, Tuple[torch.Tensor, Optional[torch.Tensor]]] = {}
+        self._banks: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}
         self._ws: Optional[ops.Workspace] = None
         self.optimizer: Optional[Adam] = None
         self.loss = None
@@ -463,7 +464,41 @@ class Model:
             batch = self._pack_batch = ops.PackBatch(layers, self.dtype, self.device)
             batch.owner = self.P                        # the table holds pointers into this buffer
             self._packs.update(batch.packs)
+            self.__dict__["_banks"] = {}
         batch.run()
+        # up-convs that run in the factored form (csrc/upconv.hip) contract against the 1x1 bank operands instead
+        banks = self.__dict__.setdefault("_banks", {})
+        for name in self._factored_upconvs():
+            banks[name] = ops.pw_bank_pack(self.param(name + "/kernel"), self.dtype, out=banks.get(name))
+
+    # ---- the decoder's `dec_up -> Conv2D(nf, 3, same, relu)` (:258-259) without the up-resized tensor
+    FACTORED_MIN_SOURCE = 16        # smallest low-resolution extent that takes the factored form (below: 3x3 kernels)
+
+    def _factored_upconvs(self) -> List[str]:
+        """Names of the up-convs that run as a bank of nine 1x1 convolutions on the low-resolution map + an interpolating
+        gather.  A static property of the graph (extents and channel counts), the same for every batch size."""
+        cached = self.__dict__.get("_factored_names")
+        if cached is not None:
+            return cached
+        names = []
+        if os.environ.get("ADUNET_NO_FACTORED_UPCONV") != "1":
+            for step in self.__dict__.get("_plan", []):     # (the segmentation models have no such step)
+                if step[0] != "upconv":
+                    continue
+                cs, lvl = step[1], step[2]
+                src = self.sizes[lvl + 1]
+                if (src >= self.FACTORED_MIN_SOURCE and cs.cin % 128 == 0 and cs.cout % 64 == 0
+                        and self._upconv_tables(src, cs.hw).ok):
+                    names.append(cs.name)
+        self._factored_names = names
+        return names
+
+    def _upconv_tables(self, src: int, dst: int) -> "ops.UpconvTables":
+        tabs = self.__dict__.setdefault("_up_tables", {})
+        key = (src, dst)
+        if key not in tabs:
+            tabs[key] = ops.UpconvTables(src, src, dst, dst, self.device)
+        return tabs[key]
 
     # ------------------------------------------------------------------ forward / backward
     def _to_dev(self, a) -> torch.Tensor:
@@ -509,20 +544,33 @@ class Model:
                     self.audit.append(("fwd_resize", "enc_down", cur1, small))
                 cur1 = small
             elif kind == "up":
-                if keep:
-                    tape.append(("up", cur1.shape[1], cur1.shape[2]))
-                big = self.dec_up((cur1, skips[step[1]]))
-                if self.audit is not None:
-                    self.audit.append(("fwd_resize", "dec_up", cur1, big))
-                cur1 = big
-                cur2 = None
+                pass            # the resize belongs to the up-conv that follows (it may never materialise)
             elif kind == "upconv":
                 cs, lvl = step[1], step[2]
-                u = ops.conv3x3_fwd(cur1, None, self._packs[cs.name][0], self.param(cs.name + "/bias"), cs.cout, relu=True)
-                if keep:
-                    tape.append(("ca", cs, cur1, u))
-                if self.audit is not None:
-                    self.audit.append(("fwd_ca", cs.name, cur1, u))
+                m = cur1.shape[0] * cur1.shape[1] * cur1.shape[2]
+                if (cs.name in self._banks and ops.pw_supported(m, cs.cin, 9 * cs.cout, self.dtype)
+                        and ops.pw_supported(m, 9 * cs.cout, cs.cin, self.dtype)):
+                    # factored form: nine 1x1 convolutions on the low-resolution map, then the interpolating gather
+                    tab = self._upconv_tables(cur1.shape[1], cs.hw)
+                    ybank = ops.pw_gemm(cur1, self._banks[cs.name][0], 9 * cs.cout)
+                    u = ops.upconv_gather_fwd(ybank, self.param(cs.name + "/bias"), tab, relu=True)
+                    if keep:
+                        tape.append(("caf", cs, cur1, u, tab))
+                    if self.audit is not None:
+                        self.audit.append(("fwd_bank", cs.name, cur1, ybank))
+                        self.audit.append(("fwd_gather", cs.name, ybank, u))
+                else:
+                    if keep:
+                        tape.append(("up", cur1.shape[1], cur1.shape[2]))
+                    big = self.dec_up((cur1, skips[lvl]))
+                    if self.audit is not None:
+                        self.audit.append(("fwd_resize", "dec_up", cur1, big))
+                    cur1 = big
+                    u = ops.conv3x3_fwd(cur1, None, self._packs[cs.name][0], self.param(cs.name + "/bias"), cs.cout, relu=True)
+                    if keep:
+                        tape.append(("ca", cs, cur1, u))
+                    if self.audit is not None:
+                        self.audit.append(("fwd_ca", cs.name, cur1, u))
                 # L.Concatenate()([x, skip]) (:261) is virtual: the skip joins as the second operand of the next conv
                 cur1, cur2 = u, skips[lvl]
             elif kind == "head":
@@ -594,7 +642,7 @@ class Model:
                 elif x2 is not None:
                     # x1 is the up-conv's ReLU output (:259-261): where the library has the fused epilogue, this dgrad
                     # also applies that ReLU's gradient and sums the up-conv's bias gradient (no relu_bwd pass later)
-                    up = tape[-1][1] if tape and tape[-1][0] == "ca" and tape[-1][3] is x1 else None
+                    up = tape[-1][1] if tape and tape[-1][0] in ("ca", "caf") and tape[-1][3] is x1 else None
                     fused_relu = (up is not None and os.environ.get("ADUNET_NO_DGRAD_RELU") != "1"
                                   and ops.conv3x3_dgrad_relu_is_fused(dz, cs.cin, x1.shape[-1]))
                     if fused_relu:
@@ -636,6 +684,18 @@ class Model:
                 d = ops.conv3x3_fwd(dz, None, self._packs[cs.name][1], None, cs.cin)
                 if audit is not None:
                     audit.append(("bwd_ca", cs.name, xin, u, d_in, dz, d))
+            elif kind == "caf":
+                # factored up-conv: dY = gather^T(dz), dx = dY Bank^T, dBank = x^T dY (all at the low resolution)
+                _, cs, xin, u, tab = rec
+                d_in = d
+                dz = d if relu_done else ops.relu_bwd(d, u, self.grad(cs.name + "/bias"), ws)
+                relu_done = False
+                dyb = ops.upconv_gather_bwd(dz, tab)
+                ops.upconv_bank_wgrad(xin, dyb, self.grad(cs.name + "/kernel"), ws)
+                self._done(cs.name + "/kernel")
+                d = ops.pw_gemm(dyb, self._banks[cs.name][1], cs.cin)
+                if audit is not None:
+                    audit.append(("bwd_caf", cs.name, xin, u, d_in, dz, dyb, d))
             elif kind == "up":
                 d_in = d
                 d = self.dec_up.resize_grad(d, rec[1], rec[2])

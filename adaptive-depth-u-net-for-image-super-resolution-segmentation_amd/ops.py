@@ -396,6 +396,91 @@ def resample(x: torch.Tensor, tab: ResampleTables, out: Optional[torch.Tensor] =
     return out
 
 
+# ---- the decoder step "dec_up -> Conv2D(nf, 3, same, relu)" without the up-resized tensor (csrc/upconv.hip)
+class UpconvTables:
+    """Device tables of one up-resize (h, w) -> (oh, ow) for the gather kernels: the two-tap forward form and the
+    transposed spans.  `ok` is False when the resize is not an up-resize with at most two taps per output index or the
+    transposed horizontal span is wider than the backward kernel's register window."""
+
+    def __init__(self, h: int, w: int, oh: int, ow: int, device):
+        from . import resize_tables as rt
+        fy, fx = rt.up_taps2(h, oh), rt.up_taps2(w, ow)
+        self.ok = fy is not None and fx is not None
+        if not self.ok:
+            return
+        ty, tx = rt.aa_spans_transposed(h, oh), rt.aa_spans_transposed(w, ow)
+        self.kyt, self.kxt = ty[1].shape[1], tx[1].shape[1]
+        self.ok = bool(_lib.load().ad_upconv_gather_bwd_supported(self.kxt))
+        self.h, self.w, self.oh, self.ow = h, w, oh, ow
+        dev_i = lambda a: torch.tensor(np.ascontiguousarray(a, dtype=np.int32), device=device)
+        dev_f = lambda a: torch.tensor(np.ascontiguousarray(a, dtype=np.float32), device=device)
+        self.sy, self.wy, self.sx, self.wx = dev_i(fy[0]), dev_f(fy[1]), dev_i(fx[0]), dev_f(fx[1])
+        self.ryt, self.wyt, self.cxt, self.wxt = dev_i(ty[0]), dev_f(ty[1]), dev_i(tx[0]), dev_f(tx[1])
+
+
+def pw_supported(m: int, k: int, n: int, dtype: torch.dtype) -> bool:
+    return bool(_lib.load().ad_pw_supported(m, k, n, dt(dtype)))
+
+
+def pw_bank_pack(w_hwio: torch.Tensor, dtype: torch.dtype, out=None):
+    """fp32 Keras kernel [3,3,cin,cout] -> (bank_fwd, bank_bwd) GEMM operands; `out` = a previous result refreshed in place."""
+    kh, kw, cin, cout = w_hwio.shape
+    assert (kh, kw) == (3, 3) and w_hwio.dtype == torch.float32
+    lib = _lib.load()
+    if out is not None:
+        bf, bd = out
+    else:
+        ne = lib.ad_pw_bank_elems(cin, cout)
+        bf = torch.empty(ne, dtype=dtype, device=w_hwio.device)
+        bd = torch.empty(ne, dtype=dtype, device=w_hwio.device)
+    with _timed("pw_bank_pack"):
+        check(lib.ad_pw_bank_pack(_p(w_hwio), cin, cout, _p(bf), _p(bd), dt(dtype), _stream()), "ad_pw_bank_pack")
+    return bf, bd
+
+
+def pw_gemm(x: torch.Tensor, bank: torch.Tensor, n_out: int) -> torch.Tensor:
+    """y[..., n_out] = x[..., k] @ bank[k, n_out] over the flattened pixels of an NHWC tensor."""
+    k = x.shape[-1]
+    m = x.numel() // k
+    y = torch.empty(x.shape[:-1] + (n_out,), dtype=x.dtype, device=x.device)
+    with _timed("pw_gemm", 2.0 * m * k * n_out, float(m * (k + n_out) * x.element_size())):
+        check(_lib.load().ad_pw_gemm(_p(x), _p(bank), _p(y), m, k, n_out, dt(x.dtype), _stream()), "ad_pw_gemm")
+    return y
+
+
+def upconv_gather_fwd(ybank: torch.Tensor, bias: Optional[torch.Tensor], tab: UpconvTables, relu: bool = True) -> torch.Tensor:
+    n, h, w, c9 = ybank.shape
+    c = c9 // 9
+    assert (h, w) == (tab.h, tab.w)
+    out = torch.empty((n, tab.oh, tab.ow, c), dtype=ybank.dtype, device=ybank.device)
+    with _timed("upconv_gather_fwd", 0.0, float((ybank.numel() + out.numel()) * ybank.element_size())):
+        check(_lib.load().ad_upconv_gather_fwd(_p(ybank), _p(bias), _p(out), _p(tab.sy), _p(tab.wy), _p(tab.sx), _p(tab.wx),
+                                               n, h, w, tab.oh, tab.ow, c, int(relu), dt(ybank.dtype), _stream()),
+              "ad_upconv_gather_fwd")
+    return out
+
+
+def upconv_gather_bwd(g: torch.Tensor, tab: UpconvTables) -> torch.Tensor:
+    n, oh, ow, c = g.shape
+    assert (oh, ow) == (tab.oh, tab.ow)
+    dyb = torch.empty((n, tab.h, tab.w, 9 * c), dtype=g.dtype, device=g.device)
+    with _timed("upconv_gather_bwd", 0.0, float((g.numel() + dyb.numel()) * g.element_size())):
+        check(_lib.load().ad_upconv_gather_bwd(_p(g), _p(dyb), _p(tab.ryt), _p(tab.wyt), tab.kyt, _p(tab.cxt), _p(tab.wxt),
+                                               tab.kxt, n, tab.h, tab.w, oh, ow, c, dt(g.dtype), _stream()),
+              "ad_upconv_gather_bwd")
+    return dyb
+
+
+def upconv_bank_wgrad(x_low: torch.Tensor, dybank: torch.Tensor, dw_out: torch.Tensor, ws: Workspace):
+    """dW [3,3,cin,cout] (fp32 view of the flat gradient buffer) = re-ordered x_low^T dybank (contraction over pixels)."""
+    cin, n9 = x_low.shape[-1], dybank.shape[-1]
+    m = x_low.numel() // cin
+    dw9 = torch.empty((3, 3, cin, n9), dtype=torch.float32, device=x_low.device)
+    conv3x3_wgrad(x_low.view(m, 1, 1, cin), None, dybank.view(m, 1, 1, n9), dw9, cin, ws)
+    with _timed("pw_bank_grad"):
+        check(_lib.load().ad_pw_bank_grad(_p(dw9), cin, n9 // 9, _p(dw_out), _stream()), "ad_pw_bank_grad")
+
+
 def resample_ln_bwd_supported(dskip: torch.Tensor, tab: ResampleTables) -> bool:
     n, oh, ow, c = dskip.shape
     return bool(_lib.load().ad_resample_ln_bwd_supported(n, oh, ow, c, tab.kx, dt(dskip.dtype)))

@@ -69,3 +69,30 @@ def aa_spans_transposed(in_size: int, out_size: int) -> Tuple[np.ndarray, np.nda
         valid = r <= last
         wt[valid, k] = dense[np.minimum(r, out_size - 1)[valid], np.arange(in_size)[valid]]
     return first.astype(np.int32), wt
+
+
+@functools.lru_cache(maxsize=None)
+def up_taps2(in_size: int, out_size: int):
+    """The up-resize's table in two-tap form for ad_upconv_gather_fwd: (starts[out] int32, weights[out, 2] float32) with
+    y[o] = w[o,0] x[starts[o]] + w[o,1] x[min(starts[o] + 1, in - 1)], or None when some output index reads more than two
+    consecutive inputs (a shrinking resize).  Leading zero-weight taps of aa_spans are skipped, the weights themselves are
+    the float32 values of aa_spans (TensorFlow's ScaleAndTranslate spans, see there)."""
+    if out_size < in_size:
+        return None
+    starts, wgt = aa_spans(in_size, out_size)
+    nz = wgt != 0
+    first = np.where(nz.any(axis=1), nz.argmax(axis=1), 0)
+    rows = np.arange(out_size)
+    w2 = np.zeros((out_size, 2), dtype=np.float32)
+    w2[:, 0] = wgt[rows, first]
+    second = first + 1
+    ok2 = second < wgt.shape[1]
+    w2[ok2, 1] = wgt[rows[ok2], second[ok2]]
+    rest = nz.copy()
+    rest[rows, first] = False
+    rest[rows[ok2], second[ok2]] = False
+    if rest.any():
+        return None
+    s2 = (starts.astype(np.int64) + first).astype(np.int32)
+    w2[(s2 + 1 > in_size - 1), 1] = 0.0      # (no such input: aa_spans never weights it, the kernel clamps the index)
+    return s2, w2

@@ -341,6 +341,40 @@ int ad_resample_ln_bwd(const void* d_low, const void* dskip, const void* z, cons
                        const int* sy, const float* wy, int ky, const int* sx, const float* wx, int kx,
                        int n, int h, int w, int oh, int ow, int c, void* ws, size_t ws_bytes, int dtype, void* stream);
 
+/* ------------------------------------------- decoder step without the up-resized tensor -- */
+
+/* `x = dec_up([x, skip]); x = L.Conv2D(nf, 3, padding="same", activation="relu")(x)`
+ * (Super_resolution/code/train_adaptive_unet.py:258-259; ResizeToMatch: shared/custom_layers.py:121-125).
+ * The resize acts on pixels, the convolution's contraction on channels, so they commute:
+ *     conv3x3(U x)[p] = b + sum_tap (U (x W_tap))[p + tap]            (zero outside the high-resolution image)
+ * and the step runs as a bank of nine 1x1 convolutions on the LOW-resolution map (one GEMM, 1 / ratio^2 of the FLOPs)
+ * followed by an interpolating / shifting gather; backwards as the transposes.  The up-resized activation and its
+ * gradient never exist in memory.  tests/test_oracle_factored_upconv.py proves the identity on the oracle.
+ *
+ *   ad_pw_bank_pack   fp32 Keras kernel W[3][3][Cin][Cout] -> the two GEMM operands (dtype): bank_fwd = B[ci][tap*Cout+co]
+ *                     (for Y = x B), bank_bwd = B^T (for dx = dY B^T), ad_pw_bank_elems() elements each.
+ *   ad_pw_gemm        y[m][n] = sum_k x[m][k] bank[k][n] on the matrix cores; x, y NHWC with the pixels flattened;
+ *                     shapes ad_pw_supported() accepts: k % 64 == 0, n % 64 == 0, every tensor below 2 GiB.
+ *   ad_pw_bank_grad   dW[3][3][Cin][Cout] (Keras layout, fp32) from the [3][3][Cin][9 Cout] tensor that
+ *                     ad_conv3x3_wgrad(x as [m,1,1,Cin], dY as [m,1,1,9 Cout]) writes (dBank = x^T dY is its centre tap).
+ *   ad_upconv_gather_fwd   out[n,oy,ox,c] = act(bias[c] + sum_{dy,dx in -1..1} [oy+dy, ox+dx inside] sum_{a,b<2}
+ *                              wy[2(oy+dy)+a] wx[2(ox+dx)+b] ybank[n, sy[oy+dy]+a, sx[ox+dx]+b, (dy+1)*3+(dx+1), c])
+ *                     two-tap tables of the up-resize (second index clamped where its weight is 0), fp32 arithmetic.
+ *   ad_upconv_gather_bwd   dybank = gather^T(g): tables of the TRANSPOSED resize (first reading row / column and kyt / kxt
+ *                     weights per low-resolution index); kxt as ad_upconv_gather_bwd_supported() accepts. */
+int ad_pw_supported(int64_t m, int k, int n, int dtype);
+size_t ad_pw_bank_elems(int cin, int cout);
+int ad_pw_bank_pack(const float* w_hwio, int cin, int cout, void* bank_fwd, void* bank_bwd, int dtype, void* stream);
+int ad_pw_gemm(const void* x, const void* bank, void* y, int64_t m, int k, int n, int dtype, void* stream);
+int ad_pw_bank_grad(const float* dw9, int cin, int cout, float* dw_hwio, void* stream);
+int ad_upconv_gather_fwd(const void* ybank, const float* bias, void* out, const int* sy, const float* wy,
+                         const int* sx, const float* wx, int n, int h, int w, int oh, int ow, int c, int relu,
+                         int dtype, void* stream);
+int ad_upconv_gather_bwd_supported(int kxt);
+int ad_upconv_gather_bwd(const void* g, void* dybank, const int* ryt, const float* wyt, int kyt, const int* cxt,
+                         const float* wxt, int kxt, int n, int h, int w, int oh, int ow, int c, int dtype,
+                         void* stream);
+
 /* ------------------------------------------------------- gradient exchange -- */
 
 /* Data parallelism over patches (the reference is single-GPU): one process per GPU, the flat fp32 gradient

@@ -200,6 +200,73 @@ def resize_aa_bwd(dy: np.ndarray, h: int, w: int) -> np.ndarray:
 
 
 # --------------------------------------------------------------------------- #
+# Decoder step "up-resize -> Conv3x3 + ReLU" without the up-resized tensor
+#   Super_resolution/code/train_adaptive_unet.py:258-259  (dec_up -> L.Conv2D(nf, 3, padding="same", activation="relu"))
+#   shared/custom_layers.py:121-125                       (ResizeToMatch)
+# The resize acts on pixels, the convolution's contraction on channels, so the two commute:
+#   conv3x3(U x)[p] = b + sum_tap (U x)[p + tap] W_tap = b + sum_tap (U (x W_tap))[p + tap]        (zero outside the image)
+# i.e. a bank of nine 1x1 convolutions on the LOW-resolution map (Y_tap = x W_tap, 1 / ratio^2 of the conv's FLOPs)
+# followed by a gather that interpolates and shifts.  The product computes the step in this form; these functions
+# restate it tap by tap (no fused shortcuts) and tests/test_oracle_factored_upconv.py checks them against
+# relu(conv2d_same_fwd(resize_aa_fwd(x), w, b)) and its gradients to float64 rounding.
+# --------------------------------------------------------------------------- #
+
+
+def upconv_bank_fwd(x: np.ndarray, w: np.ndarray) -> np.ndarray:
+    """Y[n, h, w, tap, co] = sum_ci x[n, h, w, ci] W[tap // 3, tap % 3, ci, co]: nine 1x1 convolutions, one GEMM."""
+    kh, kw, cin, cout = w.shape
+    n, h, wd, _ = x.shape
+    bank = np.transpose(w.reshape(kh * kw, cin, cout), (1, 0, 2)).reshape(cin, kh * kw * cout)
+    return (np.ascontiguousarray(x).reshape(-1, cin) @ bank).reshape(n, h, wd, kh * kw, cout)
+
+
+def _shift_rows(m: np.ndarray, d: int) -> np.ndarray:
+    """Rows of the [out, in] resize matrix moved so that row p holds the weights of output index p + d (zero rows where
+    p + d falls outside the image: the convolution's zero padding lives at the HIGH resolution)."""
+    out = np.zeros_like(m)
+    n = m.shape[0]
+    lo, hi = max(0, -d), min(n, n - d)
+    out[lo:hi] = m[lo + d:hi + d]
+    return out
+
+
+def upconv_gather_fwd(y: np.ndarray, b: np.ndarray | None, oh: int, ow: int) -> np.ndarray:
+    """out[p] = b + sum_tap (U Y_tap)[p + tap]  (pre-activation)."""
+    n, h, w, taps, cout = y.shape
+    my, mx = aa_matrix(h, oh, y.dtype), aa_matrix(w, ow, y.dtype)
+    out = np.zeros((n, oh, ow, cout), dtype=y.dtype)
+    for t in range(taps):
+        dy, dx = t // 3 - 1, t % 3 - 1
+        out += _apply_axis(_shift_rows(mx, dx), _apply_axis(_shift_rows(my, dy), y[:, :, :, t, :], 1), 2)
+    if b is not None:
+        out += b
+    return out
+
+
+def upconv_gather_bwd(g: np.ndarray, h: int, w: int) -> np.ndarray:
+    """dY[n, h, w, tap, co] from the gradient g of the pre-activation: the transpose of upconv_gather_fwd."""
+    n, oh, ow, cout = g.shape
+    my, mx = aa_matrix(h, oh, g.dtype), aa_matrix(w, ow, g.dtype)
+    dy_ = np.zeros((n, h, w, 9, cout), dtype=g.dtype)
+    for t in range(9):
+        dy, dx = t // 3 - 1, t % 3 - 1
+        dy_[:, :, :, t, :] = _apply_axis(_shift_rows(my, dy).T, _apply_axis(_shift_rows(mx, dx).T, g, 2), 1)
+    return dy_
+
+
+def upconv_bank_bwd(x: np.ndarray, w: np.ndarray, dyb: np.ndarray):
+    """(dx, dw) of upconv_bank_fwd: dx = dY W_bank^T, dW_tap = x^T dY_tap."""
+    kh, kw, cin, cout = w.shape
+    n, h, wd, _ = x.shape
+    bank = np.transpose(w.reshape(kh * kw, cin, cout), (1, 0, 2)).reshape(cin, kh * kw * cout)
+    d2 = np.ascontiguousarray(dyb).reshape(-1, kh * kw * cout)
+    dx = (d2 @ bank.T).reshape(n, h, wd, cin)
+    dbank = np.ascontiguousarray(x).reshape(-1, cin).T @ d2
+    dw = np.transpose(dbank.reshape(cin, kh * kw, cout), (1, 0, 2)).reshape(kh, kw, cin, cout)
+    return dx, dw
+
+
+# --------------------------------------------------------------------------- #
 # ClippedResidualAdd  (shared/custom_layers.py:136-139)
 # --------------------------------------------------------------------------- #
 

@@ -259,7 +259,10 @@ def check_stored_masked(got, want, ok_pixels, what, store):
     tol, scale = stored_tol(want, store)
     bad = (np.abs(got - want) > tol) & ok_pixels[..., None]
     assert not bad.any(), (what, int(bad.sum()), float((np.abs(got - want) * ok_pixels[..., None]).max() / scale))
-    assert (~ok_pixels).sum() <= max(8, 0.01 * ok_pixels.size), (what, "too many pixels on a kink", int((~ok_pixels).sum()))
+    # a pixel is left out when ANY of its C pre-activations lies within KINK of zero: the expected share grows with C
+    # (observed 1.8 % at 1 024 channels, the 0.7 / depth 5 pyramid), so the allowance does too
+    allowed = max(8, 0.01 * ok_pixels.size * max(1.0, want.shape[-1] / 256.0))
+    assert (~ok_pixels).sum() <= allowed, (what, "too many pixels on a kink", int((~ok_pixels).sum()))
 
 
 def build(scale, depth, p, dtype, device):
