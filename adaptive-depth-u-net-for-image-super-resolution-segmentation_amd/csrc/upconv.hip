@@ -192,6 +192,149 @@ __global__ __launch_bounds__(256) void bank_grad_kernel(const float* __restrict_
     }
 }
 
+// ------------------------------------------------------------------ bank weight gradient (16-bit types)
+// dBank[k][n] = sum_m X[m][k] dY[m][n]: the contraction runs over PIXELS, which both operands have as their slow axis, so
+// the MFMA fragments (8 consecutive contraction indices per lane) are transposed reads from LDS (ds_read_b64_tr_b16, as
+// conv.hip's wgrad).  A 512-thread workgroup owns 128 input channels x 576 bank columns (nine taps x 64 output channels)
+// for its share of the pixels: 8 waves as 2 (k) x 4 (n), a wave holds 4 x 9 accumulator tiles (144 registers), so per
+// 32-pixel step it reads 8 + 18 transposed fragments for 36 MFMAs and X / dY are fetched from HBM ONCE per 128 / 576
+// channels -- the generic 1x1 wgrad re-reads X nine times and dY four times and writes eight zero taps.
+// Stages of 32 pixels are double buffered in LDS ([32][128] + [32][576] elements, row strides 288 / 1184 B: an odd number
+// of 32-byte units, so the eight rows a 32-lane half reads land on distinct banks), global loads one stage ahead in
+// registers, one barrier per stage.  Each workgroup writes its partial sums to a slab [split][K][N]; pw_wgrad_reduce sums
+// the splits in a fixed order (bitwise deterministic) straight into the Keras layout dW[tap][ci][co].
+constexpr int PWG_T = 512;
+constexpr int PWG_KT = 128, PWG_NT = 576;
+constexpr int PWG_XS = PWG_KT * 2 + 32;           // 288
+constexpr int PWG_DS = PWG_NT * 2 + 32;           // 1184
+constexpr int PWG_STAGE = 32 * PWG_XS + 32 * PWG_DS;      // 47,104 B
+constexpr int PWG_LDS = 2 * PWG_STAGE;
+
+struct PwWgradArgs {
+    const char* x; const char* dy; float* slab;
+    int m, k, n;
+    int mps;                 // pixels per split (multiple of 32)
+};
+
+template <typename E>
+__device__ __forceinline__ typename Half16<E>::v8 pw_tr_pair(const char* p0, const char* p1) {
+    typedef __attribute__((address_space(3))) short4_t* lds_p;
+    typedef __attribute__((ext_vector_type(8))) short short8_t;
+    const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p0));
+    const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p1));
+    return __builtin_bit_cast(typename Half16<E>::v8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+template <typename E>
+__global__ __launch_bounds__(PWG_T, 1) void pw_wgrad_kernel(PwWgradArgs a) {
+    typedef typename Half16<E>::v8 v8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wk = wave & 1, wn = wave >> 1;
+    const int split = blockIdx.x, kg = blockIdx.y, ng = blockIdx.z;
+    const int m_begin = split * a.mps, m_end = min(a.m, m_begin + a.mps);
+    const int nst = (m_end - m_begin + 31) / 32;
+    const auto rsx = pw_rsrc(a.x, (long long)a.m * a.k * 2);
+    const auto rsd = pw_rsrc(a.dy, (long long)a.m * a.n * 2);
+    // staging slots: X 32 rows x 16 parts (one per thread), dY 32 rows x 72 parts (slots tid + 512 i, i < 5)
+    const int xrow = tid >> 4, xpart = tid & 15;
+    int drow[5], dpart[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int sl = tid + PWG_T * i;
+        drow[i] = sl / 72; dpart[i] = sl - drow[i] * 72;       // rows >= 32: beyond the stage, never stored
+    }
+    u32x4 xr, dr[5];
+#define PWG_ISSUE(S)                                                                                             \
+    {                                                                                                            \
+        const int mb_ = m_begin + (S) * 32;                                                                      \
+        const int mx_ = mb_ + xrow;                                                                              \
+        xr = __builtin_amdgcn_raw_buffer_load_b128(rsx, mx_ < m_end ? (unsigned)((mx_ * a.k + kg * PWG_KT + xpart * 8) * 2) : PW_OOB, 0, 0); \
+        _Pragma("unroll") for (int i = 0; i < 5; ++i) {                                                          \
+            const int md_ = mb_ + drow[i];                                                                       \
+            dr[i] = __builtin_amdgcn_raw_buffer_load_b128(                                                       \
+                rsd, (drow[i] < 32 && md_ < m_end) ? (unsigned)((md_ * a.n + ng * PWG_NT + dpart[i] * 8) * 2) : PW_OOB, 0, 0); \
+        }                                                                                                        \
+    }
+#define PWG_STORE(BUF)                                                                                           \
+    {                                                                                                            \
+        char* xs_ = smem + (BUF) * PWG_STAGE;                                                                    \
+        char* ds_ = xs_ + 32 * PWG_XS;                                                                           \
+        *reinterpret_cast<u32x4*>(xs_ + xrow * PWG_XS + xpart * 16) = xr;                                        \
+        _Pragma("unroll") for (int i = 0; i < 5; ++i)                                                            \
+            if (drow[i] < 32) *reinterpret_cast<u32x4*>(ds_ + drow[i] * PWG_DS + dpart[i] * 16) = dr[i];         \
+    }
+    f32x4 acc[4][9];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 9; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // transposed-read addresses: lane (G = lane >> 4, q = (lane & 15) >> 2, p = lane & 3) supplies row 4 G + q (+ 16 for
+    // the second half of the fragment), 8 bytes at column 4 p of the 16-channel tile; contraction index 8 G + j of the
+    // MFMA <-> pixel 16 (j >> 2) + 4 G + (j & 3) of the stage, the same map for both operands
+    const int G = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    const int xa = (4 * G + q) * PWG_XS + wk * 128 + pp * 8;              // + kt * 32 (+ 16 rows for the second read)
+    const int da = (4 * G + q) * PWG_DS + wn * 288 + pp * 8;              // + nt * 32
+    if (nst > 0) PWG_ISSUE(0)
+    for (int s = 0; s < nst; ++s) {
+        PWG_STORE(s & 1)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        PWG_ISSUE(s + 1)                   // (past the split: every offset out of range, zeros that are never stored)
+        const char* xs = smem + (s & 1) * PWG_STAGE;
+        const char* ds = xs + 32 * PWG_XS;
+        v8 xf[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) xf[kt] = pw_tr_pair<E>(xs + xa + kt * 32, xs + xa + kt * 32 + 16 * PWG_XS);
+#pragma unroll
+        for (int nt = 0; nt < 9; ++nt) {
+            const v8 df = pw_tr_pair<E>(ds + da + nt * 32, ds + da + nt * 32 + 16 * PWG_DS);
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) acc[kt][nt] = Half16<E>::mfma(xf[kt], df, acc[kt][nt]);
+        }
+    }
+#undef PWG_ISSUE
+#undef PWG_STORE
+    // lane holds dBank[k = kg*128 + wk*64 + kt*16 + 4 G + r][n = ng*576 + wn*144 + nt*16 + (lane & 15)]
+    float* slab = a.slab + (size_t)split * a.k * a.n;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float* row = slab + (size_t)(kg * PWG_KT + wk * 64 + kt * 16 + 4 * G + r) * a.n + ng * PWG_NT + wn * 144 + (lane & 15);
+#pragma unroll
+            for (int nt = 0; nt < 9; ++nt) row[nt * 16] = acc[kt][nt][r];
+        }
+}
+
+// dW[tap][ci][co] = sum over the splits, in ascending order, of slab[split][ci][tap * cout + co]
+__global__ __launch_bounds__(256) void pw_wgrad_reduce_kernel(const float* __restrict__ slab, int nsplit, int cin, int cout,
+                                                              float* __restrict__ dw) {
+    const int n9 = 9 * cout;
+    const int total4 = 9 * cin * cout / 4;
+    const size_t stride = (size_t)cin * n9;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total4; e += gridDim.x * 256) {
+        const int co = (e * 4) % cout, r = (e * 4) / cout;
+        const int ci = r % cin, tap = r / cin;
+        const float* src = slab + (size_t)ci * n9 + tap * cout + co;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        int sp = 0;
+        for (; sp + 3 < nsplit; sp += 4) {               // four independent loads in flight, added in a fixed order
+            const float4 v0 = *reinterpret_cast<const float4*>(src + (size_t)sp * stride);
+            const float4 v1 = *reinterpret_cast<const float4*>(src + (size_t)(sp + 1) * stride);
+            const float4 v2 = *reinterpret_cast<const float4*>(src + (size_t)(sp + 2) * stride);
+            const float4 v3 = *reinterpret_cast<const float4*>(src + (size_t)(sp + 3) * stride);
+            s.x += (v0.x + v1.x) + (v2.x + v3.x); s.y += (v0.y + v1.y) + (v2.y + v3.y);
+            s.z += (v0.z + v1.z) + (v2.z + v3.z); s.w += (v0.w + v1.w) + (v2.w + v3.w);
+        }
+        for (; sp < nsplit; ++sp) {
+            const float4 v = *reinterpret_cast<const float4*>(src + (size_t)sp * stride);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        *reinterpret_cast<float4*>(dw + (size_t)e * 4) = s;
+    }
+}
+
 // ------------------------------------------------------------------ gather (forward)
 // out[n][oy][ox][c] = act(bias[c] + sum_{dy,dx} [row oy+dy, column ox+dx inside the image]
 //                         sum_{a,b < 2} wy[oy+dy][a] wx[ox+dx][b] Y[n][sy[oy+dy]+a][sx[ox+dx]+b][tap(dy,dx)][c])
@@ -432,6 +575,58 @@ extern "C" int ad_pw_bank_grad(const float* dw9, int cin, int cout, float* dw_hw
     const int blocks = (total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048;
     bank_grad_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(dw9, cin, cout, dw_hwio);
     AD_LAUNCH_CHECK("ad_pw_bank_grad");
+    return AD_OK;
+}
+
+// pixels per split and number of splits of the bank weight gradient
+static void pw_wgrad_plan(int64_t m, int k, int n, int* mps, int* nsplit) {
+    const int groups = (k / PWG_KT) * (n / PWG_NT);
+    int want = 256 / groups;
+    if (want < 1) want = 1;
+    int per = (int)((m + want - 1) / want);
+    per = (per + 31) / 32 * 32;
+    *mps = per;
+    *nsplit = (int)((m + per - 1) / per);
+}
+
+extern "C" int ad_pw_wgrad_supported(int64_t m, int cin, int cout, int dtype) {
+    if (!ad_is_half(dtype) || m <= 0 || cin <= 0 || cout <= 0 || cin % PWG_KT || cout % 64) return 0;
+    return m * (cin > 9LL * cout ? cin : 9LL * cout) * 2 <= PW_MAX_BYTES;
+}
+
+extern "C" size_t ad_pw_wgrad_ws_bytes(int64_t m, int cin, int cout) {
+    if (m <= 0 || cin <= 0 || cout <= 0 || cin % PWG_KT || cout % 64) return 0;
+    int mps, nsplit;
+    pw_wgrad_plan(m, cin, 9 * cout, &mps, &nsplit);
+    return (size_t)nsplit * cin * 9 * cout * sizeof(float);
+}
+
+extern "C" int ad_pw_wgrad(const void* x, const void* dybank, float* dw_hwio, int64_t m, int cin, int cout, void* ws,
+                           size_t ws_bytes, int dtype, void* stream) {
+    AD_REQUIRE(ad_pw_wgrad_supported(m, cin, cout, dtype), "ad_pw_wgrad: unsupported m=%lld cin=%d cout=%d dtype=%d", (long long)m,
+               cin, cout, dtype);
+    AD_REQUIRE(x && dybank && dw_hwio && (uintptr_t)dw_hwio % 16 == 0, "ad_pw_wgrad: NULL or unaligned operand");
+    const size_t need = ad_pw_wgrad_ws_bytes(m, cin, cout);
+    if (!ws || ws_bytes < need) return ad_set_error(AD_ERR_WS, "ad_pw_wgrad: workspace %zu < %zu bytes", ws_bytes, need);
+    PwWgradArgs a;
+    a.x = (const char*)x; a.dy = (const char*)dybank; a.slab = (float*)ws;
+    a.m = (int)m; a.k = cin; a.n = 9 * cout;
+    int nsplit;
+    pw_wgrad_plan(m, a.k, a.n, &a.mps, &nsplit);
+    hipStream_t s = (hipStream_t)stream;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pw_wgrad_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, PWG_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pw_wgrad_kernel<f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, PWG_LDS);
+        attr = true;
+    }
+    dim3 grid(nsplit, a.k / PWG_KT, a.n / PWG_NT);
+    if (dtype == AD_BF16) pw_wgrad_kernel<bf16_t><<<grid, PWG_T, PWG_LDS, s>>>(a);
+    else pw_wgrad_kernel<f16_t><<<grid, PWG_T, PWG_LDS, s>>>(a);
+    AD_LAUNCH_CHECK("ad_pw_wgrad");
+    const int total4 = 9 * cin * cout / 4;
+    pw_wgrad_reduce_kernel<<<(total4 + 255) / 256 < 2048 ? (total4 + 255) / 256 : 2048, 256, 0, s>>>((const float*)ws, nsplit, cin, cout, dw_hwio);
+    AD_LAUNCH_CHECK("pw_wgrad_reduce");
     return AD_OK;
 }
 

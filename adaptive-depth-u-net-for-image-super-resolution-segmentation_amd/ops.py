@@ -475,6 +475,13 @@ def upconv_bank_wgrad(x_low: torch.Tensor, dybank: torch.Tensor, dw_out: torch.T
     """dW [3,3,cin,cout] (fp32 view of the flat gradient buffer) = re-ordered x_low^T dybank (contraction over pixels)."""
     cin, n9 = x_low.shape[-1], dybank.shape[-1]
     m = x_low.numel() // cin
+    lib = _lib.load()
+    if lib.ad_pw_wgrad_supported(m, cin, n9 // 9, dt(x_low.dtype)):         # one pass over x and dY (16-bit types)
+        ws.ensure(lib.ad_pw_wgrad_ws_bytes(m, cin, n9 // 9))
+        with _timed("pw_wgrad", 2.0 * m * cin * n9, float(m * (cin + n9) * x_low.element_size())):
+            check(lib.ad_pw_wgrad(_p(x_low), _p(dybank), _p(dw_out), m, cin, n9 // 9, ws.ptr, ws.nbytes, dt(x_low.dtype), _stream()),
+                  "ad_pw_wgrad")
+        return
     dw9 = torch.empty((3, 3, cin, n9), dtype=torch.float32, device=x_low.device)
     conv3x3_wgrad(x_low.view(m, 1, 1, cin), None, dybank.view(m, 1, 1, n9), dw9, cin, ws)
     with _timed("pw_bank_grad"):

@@ -367,6 +367,13 @@ size_t ad_pw_bank_elems(int cin, int cout);
 int ad_pw_bank_pack(const float* w_hwio, int cin, int cout, void* bank_fwd, void* bank_bwd, int dtype, void* stream);
 int ad_pw_gemm(const void* x, const void* bank, void* y, int64_t m, int k, int n, int dtype, void* stream);
 int ad_pw_bank_grad(const float* dw9, int cin, int cout, float* dw_hwio, void* stream);
+/* dW[3][3][Cin][Cout] (Keras layout, fp32) = re-ordered x^T dybank over the m pixels, in one pass over x and dybank
+ * (16-bit types, Cin % 128 == 0, Cout % 64 == 0: ad_pw_wgrad_supported; elsewhere ad_conv3x3_wgrad + ad_pw_bank_grad).
+ * Per-workgroup partial sums go to ws (ad_pw_wgrad_ws_bytes) and are added in a fixed order: bitwise deterministic. */
+int ad_pw_wgrad_supported(int64_t m, int cin, int cout, int dtype);
+size_t ad_pw_wgrad_ws_bytes(int64_t m, int cin, int cout);
+int ad_pw_wgrad(const void* x, const void* dybank, float* dw_hwio, int64_t m, int cin, int cout, void* ws, size_t ws_bytes,
+                int dtype, void* stream);
 int ad_upconv_gather_fwd(const void* ybank, const float* bias, void* out, const int* sy, const float* wy,
                          const int* sx, const float* wx, int n, int h, int w, int oh, int ow, int c, int relu,
                          int dtype, void* stream);

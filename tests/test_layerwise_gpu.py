@@ -119,6 +119,31 @@ def audit_sr_step(model, lr, hr):
             _, _, xin, u = rec
             want = ref.relu_fwd(ref.conv2d_same_fwd(f64(xin), q(W[name + "/kernel"]), W[name + "/bias"]))
             check_stored(u, want, name + " relu(conv)", bf16)
+        elif kind == "fwd_bank":
+            # factored up-conv (csrc/upconv.hip), step 1: nine 1x1 convolutions on the low-resolution map
+            _, _, xin, yb = rec
+            want = ref.upconv_bank_fwd(f64(xin), q(W[name + "/kernel"]))
+            check_stored(yb, want.reshape(yb.shape), name + " 1x1 bank", bf16)
+        elif kind == "fwd_gather":
+            # ... step 2: out = relu(b + sum_tap (U Y_tap)[p + tap]) on the product's own bank
+            _, _, yb, u = rec
+            seen.add("fwd_ca")
+            nb, hb, wb, c9 = yb.shape
+            want = ref.relu_fwd(ref.upconv_gather_fwd(f64(yb).reshape(nb, hb, wb, 9, c9 // 9), W[name + "/bias"], u.shape[1], u.shape[2]))
+            check_stored(u, want, name + " relu(gather)", bf16)
+        elif kind == "bwd_caf":
+            _, _, xin, u, d_in, dz, dyb, d = rec
+            seen.add("bwd_ca")
+            if dz is not d_in:            # (the same tensor when the dgrad above already applied this ReLU's gradient)
+                want_dz = f64(d_in) * (f64(u) > 0)
+                assert np.array_equal(f64(dz), want_dz), name + " relu grad"
+                check_f32(G[name + "/bias"], want_dz.reshape(-1, want_dz.shape[-1]).sum(0), name + "/bias grad")
+            nb, hb, wb, cin = xin.shape
+            want_dyb = ref.upconv_gather_bwd(f64(dz), hb, wb)
+            check_stored(dyb, want_dyb.reshape(dyb.shape), name + " gather^T", bf16)
+            dx, dw = ref.upconv_bank_bwd(f64(xin), q(W[name + "/kernel"]), f64(dyb).reshape(want_dyb.shape))
+            check_f32(G[name + "/kernel"], dw, name + "/kernel grad")
+            check_stored(d, dx, name + " dx (1x1 bank)", bf16)
         elif kind == "fwd_head":
             _, _, xh, inp, target, o, stats = rec
             r = ref.conv2d_same_fwd(f64(xh), W["residual_rgb/kernel"], W["residual_rgb/bias"])
@@ -249,10 +274,12 @@ def audit_sr_step(model, lr, hr):
             if before is not None:
                 want = want + f64(before)
             check_stored(d, want, name + " bwd", bf16)
-    assert seen - {"fused_relu_grad", "bwd_head_ln", "bwd_resize_ln", "bwd_dgrad_ln"} == {"fwd_cla", "fwd_resize", "fwd_ca", "fwd_head", "bwd_head", "bwd_cla", "bwd_ca",
-                                                        "bwd_resize"}
-    # (a fused dgrad + LayerNorm backward adds a record of its own next to the two "bwd_cla" records it spans)
-    return sum(r[0] != "bwd_dgrad_ln" for r in records), ("fused_relu_grad" in seen, "bwd_dgrad_ln" in seen)
+    extra = {"fused_relu_grad", "bwd_head_ln", "bwd_resize_ln", "bwd_dgrad_ln", "fwd_bank", "fwd_gather", "bwd_caf"}
+    assert seen - extra == {"fwd_cla", "fwd_resize", "fwd_ca", "fwd_head", "bwd_head", "bwd_cla", "bwd_ca", "bwd_resize"}
+    # (a fused dgrad + LayerNorm backward adds a record of its own next to the two "bwd_cla" records it spans; a factored
+    # up-conv's backward is one record where the resize + conv pair has two)
+    nrec = sum(r[0] != "bwd_dgrad_ln" for r in records) + sum(r[0] == "bwd_caf" for r in records)
+    return nrec, ("fused_relu_grad" in seen, "bwd_dgrad_ln" in seen), sum(r[0] == "bwd_caf" for r in records)
 
 
 def check_stored_masked(got, want, ok_pixels, what, store):
@@ -303,7 +330,9 @@ def test_every_step_of_the_model_against_the_oracle(device, cfg, dtype):
         pytest.skip("half is audited on the configurations that reach the wave-specialised kernels (and one small one)")
     model = build(scale, depth, p, dtype, device)
     lr, hr = synth(np.random.default_rng(4321), n, p)
-    nrec, (fused_relu, fused_ln) = audit_sr_step(model, lr, hr)
+    nrec, (fused_relu, fused_ln), nfactored = audit_sr_step(model, lr, hr)
+    # decoder levels whose source map is at least 16 pixels wide run the up-conv in the factored form, in every dtype
+    assert nfactored == sum(sz >= 16 for sz in model.sizes[1:]), (nfactored, model.sizes)
     if cfg[0] in BIG_LAUNCH_CONFIGS:  # the weights-resident kernels with the fused ReLU-grad / LayerNorm-backward epilogues
         half = dtype != torch.float32
         assert fused_relu == half and fused_ln == half, (fused_relu, fused_ln)
