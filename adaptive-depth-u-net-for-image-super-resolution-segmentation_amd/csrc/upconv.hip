@@ -339,21 +339,55 @@ __global__ __launch_bounds__(256) void pw_wgrad_reduce_kernel(const float* __res
 // out[n][oy][ox][c] = act(bias[c] + sum_{dy,dx} [row oy+dy, column ox+dx inside the image]
 //                         sum_{a,b < 2} wy[oy+dy][a] wx[ox+dx][b] Y[n][sy[oy+dy]+a][sx[ox+dx]+b][tap(dy,dx)][c])
 // Tables: two taps per output index (an up-resize never has more), the second index clamped and weighted 0 where the
-// source has no such row / column.  A thread owns one (output column, 16-byte channel vector) for R consecutive output
-// rows and walks down the low-resolution rows those rows (and their +-1 neighbours) interpolate from; per low-resolution
-// row it forms the three horizontally interpolated and shifted sums (one per dy: 3 dx x 2 taps = 6 loads each) and adds
-// them to the row accumulators with the rows' vertical weights, which are uniform over the workgroup (scalar branches).
+// source has no such row / column; sy is non-decreasing and sy[r+1] - sy[r-1] <= window - 2 (checked by the host;
+// window = 3 for every resize of ratio >= 2).
+// A thread owns one (output column, 16-byte channel vector) and MARCHES down a strip of output rows.  It keeps, for each
+// of the three vertical taps dy, the horizontally interpolated and shifted sums
+//     H_dy[q] = sum_dx sum_b wx[ox+dx][b] Y[q][sx[ox+dx]+b][tap(dy,dx)]          (3 dx x 2 taps = 6 loads each)
+// of a sliding window of three or four low-resolution rows q in registers (fp32): every low-resolution row is interpolated ONCE per
+// strip and column (the strip-per-8-rows version of this kernel redid it for every strip: 5x the arithmetic at ratio 4),
+// and an output row is two fused multiply-adds per dy on window entries picked by workgroup-uniform table values.
 struct GatherArgs {
     const char* y; const float* bias; char* out;
     const int* sy; const float* wy; const int* sx; const float* wx;
-    int h, w, oh, ow, c, relu;
+    int h, w, oh, ow, c, relu, rows;      // rows: output rows per strip
 };
 
-template <typename T, int R>
+constexpr int GF_MAXROWS = 64;
+constexpr int GB_MAXKY = 30;   // most transposed vertical taps the backward gather stages
+
+// 8-byte vector of T, unpacked to / packed from fp32 (the gathers keep per-thread state small: occupancy hides their latency)
+template <typename T> struct VecH;
+template <> struct VecH<float> {
+    static constexpr int N = 2;
+    float2 v;
+    __device__ __forceinline__ void load(const void* p) { v = *reinterpret_cast<const float2*>(p); }
+    __device__ __forceinline__ void store(void* p) const { *reinterpret_cast<float2*>(p) = v; }
+    __device__ __forceinline__ void to_f32(float* f) const { f[0] = v.x; f[1] = v.y; }
+    __device__ __forceinline__ void from_f32(const float* f) { v = make_float2(f[0], f[1]); }
+};
+template <typename E> struct VecH16 {
+    static constexpr int N = 4;
+    typename Half16<E>::v4 v;
+    __device__ __forceinline__ void load(const void* p) { v = *reinterpret_cast<const typename Half16<E>::v4*>(p); }
+    __device__ __forceinline__ void store(void* p) const { *reinterpret_cast<typename Half16<E>::v4*>(p) = v; }
+    __device__ __forceinline__ void to_f32(float* f) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f[i] = (float)v[i];
+    }
+    __device__ __forceinline__ void from_f32(const float* f) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = (E)f[i];
+    }
+};
+template <> struct VecH<bf16_t> : VecH16<bf16_t> {};
+template <> struct VecH<f16_t> : VecH16<f16_t> {};
+
+template <typename T, int GW>
 __global__ __launch_bounds__(256) void upconv_gather_fwd_kernel(GatherArgs a) {
-    constexpr int EPT = ElemTraits<T>::EPT;
+    constexpr int EPT = VecH<T>::N;
     const int vecs = a.c / EPT;
-    const int oy0 = blockIdx.y * R, nn = blockIdx.z;
+    const int oy0 = blockIdx.y * a.rows, oy1 = min(oy0 + a.rows, a.oh), nn = blockIdx.z;
     const int i = blockIdx.x * 256 + threadIdx.x;
     const bool live = i < a.ow * vecs;
     const int ox = live ? i / vecs : 0, v = live ? i - ox * vecs : 0;
@@ -368,75 +402,105 @@ __global__ __launch_bounds__(256) void upconv_gather_fwd_kernel(GatherArgs a) {
         const int x0 = a.sx[ccl];
         fx[d][0] = ok ? a.wx[2 * ccl] : 0.f;
         fx[d][1] = ok ? a.wx[2 * ccl + 1] : 0.f;
-        xoff[d][0] = x0 * 9 * a.c + v * EPT;
-        xoff[d][1] = min(x0 + 1, a.w - 1) * 9 * a.c + v * EPT;
+        xoff[d][0] = (x0 * 9 + d) * a.c + v * EPT;
+        xoff[d][1] = (min(x0 + 1, a.w - 1) * 9 + d) * a.c + v * EPT;
     }
-    const int rlo = max(oy0 - 1, 0), rhi = min(oy0 + R, a.oh - 1);
-    int qlo = a.h - 1, qhi = 0;                        // low-resolution rows the strip reads (workgroup-uniform)
-    for (int rr = rlo; rr <= rhi; ++rr) {
-        qlo = min(qlo, a.sy[rr]);
-        qhi = max(qhi, min(a.sy[rr] + 1, a.h - 1));
-    }
-    float acc[R][EPT];
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-#pragma unroll
-        for (int e = 0; e < EPT; ++e) acc[r][e] = 0.f;
-    const T* yn = reinterpret_cast<const T*>(a.y) + (size_t)nn * a.h * a.w * 9 * a.c;
-    for (int q = qlo; q <= qhi; ++q) {
-        const T* row = yn + (size_t)q * a.w * 9 * a.c;
-        float hs[3][EPT];
-#pragma unroll
-        for (int dyi = 0; dyi < 3; ++dyi) {
-            Vec16<T> ld[3][2];
-#pragma unroll
-            for (int d = 0; d < 3; ++d)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) ld[d][b].load(row + xoff[d][b] + (dyi * 3 + d) * a.c);
-#pragma unroll
-            for (int e = 0; e < EPT; ++e) hs[dyi][e] = 0.f;
-#pragma unroll
-            for (int d = 0; d < 3; ++d)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    float t[EPT];
-                    ld[d][b].to_f32(t);
-#pragma unroll
-                    for (int e = 0; e < EPT; ++e) hs[dyi][e] += fx[d][b] * t[e];
-                }
-        }
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-#pragma unroll
-            for (int dyi = 0; dyi < 3; ++dyi) {
-                const int rr = oy0 + r + dyi - 1;                   // workgroup-uniform
-                if (rr < 0 || rr >= a.oh) continue;
-                const int k = q - a.sy[rr];
-                if (k != 0 && k != 1) continue;
-                const float fy = a.wy[2 * rr + k];
-                if (fy == 0.f) continue;
-#pragma unroll
-                for (int e = 0; e < EPT; ++e) acc[r][e] += fy * hs[dyi][e];
-            }
-        }
-    }
-    if (!live) return;
     float bv[EPT];
 #pragma unroll
     for (int e = 0; e < EPT; ++e) bv[e] = a.bias ? a.bias[v * EPT + e] : 0.f;
+    const T* yn = reinterpret_cast<const T*>(a.y) + (size_t)nn * a.h * a.w * 9 * a.c;
+    float hs[3][GW][EPT];
+    // H_dy[q] for the three dy into window slot SLOT: 18 loads, then the arithmetic.  (Measured and withdrawn: keeping the
+    // 18 vectors of the NEXT window row in flight across the output rows in between -- 256 registers, one wave per SIMD
+    // less, 0.45 -> 0.49 ms on the 64 -> 256 level: this kernel lives on occupancy, hence also the 8-byte vectors.)
+    VecH<T> pend[3][3][2];
+#define GF_ISSUE(Q)                                                                                        \
+    {                                                                                                      \
+        const T* row_ = yn + (size_t)min((Q), a.h - 1) * a.w * 9 * a.c;                                    \
+        _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_)                                                   \
+            _Pragma("unroll") for (int d_ = 0; d_ < 3; ++d_)                                               \
+                _Pragma("unroll") for (int b_ = 0; b_ < 2; ++b_) pend[s_][d_][b_].load(row_ + xoff[d_][b_] + s_ * 3 * a.c); \
+    }
+#define GF_TAKE(SLOT)                                                                                      \
+    {                                                                                                      \
+        _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_) {                                                 \
+            _Pragma("unroll") for (int e_ = 0; e_ < EPT; ++e_) hs[s_][SLOT][e_] = 0.f;                     \
+            _Pragma("unroll") for (int d_ = 0; d_ < 3; ++d_)                                               \
+                _Pragma("unroll") for (int b_ = 0; b_ < 2; ++b_) {                                         \
+                    float t_[EPT];                                                                         \
+                    pend[s_][d_][b_].to_f32(t_);                                                           \
+                    _Pragma("unroll") for (int e_ = 0; e_ < EPT; ++e_) hs[s_][SLOT][e_] += fx[d_][b_] * t_[e_]; \
+                }                                                                                          \
+        }                                                                                                  \
+    }
+#define GF_ROW(Q, SLOT) GF_ISSUE(Q) GF_TAKE(SLOT)
+    // Per-row table values of the strip, staged in LDS once: the window advance of each output row and, per vertical tap
+    // dy, the weights of the four window rows (two of them non-zero; all zero where row oy + dy is outside the image).
+    // Read back as LDS broadcasts: table loads from global memory inside the row loop would sit in the same vmcnt queue as
+    // the row stores and turn every row into three dependent memory round trips.
+    __shared__ __attribute__((aligned(16))) float s_w[GF_MAXROWS][12];
+    __shared__ int s_adv[GF_MAXROWS];
+    for (int r = threadIdx.x; r < oy1 - oy0; r += 256) {
+        const int oy = oy0 + r;
+        const int qb = a.sy[max(oy - 1, 0)];
+        s_adv[r] = r == 0 ? 0 : qb - a.sy[max(oy - 2, 0)];
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        if (oy0 + r >= a.oh) break;
+        for (int s_ = 0; s_ < 3; ++s_) {
+            const int rr = oy + s_ - 1;
+            const bool ok = rr >= 0 && rr < a.oh;
+            const int k0 = ok ? a.sy[rr] - qb : 0;
+            const float f0 = ok ? a.wy[2 * rr] : 0.f, f1 = ok ? a.wy[2 * rr + 1] : 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s_w[r][s_ * 4 + k] = k == k0 ? f0 : (k == k0 + 1 ? f1 : 0.f);
+        }
+    }
+    int qbase = a.sy[max(oy0 - 1, 0)];                 // the window holds rows qbase .. qbase + GW - 1 (workgroup-uniform)
+    // (the scheduling barriers keep hipcc from issuing the 72 loads of the four initial rows at once: 144 registers)
+    GF_ROW(qbase, 0) __builtin_amdgcn_sched_barrier(0);
+    GF_ROW(qbase + 1, 1) __builtin_amdgcn_sched_barrier(0);
+    GF_ROW(qbase + 2, 2)
+    if constexpr (GW == 4) {
+        __builtin_amdgcn_sched_barrier(0);
+        GF_ROW(qbase + 3, 3)
+    }
+    __syncthreads();
+    T* on = reinterpret_cast<T*>(a.out) + ((size_t)nn * a.oh * a.ow + ox) * a.c + v * EPT;
+    for (int r = 0; r < oy1 - oy0; ++r) {
+        for (int adv = __builtin_amdgcn_readfirstlane(s_adv[r]); adv > 0; --adv) {    // slide: drop row qbase, add row qbase + GW
+#pragma unroll
+            for (int s_ = 0; s_ < 3; ++s_)
+#pragma unroll
+                for (int k = 0; k + 1 < GW; ++k)
+#pragma unroll
+                    for (int e = 0; e < EPT; ++e) hs[s_][k][e] = hs[s_][k + 1][e];
+            GF_ROW(qbase + GW, GW - 1)
+            ++qbase;
+        }
         float o[EPT];
 #pragma unroll
-        for (int e = 0; e < EPT; ++e) {
-            o[e] = acc[r][e] + bv[e];
-            if (a.relu) o[e] = fmaxf(o[e], 0.f);
+        for (int e = 0; e < EPT; ++e) o[e] = bv[e];
+#pragma unroll
+        for (int s_ = 0; s_ < 3; ++s_) {
+            const float4 wv = *reinterpret_cast<const float4*>(&s_w[r][s_ * 4]);
+            const float wk[4] = {wv.x, wv.y, wv.z, wv.w};          // (wk[3] is 0 when the window has three rows)
+#pragma unroll
+            for (int k = 0; k < GW; ++k)
+#pragma unroll
+                for (int e = 0; e < EPT; ++e) o[e] += wk[k] * hs[s_][k][e];
         }
-        Vec16<T> st;
-        st.from_f32(o);
-        st.store(reinterpret_cast<T*>(a.out) + (((size_t)nn * a.oh + oy0 + r) * a.ow + ox) * a.c + v * EPT);
+        if (a.relu) {
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) o[e] = fmaxf(o[e], 0.f);
+        }
+        if (live) {
+            VecH<T> st;
+            st.from_f32(o);
+            st.store(on + (size_t)(oy0 + r) * a.ow * a.c);
+        }
     }
+#undef GF_ROW
+#undef GF_ISSUE
+#undef GF_TAKE
 }
 
 // ------------------------------------------------------------------ gather (backward): the transpose
@@ -459,8 +523,8 @@ __global__ __launch_bounds__(256) void upconv_gather_bwd_kernel(GatherBwdArgs a)
     const int vecs = a.c / EPT;
     const int qy = blockIdx.y, nn = blockIdx.z;
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= a.w * vecs) return;
-    const int qx = i / vecs, v = i - qx * vecs;
+    const bool live = i < a.w * vecs;
+    const int qx = live ? i / vecs : 0, v = live ? i - qx * vecs : 0;
     const int c0 = a.cxt[qx] - 1;                      // first column of the window
     // weight of window column j for shift d: wxt[qx][j - 1 + (d - 1)] = wxt[qx][j + d - 2]
     float wj[3][KX2];
@@ -486,6 +550,16 @@ __global__ __launch_bounds__(256) void upconv_gather_bwd_kernel(GatherBwdArgs a)
             for (int e = 0; e < EPT; ++e) acc[s][d][e] = 0.f;
     const T* gn = reinterpret_cast<const T*>(a.g) + (size_t)nn * a.oh * a.ow * a.c;
     const int r0 = a.ryt[qy];
+    // vertical weights of the window rows, per dy, staged in LDS (workgroup-uniform; read back as broadcasts instead of
+    // global loads that would serialise with the gradient loads on vmcnt): row j <-> gradient row r0 - 1 + j, which is
+    // hi-res row r0 - 1 + j + dy of the resized tensor, transposed tap k = j + s - 2
+    __shared__ __attribute__((aligned(16))) float s_fy[GB_MAXKY + 2][4];
+    for (int t = threadIdx.x; t < (a.kyt + 2) * 3; t += 256) {
+        const int j = t / 3, s_ = t - j * 3, k = j + s_ - 2;
+        s_fy[j][s_] = (k >= 0 && k < a.kyt) ? a.wyt[qy * a.kyt + k] : 0.f;
+    }
+    __syncthreads();
+    if (!live) return;
     for (int p = max(r0 - 1, 0); p <= min(r0 + a.kyt, a.oh - 1); ++p) {
         const T* row = gn + (size_t)p * a.ow * a.c;
         float hs[3][EPT];
@@ -493,28 +567,26 @@ __global__ __launch_bounds__(256) void upconv_gather_bwd_kernel(GatherBwdArgs a)
         for (int d = 0; d < 3; ++d)
 #pragma unroll
             for (int e = 0; e < EPT; ++e) hs[d][e] = 0.f;
+        Vec16<T> ld[KX2];
+#pragma unroll
+        for (int j = 0; j < KX2; ++j) ld[j].load(row + coff[j]);
 #pragma unroll
         for (int j = 0; j < KX2; ++j) {
-            Vec16<T> ld;
             float t[EPT];
-            ld.load(row + coff[j]);
-            ld.to_f32(t);
+            ld[j].to_f32(t);
 #pragma unroll
             for (int d = 0; d < 3; ++d)
 #pragma unroll
                 for (int e = 0; e < EPT; ++e) hs[d][e] += wj[d][j] * t[e];
         }
+        const float4 fyv = *reinterpret_cast<const float4*>(&s_fy[p - (r0 - 1)][0]);
+        const float fy[3] = {fyv.x, fyv.y, fyv.z};
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {                  // dy = s - 1: gradient row p belongs to hi-res row r = p + dy
-            const int k = p + s - 1 - r0;              // workgroup-uniform
-            if (k < 0 || k >= a.kyt) continue;
-            const float fy = a.wyt[qy * a.kyt + k];
-            if (fy == 0.f) continue;
+        for (int s_ = 0; s_ < 3; ++s_)
 #pragma unroll
             for (int d = 0; d < 3; ++d)
 #pragma unroll
-                for (int e = 0; e < EPT; ++e) acc[s][d][e] += fy * hs[d][e];
-        }
+                for (int e = 0; e < EPT; ++e) acc[s_][d][e] += fy[s_] * hs[d][e];
     }
     T* dst = reinterpret_cast<T*>(a.dy) + ((((size_t)nn * a.h + qy) * a.w + qx) * 9) * a.c + v * EPT;
 #pragma unroll
@@ -631,8 +703,8 @@ extern "C" int ad_pw_wgrad(const void* x, const void* dybank, float* dw_hwio, in
 }
 
 extern "C" int ad_upconv_gather_fwd(const void* ybank, const float* bias, void* out, const int* sy, const float* wy,
-                                    const int* sx, const float* wx, int n, int h, int w, int oh, int ow, int c, int relu,
-                                    int dtype, void* stream) {
+                                    const int* sx, const float* wx, int window, int n, int h, int w, int oh, int ow, int c,
+                                    int relu, int dtype, void* stream) {
     AD_REQUIRE(ad_dtype_ok(dtype), "ad_upconv_gather_fwd: bad dtype %d", dtype);
     const int ept = ad_is_half(dtype) ? 8 : 4;
     AD_REQUIRE(ybank && out && sy && wy && sx && wx, "ad_upconv_gather_fwd: NULL operand");
@@ -644,14 +716,21 @@ extern "C" int ad_upconv_gather_fwd(const void* ybank, const float* bias, void* 
     a.y = (const char*)ybank; a.bias = bias; a.out = (char*)out;
     a.sy = sy; a.wy = wy; a.sx = sx; a.wx = wx;
     a.h = h; a.w = w; a.oh = oh; a.ow = ow; a.c = c; a.relu = relu;
-    constexpr int R = 8;
-    dim3 grid((ow * (c / ept) + 255) / 256, (oh + R - 1) / R, n);
-    AD_DISPATCH_DTYPE(dtype, T_, upconv_gather_fwd_kernel<T_, R><<<grid, 256, 0, (hipStream_t)stream>>>(a);)
+    AD_REQUIRE(window == 3 || window == 4, "ad_upconv_gather_fwd: window=%d (3: sy advances by at most 1 over two rows; 4: by 2)", window);
+    // strips: long enough to amortise the four window rows a strip starts with, short enough to fill the chip (>= ~16
+    // workgroups per CU in all)
+    const int bx = (ow * (c / (ept / 2)) + 255) / 256;           // 8-byte channel vectors
+    int rows = 64;
+    while (rows > 16 && (long long)bx * ((oh + rows - 1) / rows) * n < 4096) rows /= 2;
+    a.rows = rows;
+    dim3 grid(bx, (oh + rows - 1) / rows, n);
+    if (window == 3) { AD_DISPATCH_DTYPE(dtype, T_, upconv_gather_fwd_kernel<T_, 3><<<grid, 256, 0, (hipStream_t)stream>>>(a);) }
+    else { AD_DISPATCH_DTYPE(dtype, T_, upconv_gather_fwd_kernel<T_, 4><<<grid, 256, 0, (hipStream_t)stream>>>(a);) }
     AD_LAUNCH_CHECK("ad_upconv_gather_fwd");
     return AD_OK;
 }
 
-extern "C" int ad_upconv_gather_bwd_supported(int kxt) { return kxt >= 1 && kxt + 2 <= 16; }
+extern "C" int ad_upconv_gather_bwd_supported(int kxt) { return kxt >= 1 && kxt + 2 <= 16; }     // (kyt: GB_MAXKY, checked at the call)
 
 extern "C" int ad_upconv_gather_bwd(const void* g, void* dybank, const int* ryt, const float* wyt, int kyt, const int* cxt,
                                     const float* wxt, int kxt, int n, int h, int w, int oh, int ow, int c, int dtype,
@@ -661,6 +740,7 @@ extern "C" int ad_upconv_gather_bwd(const void* g, void* dybank, const int* ryt,
     AD_REQUIRE(g && dybank && ryt && wyt && cxt && wxt, "ad_upconv_gather_bwd: NULL operand");
     AD_REQUIRE(n > 0 && h > 0 && w > 0 && oh >= h && ow >= w && c > 0 && c % ept == 0 && kyt >= 1,
                "ad_upconv_gather_bwd: bad shape n=%d %dx%d <- %dx%d c=%d", n, h, w, oh, ow, c);
+    AD_REQUIRE(kyt <= GB_MAXKY, "ad_upconv_gather_bwd: %d vertical taps (at most %d)", kyt, GB_MAXKY);
     AD_REQUIRE(ad_upconv_gather_bwd_supported(kxt), "ad_upconv_gather_bwd: %d horizontal taps (at most 14)", kxt);
     AD_REQUIRE((long long)h * w * 9 * c < (1LL << 31) && (long long)oh * ow * c < (1LL << 31),
                "ad_upconv_gather_bwd: an image of more than 2^31 elements");

@@ -406,11 +406,15 @@ class UpconvTables:
         from . import resize_tables as rt
         fy, fx = rt.up_taps2(h, oh), rt.up_taps2(w, ow)
         self.ok = fy is not None and fx is not None
+        # the forward kernel's four-row window needs non-decreasing starts that advance by at most 2 over two output rows
+        self.ok = self.ok and all(bool((np.diff(t[0]) >= 0).all()) and (len(t[0]) < 3 or int((t[0][2:] - t[0][:-2]).max()) <= 2)
+                                  for t in (fy, fx))
         if not self.ok:
             return
+        self.window = 3 if len(fy[0]) < 3 or int((fy[0][2:] - fy[0][:-2]).max()) <= 1 else 4
         ty, tx = rt.aa_spans_transposed(h, oh), rt.aa_spans_transposed(w, ow)
         self.kyt, self.kxt = ty[1].shape[1], tx[1].shape[1]
-        self.ok = bool(_lib.load().ad_upconv_gather_bwd_supported(self.kxt))
+        self.ok = bool(_lib.load().ad_upconv_gather_bwd_supported(self.kxt)) and self.kyt <= 30
         self.h, self.w, self.oh, self.ow = h, w, oh, ow
         dev_i = lambda a: torch.tensor(np.ascontiguousarray(a, dtype=np.int32), device=device)
         dev_f = lambda a: torch.tensor(np.ascontiguousarray(a, dtype=np.float32), device=device)
@@ -455,7 +459,7 @@ def upconv_gather_fwd(ybank: torch.Tensor, bias: Optional[torch.Tensor], tab: Up
     out = torch.empty((n, tab.oh, tab.ow, c), dtype=ybank.dtype, device=ybank.device)
     with _timed("upconv_gather_fwd", 0.0, float((ybank.numel() + out.numel()) * ybank.element_size())):
         check(_lib.load().ad_upconv_gather_fwd(_p(ybank), _p(bias), _p(out), _p(tab.sy), _p(tab.wy), _p(tab.sx), _p(tab.wx),
-                                               n, h, w, tab.oh, tab.ow, c, int(relu), dt(ybank.dtype), _stream()),
+                                               tab.window, n, h, w, tab.oh, tab.ow, c, int(relu), dt(ybank.dtype), _stream()),
               "ad_upconv_gather_fwd")
     return out
 
