@@ -100,35 +100,44 @@ __global__ __launch_bounds__(PW_T, 2) void pw_gemm_kernel(PwArgs a) {
         const int mrow = m0 + mt * 16 + l15;
         xo[mt] = mrow < a.m ? (unsigned)((mrow * a.k + grp * KV) * TSZ) : PW_OOB;
     }
-    const int nkc = a.k / 64;
+    // Fragment stream: step (nb, ks) = the 4 pixel-row and 4 bank fragments of k-step ks of output block nb.  Two register
+    // sets alternate; the loads of step t + 2 are issued right after the MFMAs of step t, BEFORE the stores that end an
+    // output block, so that a wait for fragments never has the block's stores in front of it in the vmcnt queue (vmcnt
+    // retires in issue order: with the stores older than the next loads every block boundary cost a store round trip).
+    // Every step issues the same 8 loads and every block the same 8 / 16 stores, unconditionally (past the end the cursor
+    // re-reads the last step), which keeps hipcc's s_waitcnt vmcnt counts exact.
+    const int kpn = a.k / KSTEP;                         // k-steps per output block (even: k % 64 == 0)
+    frag xf0[4], bf0[4], xf1[4], bf1[4];
+    int inb = nb0, iks = 0;                              // cursor of the next step to issue
+#define PW_ISSUE(XF, BF)                                                                                         \
+    {                                                                                                            \
+        const unsigned koff_ = (unsigned)(iks * KSTEP * TSZ);                                                    \
+        const unsigned brow_ = (unsigned)(((iks * KSTEP / KV) * a.n + inb * 64) * 16);                           \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                          \
+            XF[t] = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(rsx, xo[t], koff_, 0));       \
+            BF[t] = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(rsb, bo0 + t * 256, brow_, 0)); \
+        }                                                                                                        \
+        if (++iks == kpn) { if (inb + 1 < nb1) { iks = 0; ++inb; } else { iks = kpn - 1; } }                     \
+    }
+#define PW_MMA(XF, BF)                                                                                           \
+    _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                             \
+        _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = P::mma(BF[nt], XF[mt], acc[mt][nt]);
+    // bank fragment of n-tile nt: Bp[ks*KSTEP / KV + grp][nb*64 + 16 nt + l15][KV]
+    const unsigned bo0 = (unsigned)(((grp * a.n) + l15) * 16);
+    PW_ISSUE(xf0, bf0)
+    PW_ISSUE(xf1, bf1)
     for (int nb = nb0; nb < nb1; ++nb) {
-        // bank fragment of n-tile nt: Bp[(kc*64 + ks*KSTEP) / KV + grp][nb*64 + 16 nt + l15][KV]
-        const unsigned bo = (unsigned)(((grp * a.n) + nb * 64 + l15) * 16);
         f32x4 acc[4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        frag xf[NKS][4], bf[NKS][4];
-#define PW_LOAD(KC)                                                                                              \
-    _Pragma("unroll") for (int ks = 0; ks < NKS; ++ks) {                                                         \
-        _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                          \
-            const unsigned koff_ = (unsigned)(((KC) * 64 + ks * KSTEP) * TSZ);                                   \
-            xf[ks][t] = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(rsx, xo[t], koff_, 0));   \
-            const unsigned brow_ = (unsigned)((((KC) * 64 + ks * KSTEP) / KV) * a.n * 16);                       \
-            bf[ks][t] = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(rsb, bo + t * 256, brow_, 0)); \
-        }                                                                                                        \
-    }
-        for (int kc = 0; kc < nkc; ++kc) {
-            PW_LOAD(kc)
-#pragma unroll
-            for (int ks = 0; ks < NKS; ++ks)
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = P::mma(bf[ks][nt], xf[ks][mt], acc[mt][nt]);
+        for (int ks = 0; ks < kpn; ks += 2) {
+            PW_MMA(xf0, bf0)
+            PW_ISSUE(xf0, bf0)
+            PW_MMA(xf1, bf1)
+            PW_ISSUE(xf1, bf1)
         }
-#undef PW_LOAD
         // lane holds channels nb*64 + 16 nt + 4 grp .. +3 of pixel m0 + 16 mt + l15
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
@@ -152,6 +161,8 @@ __global__ __launch_bounds__(PW_T, 2) void pw_gemm_kernel(PwArgs a) {
             }
         }
     }
+#undef PW_ISSUE
+#undef PW_MMA
 }
 
 // Bank operands from the fp32 Keras kernel W[3][3][Cin][Cout] (HWIO):
