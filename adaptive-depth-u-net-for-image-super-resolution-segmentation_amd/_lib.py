@@ -21,6 +21,9 @@ _vp, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 SIGNATURES = {
     "ad_version": (_i, []),
     "ad_last_error": (C.c_char_p, []),
+    "ad_device_cus": (_i, []),
+    "ad_set_option": (_i, [C.c_char_p, _i]),
+    "ad_get_option": (_i, [C.c_char_p]),
     "ad_cin_granule": (_i, [_i]),
     "ad_pad_channels": (_i, [_vp, _vp, _i64, _i, _i, _i, _vp]),
     "ad_conv3x3_pack": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp]),
@@ -124,6 +127,10 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
+    # A/B switches: the HOST reads the environment and sets the library's explicit options (ad_set_option)
+    for env, opt in (("ADUNET_NO_MAP1", b"no_map1"), ("ADUNET_NO_MAP4", b"no_map4"), ("ADUNET_NO_DGRAD_LN", b"no_dgrad_ln")):
+        if os.environ.get(env):
+            lib.ad_set_option(opt, 1)
     _lib = lib
     return lib
 

@@ -2,6 +2,7 @@
 #include "common.h"
 #include <stdarg.h>
 #include <stdio.h>
+#include <string.h>
 
 static thread_local char g_err[512] = "";
 
@@ -14,6 +15,38 @@ int ad_set_error(int code, const char* fmt, ...) {
 }
 
 extern "C" int ad_version(void) { return 1; }
+
+// ---- the only process-wide state of the library besides the last error string: the CU count of the device (read once)
+// and the options a caller sets explicitly
+int ad_num_cu() {
+    static int ncu = 0;
+    if (ncu == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v >= 64)
+            ncu = v / 64 * 64;          // whole groups of 8 XCDs x 8 (the XCD-aware work order deals tiles in such groups)
+        else
+            ncu = 256;                  // MI355X / MI350X
+    }
+    return ncu;
+}
+
+static int g_options[AD_OPT_COUNT] = {0, 0, 0};
+static const char* const g_option_names[AD_OPT_COUNT] = {"no_map1", "no_map4", "no_dgrad_ln"};
+int ad_option(int which) { return which >= 0 && which < AD_OPT_COUNT ? g_options[which] : 0; }
+
+extern "C" int ad_set_option(const char* name, int value) {
+    for (int i = 0; i < AD_OPT_COUNT; ++i)
+        if (name && strcmp(name, g_option_names[i]) == 0) { g_options[i] = value; return AD_OK; }
+    return ad_set_error(AD_ERR_ARG, "ad_set_option: unknown option '%s' (no_map1, no_map4, no_dgrad_ln)", name ? name : "(null)");
+}
+
+extern "C" int ad_get_option(const char* name) {
+    for (int i = 0; i < AD_OPT_COUNT; ++i)
+        if (name && strcmp(name, g_option_names[i]) == 0) return g_options[i];
+    return -1;
+}
+
+extern "C" int ad_device_cus(void) { return ad_num_cu(); }
 extern "C" const char* ad_last_error(void) { return g_err; }
 extern "C" int ad_cin_granule(int dtype) { return ad_is_half(dtype) ? 32 : 16; }
 

@@ -16,6 +16,11 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 
 int ad_set_error(int code, const char* fmt, ...);
+// Compute units of the current device, queried once (api.hip): the persistent kernels launch one workgroup per CU.
+int ad_num_cu();
+// Explicit library options (ad_set_option, include/adunet.h): the library itself never reads the environment.
+enum { AD_OPT_NO_MAP1 = 0, AD_OPT_NO_MAP4 = 1, AD_OPT_NO_DGRAD_LN = 2, AD_OPT_COUNT = 3 };
+int ad_option(int which);
 
 static inline bool ad_is_half(int dtype) { return dtype == AD_BF16 || dtype == AD_F16; }   // 16-bit storage types
 static inline bool ad_dtype_ok(int dtype) { return dtype == AD_F32 || dtype == AD_BF16 || dtype == AD_F16; }

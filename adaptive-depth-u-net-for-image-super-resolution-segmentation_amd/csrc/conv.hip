@@ -41,7 +41,7 @@ constexpr int TM = 256;         // pixels per workgroup tile
 constexpr int BN = 64;          // output channels per workgroup
 constexpr int WSLOTS = 9 * 4 * BN / 256;   // 16-byte weight slots per thread and channel chunk (= 9)
 constexpr int WT_BYTES = 9 * 4 * BN * 16;  // one channel chunk of packed weights, all taps
-constexpr int NUM_CU = 256;
+#define NUM_CU ad_num_cu()      // host code only: compute units of the device, queried once (api.hip)
 
 struct Geo {
     int lti, lth, ltw;  // log2 of images / rows / cols per tile
@@ -637,7 +637,7 @@ struct WsOrder {
 };
 __device__ __forceinline__ WsOrder ws_order(int ntiles, int nblk) {
     const int b = blockIdx.x, xcd = b & 7, r = b >> 3;
-    const int tpx = (NUM_CU / 8) / nblk;            // tiles per XCD and round (nblk divides 32: launcher)
+    const int tpx = (int)(gridDim.x >> 3) / nblk;   // tiles per XCD and round: one workgroup per CU, nblk divides CUs / 8 (launcher)
     WsOrder o;
     o.nb = r % nblk;
     o.slot0 = xcd * tpx + r / nblk;
@@ -2512,8 +2512,7 @@ int launch_fwd(ConvArgs a, void* ws, size_t ws_bytes, hipStream_t s);
 
 // conv3x3_map1_kernel: 1x1 maps, four chunks per step group, the concat boundary on a chunk, the output split on 16-channel tiles
 static bool map1_ok(int n, int h, int w, int c1, int c2, int cout, int cy1) {
-    static const bool off = getenv("ADUNET_NO_MAP1") != nullptr;      // A/B switch
-    if (off) return false;
+    if (ad_option(AD_OPT_NO_MAP1)) return false;                      // A/B switch (ad_set_option)
     const long long in_bytes = (long long)n * (c1 > c2 ? c1 : c2) * 2;        // 32-bit offsets inside the kernel
     // small batches of 1x1 maps only (a bottleneck level): every workgroup re-reads its 64 images' activations from
     // L2, which is the right trade for a few hundred images and the wrong one for the 1x1 GEMM over 262 144 "images"
@@ -2524,8 +2523,7 @@ static bool map1_ok(int n, int h, int w, int c1, int c2, int cout, int cy1) {
 
 // conv3x3_map4_kernel: 4x4 maps, whole 128-channel phases, the concat boundary and the output split on 16-channel tiles
 static bool map4_ok(int n, int h, int w, int c1, int c2, int cout, int cy1) {
-    static const bool off = getenv("ADUNET_NO_MAP4") != nullptr;      // A/B switch
-    if (off) return false;
+    if (ad_option(AD_OPT_NO_MAP4)) return false;                      // A/B switch (ad_set_option)
     const long long in_bytes = (long long)n * 16 * (c1 > c2 ? c1 : c2) * 2;   // 32-bit offsets inside the kernel
     return h == 4 && w == 4 && n >= 1 && in_bytes <= WR_MAX_BYTES && (c1 + c2) % 128 == 0 && c1 % 128 == 0 && c1 + c2 <= 8192 &&
            cout % 16 == 0 && cout <= 8192 && cy1 % 16 == 0;
@@ -2896,7 +2894,7 @@ extern "C" int ad_conv3x3_dgrad_relu(const void* dz, int c1, const void* w_dgrad
 // ---- dgrad with the producer's LayerNorm + ReLU backward fused (conv_block's second conv, Super_resolution/code/
 // train_adaptive_unet.py:200-210: its input is the first LayerNorm's activation)
 extern "C" int ad_conv3x3_dgrad_ln_bwd_is_fused(int n, int h, int w, int c1, int cout, int dtype) {
-    static const bool off = getenv("ADUNET_NO_DGRAD_LN") != nullptr;      // A/B switch
+    const bool off = ad_option(AD_OPT_NO_DGRAD_LN) != 0;                  // A/B switch (ad_set_option)
     if (off || !ad_is_half(dtype) || n <= 0 || h <= 0 || w <= 0 || c1 <= 0 || cout != BN) return 0;
     if (images_per_launch(n, h, w, c1, 0, cout, false, false) < n) return 0;        // image runs: plain path
     return fwd_ws_kind(n, h, w, c1, 0, cout, false) == 1;      // weights-resident kernel (contraction over 64 channels)

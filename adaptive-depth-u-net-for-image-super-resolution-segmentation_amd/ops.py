@@ -390,7 +390,7 @@ def resample(x: torch.Tensor, tab: ResampleTables, out: Optional[torch.Tensor] =
     if out is None:
         assert not accumulate
         out = torch.empty((n, tab.oh, tab.ow, c), dtype=x.dtype, device=x.device)
-    with _timed("resample"):
+    with _timed("resample", 0.0, float((x.numel() + out.numel() * (2 if accumulate else 1)) * x.element_size())):
         check(_lib.load().ad_resample(_p(x), _p(out), _p(tab.sy), _p(tab.wy), tab.ky, _p(tab.sx), _p(tab.wx), tab.kx,
                                       n, h, w, tab.oh, tab.ow, c, int(accumulate), dt(x.dtype), _stream()), "ad_resample")
     return out
@@ -505,7 +505,7 @@ def resample_ln_bwd(d_low, tab: ResampleTables, dskip, z, mean, rstd, gamma, bet
     dz = torch.empty_like(z)
     lib = _lib.load()
     ws.ensure(lib.ad_resample_ln_bwd_ws_bytes(n, oh, ow, c, dt(z.dtype)))
-    with _timed("resample_ln_bwd"):
+    with _timed("resample_ln_bwd", 0.0, float((d_low.numel() + 3 * z.numel()) * z.element_size())):
         check(lib.ad_resample_ln_bwd(_p(d_low), _p(dskip), _p(z), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dz), _p(dgamma),
                                      _p(dbeta), _p(dbias), _p(tab.sy), _p(tab.wy), tab.ky, _p(tab.sx), _p(tab.wx), tab.kx,
                                      n, h, w, oh, ow, c, ws.ptr, ws.nbytes, dt(z.dtype), _stream()), "ad_resample_ln_bwd")
@@ -522,7 +522,7 @@ def head_fwd(xh, w, b, inp, target, ws: Workspace, loss_kind: int = 0, eps: floa
         sqerr = torch.empty(n, dtype=torch.float32, device=xh.device)
     lib = _lib.load()
     ws.ensure(lib.ad_head_ws_bytes(n, ch))
-    with _timed("head_fwd"):
+    with _timed("head_fwd", 0.0, float(xh.numel() * xh.element_size() + (3 if target is not None else 2) * out.numel() * 4)):
         check(lib.ad_head_fwd(_p(xh), _p(w), _p(b), _p(inp), _p(target), _p(out), _p(stats), _p(sqerr), n, h * wd, ch,
                               loss_kind, eps, ws.ptr, ws.nbytes, dt(xh.dtype), _stream()), "ad_head_fwd")
     return out, stats, sqerr
@@ -548,7 +548,7 @@ def head_ln_bwd(xh, w, b, inp, target, z, mean, rstd, gamma, beta, dw, db, dgamm
     dz = torch.empty_like(z)
     lib = _lib.load()
     ws.ensure(lib.ad_head_ln_bwd_ws_bytes(n, ch))
-    with _timed("head_ln_bwd"):
+    with _timed("head_ln_bwd", 0.0, float(3 * xh.numel() * xh.element_size() + 2 * inp.numel() * 4)):
         check(lib.ad_head_ln_bwd(_p(xh), _p(w), _p(b), _p(inp), _p(target), _p(z), _p(mean), _p(rstd), _p(gamma), _p(beta),
                                  _p(dz), _p(dw), _p(db), _p(dgamma), _p(dbeta), _p(dbias_conv), n, h * wd, ch, loss_kind, eps,
                                  grad_scale, _p(loss_scale), ws.ptr, ws.nbytes, dt(xh.dtype), _stream()), "ad_head_ln_bwd")
@@ -556,7 +556,7 @@ def head_ln_bwd(xh, w, b, inp, target, z, mean, rstd, gamma, beta, dw, db, dgamm
 
 
 def adam_step(p, g, m, v, step: int, lr=1e-4, b1=0.9, b2=0.999, eps=1e-7, gscale: float = 1.0):
-    with _timed("adam_step"):
+    with _timed("adam_step", 0.0, 28.0 * p.numel()):
         check(_lib.load().ad_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, b1, b2, eps, step, gscale, _stream()),
               "ad_adam_step")
 
@@ -567,7 +567,7 @@ def adam_alpha(lr: float, b1: float, b2: float, step: int) -> float:
 
 def adam_step_dev(p, g, m, v, alpha_dev: torch.Tensor, b1=0.9, b2=0.999, eps=1e-7, gscale: float = 1.0):
     """Adam update whose step-dependent factor is read from device memory (hipGraph-replayable)."""
-    with _timed("adam_step"):
+    with _timed("adam_step", 0.0, 28.0 * p.numel()):
         check(_lib.load().ad_adam_step_dev(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(alpha_dev), b1, b2, eps, gscale,
                                            _stream()), "ad_adam_step_dev")
 
@@ -585,7 +585,7 @@ def loss_scale_update(state: torch.Tensor, growth_steps: int):
 
 def adam_step_scaled(p, g, m, v, lr_dev: torch.Tensor, state: torch.Tensor, b1=0.9, b2=0.999, eps=1e-7, gscale: float = 1.0):
     """Adam under a device-resident loss scaler: skipped on overflow, gradients unscaled, applied-step bias correction."""
-    with _timed("adam_step"):
+    with _timed("adam_step", 0.0, 28.0 * p.numel()):
         check(_lib.load().ad_adam_step_scaled(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(lr_dev), b1, b2, eps, gscale,
                                               _p(state), _stream()), "ad_adam_step_scaled")
 

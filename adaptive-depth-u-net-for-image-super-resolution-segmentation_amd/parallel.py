@@ -91,17 +91,27 @@ class DataParallel:
         dist.broadcast(uid, src=0, group=group)
         raw = bytes(uid.cpu().tolist())
         comm = C.c_void_p()
-        torch.cuda.synchronize(device)
-        _lib.check(lib.ad_comm_create(raw, dist.get_rank(group), self.world, C.byref(comm)), "ad_comm_create")
+        # ncclCommInitRank binds the communicator to the CURRENT HIP device: make that the model's device, whatever the
+        # caller's current device is
+        with torch.cuda.device(device):
+            torch.cuda.synchronize(device)
+            _lib.check(lib.ad_comm_create(raw, dist.get_rank(group), self.world, C.byref(comm)), "ad_comm_create")
         self._lib, self._check = lib, _lib.check
         return comm
 
+    def __del__(self):          # error paths that never reach close(): do not leak the RCCL communicator
+        try:
+            self.close()
+        except Exception:
+            pass
+
     def close(self):
         """Destroy the native communicator (after the last step, before the process group goes away)."""
-        if self._native is not None:
-            torch.cuda.synchronize()
-            self._check(self._lib.ad_comm_destroy(self._native), "ad_comm_destroy")
-            self._native = None
+        if getattr(self, "_native", None) is not None:
+            comm, self._native = self._native, None
+            with torch.cuda.device(self.model.G.device):
+                torch.cuda.synchronize()
+                self._check(self._lib.ad_comm_destroy(comm), "ad_comm_destroy")
 
     def _launch(self, lo: int, hi: int):
         g = self.model.G[lo:hi]
@@ -109,8 +119,9 @@ class DataParallel:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             self._comm.wait_event(ev)
-            self._check(self._lib.ad_allreduce_bucket(self._native, g.data_ptr(), hi - lo, self._comm.cuda_stream),
-                        "ad_allreduce_bucket")
+            with torch.cuda.device(g.device):
+                self._check(self._lib.ad_allreduce_bucket(self._native, g.data_ptr(), hi - lo, self._comm.cuda_stream),
+                            "ad_allreduce_bucket")
             done = torch.cuda.Event()
             done.record(self._comm)
             self._works.append(_EventWork(done))

@@ -91,69 +91,78 @@ def degrade_image(image: np.ndarray, scale: float, output_size: int) -> np.ndarr
     return up.astype(np.float32)
 
 
-def random_patch(image: np.ndarray, patch_size: int, *, rng: np.random.Generator | None = None) -> np.ndarray:
-    """pipeline.py:97-118."""
+def _require_rgb_and_size(image: np.ndarray, patch_size: int) -> None:
+    """Argument checks shared by the croppers; messages are the reference's (shared/pipeline.py:104-107,150-153)."""
     if patch_size <= 0:
         raise ValueError("patch_size must be positive.")
     if image.ndim != 3 or image.shape[-1] != 3:
         raise ValueError("image must be an HxWx3 RGB array.")
-    height, width = image.shape[:2]
-    if height < patch_size or width < patch_size:
+
+
+def _slack(image: np.ndarray, patch_size: int) -> Tuple[int, int]:
+    """Free room (rows, columns) for a patch_size crop; ValueError when the image is smaller than the crop."""
+    room = (image.shape[0] - patch_size, image.shape[1] - patch_size)
+    if min(room) < 0:
         raise ValueError("patch_size exceeds image dimensions.")
-    generator = rng or np.random.default_rng()
-    max_y, max_x = height - patch_size, width - patch_size
-    top = int(generator.integers(0, max_y + 1)) if max_y > 0 else 0
-    left = int(generator.integers(0, max_x + 1)) if max_x > 0 else 0
-    return image[top:top + patch_size, left:left + patch_size, :]
+    return room
+
+
+def random_patch(image: np.ndarray, patch_size: int, *, rng: np.random.Generator | None = None) -> np.ndarray:
+    """One uniformly placed crop (a view).  Contract of shared/pipeline.py:97-118: the generator is consulted once per
+    axis that has room, rows before columns (what makes a seeded stream reproduce the reference's crop sequence)."""
+    _require_rgb_and_size(image, patch_size)
+    room = _slack(image, patch_size)
+    draw = (rng if rng is not None else np.random.default_rng()).integers
+    top, left = (int(draw(0, r + 1)) if r > 0 else 0 for r in room)
+    return image[top:top + patch_size, left:left + patch_size]
 
 
 def random_patches(image: np.ndarray, patch_size: int, count: int, *, rng: np.random.Generator | None = None) -> np.ndarray:
-    """pipeline.py:121-136."""
+    """`count` crops of one image stacked on a new leading axis (shared/pipeline.py:121-136)."""
     if count <= 0:
         raise ValueError("count must be positive.")
-    generator = rng or np.random.default_rng()
-    return np.stack([random_patch(image, patch_size, rng=generator) for _ in range(count)], axis=0)
+    source = rng if rng is not None else np.random.default_rng()
+    out = np.empty((count, patch_size, patch_size, 3) if patch_size > 0 else (count, 0, 0, 3), dtype=image.dtype)
+    for k in range(count):
+        out[k] = random_patch(image, patch_size, rng=source)
+    return out
 
 
 def grid_patches(image: np.ndarray, patch_size: int, *, stride: int | None = None, drop_remainder: bool = False) -> np.ndarray:
-    """pipeline.py:139-174 -- regular grid; bottom-right aligned patch if the stride skipped everything."""
-    if patch_size <= 0:
-        raise ValueError("patch_size must be positive.")
-    if image.ndim != 3 or image.shape[-1] != 3:
-        raise ValueError("image must be an HxWx3 RGB array.")
-    stride = stride or patch_size
-    if stride <= 0:
+    """Crops on a regular grid, row-major (shared/pipeline.py:139-174).  Every image that passes the size check yields
+    the crop at (0, 0), so the reference's bottom-right fallback for an empty grid (`drop_remainder=False`) never
+    triggers; the argument is accepted for signature compatibility."""
+    _require_rgb_and_size(image, patch_size)
+    step = stride if stride else patch_size
+    if step <= 0:
         raise ValueError("stride must be positive.")
-    height, width = image.shape[:2]
-    if height < patch_size or width < patch_size:
-        raise ValueError("patch_size exceeds image dimensions.")
-    patches = [image[t:t + patch_size, l:l + patch_size, :]
-               for t in range(0, height - patch_size + 1, stride)
-               for l in range(0, width - patch_size + 1, stride)]
-    if not patches and not drop_remainder:
-        patches.append(image[-patch_size:, -patch_size:, :])
-    return np.stack(patches, axis=0) if patches else np.empty((0, patch_size, patch_size, 3), dtype=image.dtype)
+    room_y, room_x = _slack(image, patch_size)
+    # all windows as a strided view [rows, cols, 3, P, P], thinned to the grid, then copied into [count, P, P, 3]
+    windows = np.lib.stride_tricks.sliding_window_view(image, (patch_size, patch_size), axis=(0, 1))[::step, ::step]
+    assert windows.shape[:2] == (room_y // step + 1, room_x // step + 1)
+    return np.ascontiguousarray(np.moveaxis(windows, 2, -1).reshape(-1, patch_size, patch_size, 3))
 
 
 def _iter_random_patch_pairs(hr_files, patch_size, patches_per_image, scale, seed) -> Iterator[Tuple[np.ndarray, np.ndarray]]:
-    """pipeline.py:177-195 -- infinite stream; one rng drives the file shuffle and the crops."""
+    """Endless (lr, hr) stream of shared/pipeline.py:177-195: ONE seeded generator orders each pass over the files and
+    then places that pass's crops, `patches_per_image` per file, in file order."""
+    if patches_per_image <= 0:
+        raise ValueError("count must be positive.")
+    files = list(hr_files)
     rng = np.random.default_rng(seed)
-    hr_files = list(hr_files)
-    if not hr_files:
-        return
-    while True:
-        rng.shuffle(hr_files)
-        for path in hr_files:
-            hr_image = load_rgb_image_full(path)
-            for hr_patch in random_patches(hr_image, patch_size, count=patches_per_image, rng=rng):
+    while files:
+        rng.shuffle(files)
+        for path in files:
+            image = load_rgb_image_full(path)
+            for _ in range(patches_per_image):
+                hr_patch = random_patch(image, patch_size, rng=rng)
                 yield degrade_image(hr_patch, scale, patch_size), hr_patch
 
 
 def _iter_grid_patch_pairs(hr_files, patch_size, stride, scale) -> Iterator[Tuple[np.ndarray, np.ndarray]]:
-    """pipeline.py:198-211."""
+    """Finite evaluation stream (shared/pipeline.py:198-211): files in the given order, grid crops row-major."""
     for path in hr_files:
-        hr_patches = grid_patches(load_rgb_image_full(path), patch_size, stride=stride, drop_remainder=False)
-        for hr_patch in hr_patches:
+        for hr_patch in grid_patches(load_rgb_image_full(path), patch_size, stride=stride):
             yield degrade_image(hr_patch, scale, patch_size), hr_patch
 
 
@@ -223,24 +232,27 @@ def make_eval_patch_dataset(hr_files: Sequence[str], patch_size: int, scale: flo
 
 
 def split_indices(n_samples: int, train: float, val: float, test: float, seed: int):
-    """pipeline.py:291-317."""
+    """Seeded train / val / test partition of range(n_samples) (shared/pipeline.py:291-317): fractions are normalised by
+    their sum, counts rounded, and (where the sample count allows) the train part leaves room for one validation and one
+    test sample, the validation part for one test sample."""
     if not 0 < train < 1:
         raise ValueError("Train fraction should be between 0 and 1.")
-    if not 0 <= val < 1 or not 0 <= test < 1:
+    if not (0 <= val < 1 and 0 <= test < 1):
         raise ValueError("Val/test fractions should be between 0 and 1.")
-    total = train + val + test
-    if total <= 0:
+    whole = train + val + test
+    if whole <= 0:
         raise ValueError("Fractions must sum to a positive value.")
-    rng = np.random.default_rng(seed)
-    indices = np.arange(n_samples)
-    rng.shuffle(indices)
-    train_count = int(round(n_samples * train / total))
-    val_count = int(round(n_samples * val / total))
-    train_count = min(train_count, n_samples - 2) if n_samples > 2 else train_count
-    val_count = min(val_count, n_samples - train_count - 1) if n_samples > (train_count + 1) else val_count
-    if train_count <= 0:
+    order = np.arange(n_samples)
+    np.random.default_rng(seed).shuffle(order)
+    n_train, n_val = (int(round(n_samples * part / whole)) for part in (train, val))
+    if n_samples > 2:
+        n_train = min(n_train, n_samples - 2)
+    if n_samples > n_train + 1:
+        n_val = min(n_val, n_samples - n_train - 1)
+    if n_train <= 0:
         raise ValueError("Train split is empty; adjust fractions.")
-    return indices[:train_count], indices[train_count:train_count + val_count], indices[train_count + val_count:]
+    first, second, third = np.split(order, [n_train, n_train + n_val])
+    return first, second, third
 
 
 # ----------------------------------------------------------------------------- MI355X feed path

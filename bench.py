@@ -59,26 +59,28 @@ def kernel_source_stamp():
     kernels it was measured on are the ones in the tree."""
     import hashlib
     h = hashlib.sha256()
-    csrc = os.path.join(ROOT, "adaptive-depth-u-net-for-image-super-resolution-segmentation_amd", "csrc")
-    for name in ("conv.hip", "common.h"):
-        with open(os.path.join(csrc, name), "rb") as f:
+    pkg = os.path.join(ROOT, "adaptive-depth-u-net-for-image-super-resolution-segmentation_amd")
+    # every kernel source of the step, plus the build recipe (compiler flags change the traffic of the same source)
+    for name in ("csrc/common.h", "csrc/conv.hip", "csrc/upconv.hip", "csrc/norm.hip", "csrc/resize.hip", "csrc/head.hip",
+                 "csrc/optim.hip", "build.py"):
+        with open(os.path.join(pkg, name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(workload, dtype, batch):
-    """HBM bytes per launch of the conv3x3_fwd family from the committed rocprofv3 PMC passes (profiles/README.md).
-    PMC counters need their own rocprofv3 runs, so the figure is read from the newest profiles/r*_pmc_traffic.json; it is
-    None when that file was measured on another configuration or on other kernel sources (stale)."""
+def pmc_record(workload, dtype, batch):
+    """The committed rocprofv3 PMC passes (profiles/README.md) of the newest round, or None when they were measured on
+    another configuration or on other kernel sources (stale).  PMC counters need their own rocprofv3 runs, so the figures
+    cannot be taken by the run that prints them; the sha256 stamp ties them to the sources in the tree."""
     import glob
-    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    import re
+    cands = glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json"))
+    cands.sort(key=lambda p: int(re.search(r"r(\d+)_pmc_traffic", os.path.basename(p)).group(1)))     # r10 after r02
     if (workload, dtype, batch) != ("K2p", "bf16", 64) or not cands:
         return None
     with open(cands[-1]) as f:
         rec = json.load(f)
-    if rec.get("kernel_source_stamp") != kernel_source_stamp():
-        return None
-    return rec["families"]["conv3x3_fwd"]["hbm_bytes_per_launch"]
+    return rec if rec.get("kernel_source_stamp") == kernel_source_stamp() else None
 
 
 def cpu_baseline(scale, depth, patch, workload):
@@ -179,6 +181,10 @@ def main():
     ap.add_argument("--no-micro", action="store_true", help="skip the 64->64 @256x256 N=32 micro-kernel measurement")
     ap.add_argument("--breakdown", action="store_true", help="print the per-op-family time table to stderr")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend of the N > 1 run: nccl = RCCL over xGMI, one rank per GPU (the driver's "
+                         "scaling run); gloo = a rehearsal of the same rank logic on a box with fewer GPUs than ranks (the "
+                         "ranks share the visible GPUs, gradients travel through host memory: NOT a scaling measurement)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -191,15 +197,20 @@ def main():
         raise SystemExit(launch_ranks(args.gpus))
     if world != args.gpus:
         args.gpus = world
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # one rank per GPU; under --backend gloo the ranks may outnumber the GPUs and share them round-robin
+    dev_index = local_rank if args.backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
 
     import torch.distributed as dist
     use_dist = "RANK" in os.environ          # launched by torch.distributed.run (also exercised at world size 1)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from adunet_amd import ops
     from adunet_amd.model import Adam, build_losses_and_metrics, build_super_resolution_unet
@@ -298,21 +309,58 @@ def main():
             # dgrad launches whose epilogue is the LayerNorm / ReLU backward of the layer below (z, mean, rstd streamed in,
             # ~900 VALU instructions per tile and wave; replaces a separate 1.6 GB layernorm_relu_bwd pass)
             "dgrad_ln_bwd_fused": family(["conv3x3_dgrad_ln_bwd"]),
+            # the decoder's up-resize -> Conv3x3 pairs in their factored form (csrc/upconv.hip): the 1x1 bank GEMMs at the LOW
+            # resolution (Y = x B, dx = dY B^T, dB = x^T dY).  GFLOP = what these launches EXECUTE (1 / ratio^2 of the 3x3
+            # convolution they stand for); the interpolating gathers beside them are HBM-bound and listed in `hbm_ops`
+            "upconv_bank_gemms": family(["pw_gemm", "pw_wgrad"]),
         }
         conv_ms = sum(f["ms_per_step"] for f in fam.values())
         conv_gf = sum(f["gflop_per_step"] for f in fam.values())
         total_ms = sum(v[1] for v in summ.values()) * per_step
-        n_launch, ms = summ["conv3x3_fwd"]
-        dom = fam["fwd_dgrad"]
+        for f in fam.values():
+            f["share_of_step"] = f["ms_per_step"] / total_ms if total_ms > 0 else None
+        fam_kernels = {
+            "fwd_dgrad": "conv3x3_fwd_wres_kernel / conv3x3_fwd_ws_kernel / conv3x3_map4_kernel / conv3x3_map1_kernel "
+                         "(conv3x3_fwd_kernel + splitk_finalize_kernel for other shapes) with the plain bias / ReLU epilogue",
+            "fused_ln_fwd": "conv3x3_fwd_wres_kernel<.,2> / conv3x3_fwd_ws_kernel<.,2> (Conv2D -> LayerNorm -> ReLU in one "
+                            "launch) and conv3x3_c3_fwd_kernel (first layer)",
+            "wgrad": "conv3x3_wgrad_ws_kernel / conv3x3_wgrad_kernel + wgrad_reduce_kernel, conv3x3_c3_wgrad_kernel",
+            "dgrad_relu_fused": "conv3x3_fwd_wres_kernel<.,3> (dgrad + ReLU-grad of the up-conv)",
+            "dgrad_ln_bwd_fused": "conv3x3_fwd_wres_kernel<.,4> (dgrad + LayerNorm / ReLU backward of the layer below)",
+            "upconv_bank_gemms": "pw_gemm_kernel, pw_wgrad_kernel + pw_wgrad_reduce_kernel (1x1 bank of the factored up-conv)",
+        }
+        dom_name = max(fam, key=lambda k: fam[k]["ms_per_step"])
+        dom = fam[dom_name]
+        dom_ops = {"fwd_dgrad": ["conv3x3_fwd"], "fused_ln_fwd": ["conv3x3_ln_relu_fwd", "conv3x3_c3_ln_relu_fwd"],
+                   "wgrad": ["conv3x3_wgrad", "conv3x3_c3_wgrad"], "dgrad_relu_fused": ["conv3x3_dgrad_relu"],
+                   "dgrad_ln_bwd_fused": ["conv3x3_dgrad_ln_bwd"], "upconv_bank_gemms": ["pw_gemm", "pw_wgrad"]}[dom_name]
+        n_launch = sum(summ.get(k, (0, 0.0))[0] for k in dom_ops)
+        ms = sum(summ.get(k, (0, 0.0))[1] for k in dom_ops)
+        dom_bytes = sum(timer.nbytes(k) for k in dom_ops)
+        # HBM-bound ops of the step, each with the bytes it must move (operands once) and the rate it moves them at
+        hbm_ops = {}
+        for k in ("upconv_gather_fwd", "upconv_gather_bwd", "resample", "resample_ln_bwd", "head_fwd", "head_ln_bwd", "adam_step"):
+            if k in summ and timer.nbytes(k) > 0:
+                cnt, t_ms = summ[k]
+                hbm_ops[k] = {"launches_per_step": cnt * per_step, "ms_per_step": t_ms * per_step,
+                              "algorithmic_gb_per_step": timer.nbytes(k) * per_step / 1e9,
+                              "tb_per_s": timer.nbytes(k) / t_ms / 1e9, "frac_of_8_tb_per_s": timer.nbytes(k) / t_ms / 1e9 / 8.0}
         if args.breakdown:
             print(f"{'op family':<26}{'launches/step':>14}{'ms/step':>10}{'share':>8}", file=sys.stderr)
             for k, (cnt, t_ms) in sorted(summ.items(), key=lambda kv: -kv[1][1]):
                 print(f"{k:<26}{cnt * per_step:>14.1f}{t_ms * per_step:>10.3f}{t_ms * per_step / total_ms:>8.1%}", file=sys.stderr)
             print(f"{'(sum of op events)':<26}{'':>14}{total_ms:>10.3f}", file=sys.stderr)
         img_s = batch * world * args.steps / elapsed
+        ms_step = elapsed * 1000.0 / args.steps
+        pmc = pmc_record(args.workload, args.dtype, batch)
+        pmc_fam = {"fwd_dgrad": "conv3x3_fwd", "fused_ln_fwd": "conv3x3_ln_relu_fwd", "wgrad": "conv3x3_wgrad",
+                   "dgrad_relu_fused": "conv3x3_dgrad_relu", "dgrad_ln_bwd_fused": "conv3x3_dgrad_ln_bwd",
+                   "upconv_bank_gemms": "upconv_bank_gemms"}[dom_name]
+        traffic = pmc["families"][pmc_fam]["hbm_bytes_per_launch"] if pmc and pmc_fam in pmc.get("families", {}) else None
+        hbm_gb = pmc.get("hbm_bytes_per_step", 0.0) / 1e9 if pmc and pmc.get("hbm_bytes_per_step") else None
         line = {
             "metric": METRIC, "value": img_s, "unit": "images/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed * 1000.0 / args.steps, "higher_is_better": True,
+            "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.workload}: SR U-Net scale {scale} depth {depth} patch {patch} train step",
                        "global_batch": batch * world, "per_gpu_batch": batch, "params": model.count_params(),
@@ -320,28 +368,40 @@ def main():
                        "conv_gflop_per_image_step": f_step / 1e9, "model_tflops": img_s * f_step / world / 1e12,
                        "final_loss": float(last_loss), "final_psnr": float(last_psnr)},
             "roofline": {"bound": "mfma",
-                         "kernel": "forward-conv / dgrad family: conv3x3_fwd_wres_kernel, conv3x3_fwd_ws_kernel, "
-                                   "conv3x3_map4_kernel, conv3x3_map1_kernel (conv3x3_fwd_kernel + splitk_finalize_kernel "
-                                   "for other shapes), launches with the plain bias / ReLU epilogue only; launches that carry "
-                                   "a LayerNorm forward, a ReLU-grad or (bf16, since r02: the four full-resolution 64->64 "
-                                   "dgrads, this family's fastest members until then) a LayerNorm backward in their epilogue "
-                                   "are the other entries of `families`",
+                         # the conv kernel family with the largest share of the step (`families` has them all, each with its
+                         # share); FLOPs as launched minus zero-padded channels, time = HIP events on the launch stream
+                         "family": dom_name, "kernel": fam_kernels[dom_name],
                          "achieved": dom["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": dom["frac"],
-                         "traffic": pmc_traffic(args.workload, args.dtype, batch),
-                         "algorithmic_bytes_per_launch": timer.nbytes("conv3x3_fwd") / n_launch,
-                         "launches_per_step": n_launch * per_step, "avg_launch_ms": ms / n_launch,
-                         "gflop_per_launch": dom["gflop_per_step"] / (n_launch * per_step),
-                         # the whole truth next to the dominant family: SURVEY 8d's step-level figure (every HBM-bound op
-                         # included: images/s x conv FLOPs per image-step / peak, per GPU) and every conv kernel family
+                         "traffic": traffic,
+                         "algorithmic_bytes_per_launch": dom_bytes / n_launch if n_launch else None,
+                         "launches_per_step": n_launch * per_step, "avg_launch_ms": ms / n_launch if n_launch else None,
+                         "gflop_per_launch": dom["gflop_per_step"] / (n_launch * per_step) if n_launch else None,
+                         "share_of_step": dom["share_of_step"],
+                         # SURVEY 8d's step-level figure: images/s x the REFERENCE GRAPH's conv FLOPs per image-step / peak
+                         # (every HBM-bound op included; the factored up-convs execute fewer FLOPs than the graph's 3x3
+                         # convolutions they replace: `executed_gflop_per_step` is what the MFMA launches really did)
                          "frac_step": img_s / world * f_step / 1e12 / PEAK_BF16_TFLOPS,
+                         "algorithmic_gflop_per_step": f_step * batch / 1e9,
+                         "executed_gflop_per_step": conv_gf,
                          "frac_all_conv_kernels": conv_gf / conv_ms / PEAK_BF16_TFLOPS if conv_ms > 0 else None,
+                         # HBM side of the same step (stamped PMC passes, profiles/): GB per step through the fabric and
+                         # that divided by the step time and 8 TB/s
+                         "hbm_gb_per_step": hbm_gb,
+                         "hbm_frac": hbm_gb / (ms_step / 1e3) / 8000.0 if hbm_gb else None,
                          "families": fam,
+                         "hbm_ops": hbm_ops,
                          "non_conv_ms_per_step": total_ms - conv_ms,
                          "timing": ("HIP events around every launch of %d eager steps run right after the graph-replayed "
                                     "timed region" % timed_steps) if graphed else "HIP events inside the timed region"},
         }
         if use_dist:
-            line["rccl_ranks"] = dist.get_world_size()
+            line["ranks"] = dist.get_world_size()
+            line["dist_backend"] = args.backend
+            if args.backend == "nccl":
+                line["rccl_ranks"] = dist.get_world_size()
+            else:
+                line["note"] = ("gloo rehearsal: %d ranks on %d GPU(s), gradients exchanged through host memory; value is NOT "
+                                "a scaling measurement" % (world, torch.cuda.device_count()))
             line["exposed_comm_ms_per_step"] = exposed_ms
             line["exchange"] = "ad_allreduce_bucket" if model._dp._native is not None else "torch.distributed.all_reduce"
         if world == 1 and args.dtype == "bf16" and not args.no_micro:
@@ -350,11 +410,13 @@ def main():
             line["cpu_baseline"] = cpu_baseline(scale, depth, patch, args.workload)
         print(json.dumps(line), flush=True)
     if use_dist:
-        model._dp.close()
-        del step_fn, model            # graphs and side streams go before the communicator they reference
-        torch.cuda.synchronize()
-        dist.barrier()
-        dist.destroy_process_group()
+        try:
+            model._dp.close()
+            del step_fn, model            # graphs and side streams go before the communicator they reference
+            torch.cuda.synchronize()
+            dist.barrier()
+        finally:
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -14,8 +14,10 @@
  *    half storage: the reference's mixed_float16 policy).
  *    Parameters, gradients, statistics and reduction outputs are always fp32.
  *  - `stream` is a hipStream_t passed as void*; every call is asynchronous on it.
- *  - No allocation, no synchronisation, no hidden state: scratch memory is passed
- *    in as (`ws`, `ws_bytes`); ad_*_ws_bytes() says how much a call needs.
+ *  - No allocation, no synchronisation: scratch memory is passed in as (`ws`, `ws_bytes`);
+ *    ad_*_ws_bytes() says how much a call needs.  Process-wide state is limited to what is
+ *    declared here: the last-error string, the device's CU count (read once, ad_device_cus)
+ *    and the options set through ad_set_option.  The library never reads the environment.
  *  - Return value: 0 = ok, negative = error (AD_ERR_*); ad_last_error() returns a
  *    thread-local message.  No exceptions cross the boundary.
  *  - One caller thread per device (the reference drives the model from a single
@@ -46,6 +48,18 @@ extern "C" {
 
 int ad_version(void);
 const char* ad_last_error(void);
+
+/* Compute units of the current device (hipDeviceAttributeMultiprocessorCount, queried at the first call and rounded down
+ * to a multiple of 64; 256 on MI355X): the persistent kernels launch one workgroup per CU and deal tiles XCD by XCD. */
+int ad_device_cus(void);
+
+/* A/B switches for measurements, all 0 by default; nothing else changes the kernel a call selects:
+ *   "no_map1"      1x1 feature maps take the generic kernel instead of conv3x3_map1_kernel
+ *   "no_map4"      4x4 feature maps take the generic kernel instead of conv3x3_map4_kernel
+ *   "no_dgrad_ln"  ad_conv3x3_dgrad_ln_bwd_is_fused() answers 0 (dgrad and LayerNorm backward as two launches)
+ * ad_get_option returns the value, -1 for an unknown name. */
+int ad_set_option(const char* name, int value);
+int ad_get_option(const char* name);
 
 /* Channel granularity of the conv kernels for `dtype`: Cin of every conv input
  * tensor must be a multiple of this (32 for bf16, 16 for f32); the 3-channel network

@@ -139,8 +139,40 @@ def test_bench_plain_and_under_torchrun_agree(device):
     assert abs(a["value"] - b["value"]) < 0.05 * a["value"], (a["value"], b["value"])
     for line in (a, b):
         rf = line["roofline"]
-        assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "frac_step", "families"} <= set(rf)
-        assert 0.2 < rf["frac"] < 1.0 and 0.1 < rf["frac_step"] < rf["frac"]
+        assert {"bound", "family", "kernel", "achieved", "peak", "unit", "frac", "traffic", "frac_step", "families", "hbm_ops",
+                "share_of_step", "hbm_gb_per_step", "hbm_frac", "executed_gflop_per_step"} <= set(rf)
+        assert 0.2 < rf["frac"] < 1.0 and 0.1 < rf["frac_step"] < 1.0
+        # the line names the conv family with the largest share of the step
+        assert rf["family"] == max(rf["families"], key=lambda k: rf["families"][k]["ms_per_step"])
+        assert rf["executed_gflop_per_step"] < rf["algorithmic_gflop_per_step"]      # the factored up-convs
+
+
+def test_bench_starts_two_gloo_ranks_on_one_gpu(device):
+    """`python bench.py --gpus 2 --backend gloo`: the N > 1 start-up path of the driver's scaling run (bench.py starts its own
+    ranks as a child `torch.distributed.run` before anything in the parent touches the GPU) rehearsed on the one-GPU box:
+    two ranks share the device, gradients travel over gloo.  Rank 0 prints exactly ONE JSON line, the child's return code
+    becomes ours, both process groups are destroyed (the command returns)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "3",
+                          "--warmup", "1", "--batch", "8", "--no-cpu-baseline", "--no-micro"],
+                         capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert run.returncode == 0, run.stderr[-3000:]
+    lines = [l for l in run.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, run.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["ranks"] == 2 and rec["dist_backend"] == "gloo" and "rccl_ranks" not in rec
+    assert rec["config"]["global_batch"] == 16 and rec["config"]["parallelism"] == "dp2"
+    assert rec["exposed_comm_ms_per_step"] is not None and rec["exchange"] == "torch.distributed.all_reduce"
+    assert rec["value"] > 0 and np.isfinite(rec["config"]["final_loss"])
+    # a run that fails inside the ranks (zero timed steps: rank 0 cannot form a rate): the children's return code comes back
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "0",
+                          "--warmup", "0", "--batch", "2", "--workload", "K1", "--no-cpu-baseline", "--no-micro"],
+                         capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert bad.returncode != 0 and not [l for l in bad.stdout.splitlines() if l.startswith("{")]
 
 
 def test_experiment_sweep_launcher(device, tmp_path):

@@ -203,3 +203,31 @@ def test_prefetch_loader_streams_crops_from_the_decoded_cache(tmp_path):
         loader.close()
     with pytest.raises(ValueError):
         pipeline.PrefetchPatchLoader(files, patch_size=64, batch_size=2)      # patch larger than the images
+
+
+def test_croppers_follow_the_reference_contract():
+    """grid_patches = row-major crops at multiples of the stride; random_patch consults the generator once per axis with
+    room, rows first (shared/pipeline.py:97-174): a seeded stream must place the same crops as the reference's."""
+    from adunet_amd import pipeline as P
+    rng = np.random.default_rng(0)
+    for h, w, p, st in [(17, 23, 5, None), (16, 16, 8, 3), (9, 30, 9, 7), (12, 12, 12, 5)]:
+        img = rng.random((h, w, 3)).astype(np.float32)
+        got = P.grid_patches(img, p, stride=st)
+        step = st or p
+        want = [img[t:t + p, l:l + p] for t in range(0, h - p + 1, step) for l in range(0, w - p + 1, step)]
+        assert got.shape == (len(want), p, p, 3) and all(np.array_equal(a, b) for a, b in zip(got, want))
+    img = rng.random((20, 9, 3)).astype(np.float32)
+    a, b = np.random.default_rng(7), np.random.default_rng(7)
+    for _ in range(5):
+        crop = P.random_patch(img, 9, rng=a)                  # no room along the columns: ONE draw
+        top = int(b.integers(0, 20 - 9 + 1))
+        assert np.array_equal(crop, img[top:top + 9, :9])
+    assert a.integers(0, 1 << 30) == b.integers(0, 1 << 30)   # the two generators are in the same state
+    tr, va, te = P.split_indices(10, 0.7, 0.2, 0.1, seed=3)
+    order = np.arange(10)
+    np.random.default_rng(3).shuffle(order)
+    assert np.array_equal(np.concatenate([tr, va, te]), order) and (len(tr), len(va), len(te)) == (7, 2, 1)
+    with pytest.raises(ValueError, match="patch_size exceeds image dimensions"):
+        P.grid_patches(img, 10)
+    with pytest.raises(ValueError, match="stride must be positive"):
+        P.grid_patches(img, 4, stride=-1)
