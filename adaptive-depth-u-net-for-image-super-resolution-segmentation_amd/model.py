@@ -787,7 +787,13 @@ class Model:
         sc = self._scaler()
         if sc is not None:
             sc.calls += 1
-            sc.lr_dev.fill_(opt.lr_at(sc.calls - 1))     # (a schedule sees issued steps; skipped ones are not re-read)
+            if callable(opt.learning_rate):
+                # Keras evaluates a schedule at the inner optimizer's `iterations` = APPLIED steps (a step skipped on
+                # overflow does not advance it): read the applied-step count back (one small device -> host copy per step,
+                # only for scheduled learning rates under the float16 policy)
+                sc.lr_dev.fill_(opt.lr_at(int(sc.state[4].item())))
+            else:
+                sc.lr_dev.fill_(opt.lr_at(0))
         else:
             opt.iterations += 1
             if alpha_dev is not None:

@@ -316,12 +316,27 @@ class DeviceDegrader:
         return lr, hr
 
 
-def _crop_worker(cache, order_seed, patch_size, batch_size, slots, free_q, full_q, shm_name, stop):
-    """Worker process: fill free batch slots with random HR crops (uint8) until told to stop."""
+def _crop_worker(cache, order_seed, patch_size, batch_size, slots, free_q, full_q, shm_name, stop, patches_per_image):
+    """Worker process: fill free batch slots with random HR crops (uint8) until told to stop.  Sampling follows the
+    reference's stream (shared/pipeline.py:177-195): passes over a freshly shuffled file order, `patches_per_image` crops
+    from each image of the pass -- every image is visited once per pass, none is drawn twice before the others."""
     from multiprocessing import shared_memory
     shm = shared_memory.SharedMemory(name=shm_name)
     ring = np.ndarray((slots, batch_size, patch_size, patch_size, 3), np.uint8, buffer=shm.buf)
     rng = np.random.default_rng(order_seed)
+
+    def crops():
+        order = np.arange(len(cache))
+        while True:
+            rng.shuffle(order)
+            for idx in order:
+                img = cache[int(idx)]
+                for _ in range(patches_per_image):
+                    top = int(rng.integers(0, img.shape[0] - patch_size + 1))
+                    left = int(rng.integers(0, img.shape[1] - patch_size + 1))
+                    yield img[top:top + patch_size, left:left + patch_size]
+
+    stream = crops()
     try:
         while not stop.is_set():
             try:
@@ -329,10 +344,7 @@ def _crop_worker(cache, order_seed, patch_size, batch_size, slots, free_q, full_
             except Exception:
                 continue
             for i in range(batch_size):
-                img = cache[int(rng.integers(0, len(cache)))]
-                top = int(rng.integers(0, img.shape[0] - patch_size + 1))
-                left = int(rng.integers(0, img.shape[1] - patch_size + 1))
-                ring[slot, i] = img[top:top + patch_size, left:left + patch_size]
+                ring[slot, i] = next(stream)
             full_q.put(slot)
     finally:
         shm.close()
@@ -340,7 +352,8 @@ def _crop_worker(cache, order_seed, patch_size, batch_size, slots, free_q, full_
 
 class PrefetchPatchLoader:
     """Infinite stream of HR crop batches [B, P, P, 3] uint8 from a decode-once image cache, cut by `workers` forked
-    processes into a shared-memory ring of `slots` batches.  `shard=(rank, world)` gives every data-parallel rank its own
+    processes into a shared-memory ring of `slots` batches.  Construct it BEFORE the process initialises the GPU where
+    that is possible (the workers are forked; they only ever run NumPy, never HIP).  `shard=(rank, world)` gives every data-parallel rank its own
     random streams (seed + 1000 * rank + worker).  Use with DeviceDegrader:
 
         loader = PrefetchPatchLoader(files, 256, 64, seed=1234, workers=8)
@@ -350,14 +363,14 @@ class PrefetchPatchLoader:
     """
 
     def __init__(self, hr_files: Sequence[str], patch_size: int, batch_size: int, seed: int = 1234, workers: int = 4,
-                 slots: int = 8, shard: Tuple[int, int] = (0, 1)):
+                 slots: int = 8, shard: Tuple[int, int] = (0, 1), patches_per_image: int = 4):
         import multiprocessing as mp
         from multiprocessing import shared_memory
         hr_files = list(hr_files)
         if not hr_files:
             raise ValueError("hr_files must contain at least one path.")
-        if patch_size <= 0 or batch_size <= 0 or workers <= 0 or slots < 2:
-            raise ValueError("patch_size, batch_size and workers must be positive; slots >= 2.")
+        if patch_size <= 0 or batch_size <= 0 or workers <= 0 or slots < 2 or patches_per_image <= 0:
+            raise ValueError("patch_size, batch_size, workers and patches_per_image must be positive; slots >= 2.")
         self.cache = []
         for path in hr_files:                                      # decode once, keep 8-bit
             from PIL import Image
@@ -377,7 +390,7 @@ class PrefetchPatchLoader:
         rank, world = shard
         self._procs = [ctx.Process(target=_crop_worker, daemon=True,
                                    args=(self.cache, seed + 1000 * rank + w, patch_size, batch_size, slots, self._free,
-                                         self._full, self._shm.name, self._stop)) for w in range(workers)]
+                                         self._full, self._shm.name, self._stop, patches_per_image)) for w in range(workers)]
         for p in self._procs:
             p.start()
         self._held = None
@@ -408,3 +421,29 @@ class PrefetchPatchLoader:
     def __del__(self):
         if getattr(self, "_procs", None):
             self.close()
+
+
+class FastFeedDataset:
+    """Drop-in for the training dataset of `make_training_patch_dataset`: an endless iterable of (lr, hr) float32
+    [B, P, P, 3] batches -- here DEVICE tensors: uint8 HR crops from PrefetchPatchLoader cross PCIe (1/8 of the bytes of
+    two float32 tensors) and DeviceDegrader synthesises the LR input in HBM with the reference's area-shrink / cubic-enlarge
+    matrices.  `model.fit` takes the tensors as they are."""
+
+    def __init__(self, hr_files: Sequence[str], patch_size: int, batch_size: int, scale: float, patches_per_image: int = 4,
+                 seed: int = 1234, workers: int = 4, shard: Tuple[int, int] = (0, 1), device=None):
+        self.loader = PrefetchPatchLoader(hr_files, patch_size, batch_size, seed=seed, workers=workers, shard=shard,
+                                          patches_per_image=patches_per_image)
+        self.patch_size, self.scale, self.device = patch_size, scale, device
+        self._degrade = None
+
+    def __iter__(self):
+        import torch
+        if self._degrade is None:
+            dev = torch.device(self.device) if self.device is not None else torch.device("cuda", torch.cuda.current_device())
+            self._degrade = DeviceDegrader(self.patch_size, self.scale, dev)
+            self.device = dev
+        for hr_u8 in self.loader:
+            yield self._degrade(torch.from_numpy(hr_u8).to(self.device, non_blocking=False))
+
+    def close(self):
+        self.loader.close()

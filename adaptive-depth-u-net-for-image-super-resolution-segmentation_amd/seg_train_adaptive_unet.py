@@ -89,9 +89,9 @@ def load_isic_image(path, size: int) -> np.ndarray:
     with Image.open(str(path)) as im:
         rgb = np.asarray(im.convert("RGB"), np.float32) / 255.0
     h, w = rgb.shape[:2]
-    my = _area_matrix(h, size) if h >= size else _bilinear_matrix(h, size)
-    mx = _area_matrix(w, size) if w >= size else _bilinear_matrix(w, size)
-    return _resize_separable(rgb, my, mx).astype(np.float32)
+    # tf.image.ResizeMethod.AREA in both directions, as the reference (:146): each output pixel averages the input area
+    # it covers (for an enlargement that area lies inside one or two input pixels)
+    return _resize_separable(rgb, _area_matrix(h, size), _area_matrix(w, size)).astype(np.float32)
 
 
 def load_isic_mask(path, size: int) -> np.ndarray:
@@ -131,24 +131,38 @@ def apply_isic_augmentations(image: np.ndarray, mask: np.ndarray, size: int, rng
 
 class IsicDataset:
     """Re-iterable stream of (image [B,S,S,3], mask [B,S,S,1]) float32 batches (build_isic_dataset, :199-226):
-    optional full reshuffle per pass, optional augmentation, last batch kept (drop_remainder=False)."""
+    optional full reshuffle per pass, optional augmentation, last batch kept (drop_remainder=False).
+
+    The reference maps decode + resize over tf.data with AUTOTUNE parallelism and prefetch (:214-225).  Here every file
+    is decoded and area-resized ONCE (a multi-megapixel ISIC photograph costs ~10 GFLOP of float64 resize) into an
+    in-memory cache at `image_size` -- float32 images as the reference's pipeline holds them, uint8 masks -- and a pass
+    only augments cached arrays.  Batches are assembled by a background thread `prefetch` batches ahead of the consumer
+    (NumPy releases the GIL in the resize / copy kernels), so the GPU step and the host augmentation overlap."""
 
     def __init__(self, pairs: Sequence[Tuple[str, str]], batch_size: int, image_size: int, augment: bool, shuffle: bool,
-                 seed: int):
+                 seed: int, cache: bool = True, prefetch: int = 4):
         self.pairs, self.batch_size, self.size = list(pairs), int(batch_size), int(image_size)
         self.augment, self.shuffle, self.seed = augment, shuffle, seed
         self._pass = 0
+        self._cache = {} if cache else None
+        self.prefetch = int(prefetch)
 
     def __len__(self) -> int:
         return math.ceil(len(self.pairs) / self.batch_size)
 
-    def __iter__(self) -> Iterator[Tuple[np.ndarray, np.ndarray]]:
-        rng = np.random.default_rng(self.seed + self._pass)          # reshuffle_each_iteration=True
-        self._pass += 1
-        order = rng.permutation(len(self.pairs)) if self.shuffle else np.arange(len(self.pairs))
+    def _item(self, i: int) -> Tuple[np.ndarray, np.ndarray]:
+        if self._cache is not None and i in self._cache:
+            img, msk8 = self._cache[i]
+            return img, msk8.astype(np.float32)
+        img, msk = load_isic_image(self.pairs[i][0], self.size), load_isic_mask(self.pairs[i][1], self.size)
+        if self._cache is not None:
+            self._cache[i] = (img, msk.astype(np.uint8))
+        return img, msk
+
+    def _batches(self, rng: np.random.Generator, order: np.ndarray) -> Iterator[Tuple[np.ndarray, np.ndarray]]:
         imgs, masks = [], []
         for i in order:
-            img, msk = load_isic_image(self.pairs[i][0], self.size), load_isic_mask(self.pairs[i][1], self.size)
+            img, msk = self._item(int(i))
             if self.augment:
                 img, msk = apply_isic_augmentations(img, msk, self.size, rng)
             imgs.append(img)
@@ -158,6 +172,36 @@ class IsicDataset:
                 imgs, masks = [], []
         if imgs:
             yield np.stack(imgs), np.stack(masks)
+
+    def __iter__(self) -> Iterator[Tuple[np.ndarray, np.ndarray]]:
+        rng = np.random.default_rng(self.seed + self._pass)          # reshuffle_each_iteration=True
+        self._pass += 1
+        order = rng.permutation(len(self.pairs)) if self.shuffle else np.arange(len(self.pairs))
+        source = self._batches(rng, order)
+        if self.prefetch <= 0:
+            yield from source
+            return
+        import queue
+        import threading
+        q: "queue.Queue" = queue.Queue(maxsize=self.prefetch)
+        done = object()
+
+        def produce():
+            try:
+                for item in source:
+                    q.put(item)
+                q.put(done)
+            except BaseException as exc:        # surfaces in the consumer
+                q.put(exc)
+
+        threading.Thread(target=produce, daemon=True).start()
+        while True:
+            item = q.get()
+            if item is done:
+                return
+            if isinstance(item, BaseException):
+                raise item
+            yield item
 
 
 def build_isic_dataset(image_dir, mask_dir, batch_size: int, image_size: int, augment: bool, shuffle: bool, seed: int):

@@ -60,6 +60,12 @@ def train(args: argparse.Namespace):
 
     train_ds, train_count = make_training_patch_dataset(tr, patch_size, args.patches_per_image, DATA_LR_SHRINK,
                                                         args.batch_size, args.seed, args.shuffle_buffer)
+    if getattr(args, "fast_feed", False):
+        # MI355X feed path (not a reference flag): decode-once uint8 cache, forked crop workers, LR synthesis in HBM.  Started
+        # here, before the model initialises the GPU in this process (the workers are forked and never touch HIP).
+        from .pipeline import FastFeedDataset
+        train_ds = FastFeedDataset(tr, patch_size, args.batch_size, DATA_LR_SHRINK, args.patches_per_image, args.seed,
+                                   workers=args.feed_workers)
     val_ds = val_count = None
     if va:
         val_ds, val_count, _ = make_eval_patch_dataset(va, patch_size, DATA_LR_SHRINK, args.batch_size, stride=args.eval_stride)
@@ -86,8 +92,9 @@ def train(args: argparse.Namespace):
             resume = cands[-1]
         if not resume.exists():
             raise FileNotFoundError(f"Checkpoint not found: {resume}")
-        try:      # weights as in the reference (:511); the optimizer state too when the checkpoint carries it
-            model.load_weights(resume, restore_optimizer=True)
+        try:      # weights only, as the reference's model.load_weights (:511): the optimizer restarts.  --resume_optimizer also
+            # brings back the Adam moments / iteration count / loss scaler when the checkpoint carries them
+            model.load_weights(resume, restore_optimizer=bool(getattr(args, "resume_optimizer", False)))
         except Exception as exc:
             raise RuntimeError(f"Failed to load weights from {resume}: {exc}") from exc
 
@@ -158,6 +165,12 @@ def parse_args(argv=None) -> argparse.Namespace:
     p.add_argument("--high_res_dir", type=str, default=None)
     p.add_argument("--low_res_dir", type=str, default=None)
     p.add_argument("--resume_from", type=str, default=None)
+    p.add_argument("--resume_optimizer", action="store_true",
+                   help="with --resume_from: also restore the optimizer state saved in the checkpoint (not a reference flag; the "
+                        "reference reloads weights only)")
+    p.add_argument("--fast_feed", action="store_true",
+                   help="train from the decode-once / forked-worker / device-degradation feed (not a reference flag)")
+    p.add_argument("--feed_workers", type=int, default=4)
     p.add_argument("--initial_epoch", type=int, default=0)
     return p.parse_args(argv)
 

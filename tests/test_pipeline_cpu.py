@@ -231,3 +231,27 @@ def test_croppers_follow_the_reference_contract():
         P.grid_patches(img, 10)
     with pytest.raises(ValueError, match="stride must be positive"):
         P.grid_patches(img, 4, stride=-1)
+
+
+def test_isic_dataset_cache_and_prefetch_give_the_same_stream(tmp_path):
+    """Decode-once cache + background prefetch (the tf.data map(AUTOTUNE) + prefetch of Segmenation/code/
+    train_adaptive_unet.py:214-225) must not change what the stream yields: same batches as the uncached, unthreaded
+    iteration, pass after pass (pass k is seeded seed + k), enlargement by AREA like every other size."""
+    from PIL import Image
+    from adunet_amd import seg_train_adaptive_unet as S
+    rng = np.random.default_rng(0)
+    (tmp_path / "img").mkdir()
+    (tmp_path / "msk").mkdir()
+    for i, (h, w) in enumerate([(40, 52), (33, 33), (20, 64), (70, 18), (48, 48)]):     # two of them smaller than the target
+        Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)).save(tmp_path / "img" / f"ISIC_{i:07d}.png")
+        Image.fromarray((rng.random((h, w)) > 0.5).astype(np.uint8) * 255).save(tmp_path / "msk" / f"ISIC_{i:07d}_segmentation.png")
+    pairs = S.collect_isic_pairs(tmp_path / "img", tmp_path / "msk")
+    fast = S.IsicDataset(pairs, 2, 32, augment=True, shuffle=True, seed=5)
+    slow = S.IsicDataset(pairs, 2, 32, augment=True, shuffle=True, seed=5, cache=False, prefetch=0)
+    for _ in range(3):                                   # three passes: the second and third come from the cache
+        a, b = list(fast), list(slow)
+        assert len(a) == len(b) == 3 and a[-1][0].shape[0] == 1
+        for (ia, ma), (ib, mb) in zip(a, b):
+            assert np.array_equal(ia, ib) and np.array_equal(ma, mb) and ia.dtype == np.float32 and set(np.unique(ma)) <= {0.0, 1.0}
+    img = S.load_isic_image(pairs[3][0], 32)             # 70 x 18 -> 32 x 32: shrink one axis, enlarge the other, AREA both
+    assert img.shape == (32, 32, 3) and 0.0 <= img.min() and img.max() <= 1.0
