@@ -155,9 +155,13 @@ __global__ __launch_bounds__(PW_T, 2) void pw_gemm_kernel(PwArgs a) {
                 }
             } else {
                 const unsigned yo = mrow < a.m ? (unsigned)((mrow * a.n + nb * 64 + grp * 4) * TSZ) : PW_OOB;
+                // The n-tile offset goes into the VECTOR offset (hipcc folds it into the instruction's immediate), never into
+                // the scalar soffset operand: a 16-byte buffer store whose soffset is an SGPR (128 and 192 are not inline
+                // constants) reads its data registers late, hipcc assumes that form has no store-data hazard and lets the
+                // next VALU write reuse them at once -- seen as address words in place of accumulator values (gfx950, ROCm 7.2)
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt)
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[mt][nt]), rsy, yo, nt * 16 * TSZ, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[mt][nt]), rsy, yo + nt * 16 * TSZ, 0, 0);
             }
         }
     }
