@@ -169,6 +169,123 @@ __global__ __launch_bounds__(PW_T, 2) void pw_gemm_kernel(PwArgs a) {
 #undef PW_MMA
 }
 
+// ---- LDS-tiled form of the same product for the 16-bit types (the bank GEMMs of ratio ~0.5-0.7 pyramids carry a third to a
+// half of the up-conv's FLOPs: fragments straight from L2 cap the kernel above at ~0.2 of the MFMA peak).
+// A 512-thread workgroup owns a 256-pixel x NT-channel tile (NT = 32 NW: 192 for the bank's 9 Cout columns, 128 for the
+// Cin columns of dx), 8 waves as 4 (pixels) x 2 (channels), a wave 64 pixels x 16 NW channels.  K advances in stages of 64:
+// pixel rows and bank columns of a stage go global -> registers -> LDS one stage ahead of their use (double-buffered
+// stage: [2 chunks][256 rows][96 B] + [2 chunks][4 k-slots][NT][16 B], the row stride and k-slot layout of conv.hip, both
+// conflict-free for the ds_read_b128 fragment reads), one barrier per stage.  Workgroups are persistent and walk the tiles
+// n-fastest (the pixel rows of a tile row stay in L2); the fragment stream runs across tile boundaries, the loads of the
+// next tile's first stage are in flight while a tile's results are packed and stored.
+constexpr int PL_T = 512;
+constexpr int PL_XB = 256 * 96;                 // one 32-k chunk of 256 pixel rows (24,576 B)
+template <int NW> struct PlGeo {
+    static constexpr int NT = 32 * NW;                      // channels per tile
+    static constexpr int WB = 4 * NT * 16;                  // one 32-k chunk of the bank tile
+    static constexpr int STAGE = 2 * PL_XB + 2 * WB;
+    static constexpr int WSL = 8 * NT / PL_T;               // bank slots per thread and stage (3 or 2)
+};
+
+template <typename E, int NW>
+__global__ __launch_bounds__(PL_T, 1) void pw_gemm_lds_kernel(PwArgs a) {
+    typedef PwPol<E> P;
+    typedef typename P::frag frag;
+    typedef PlGeo<NW> G;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 3, wn = wave >> 2;
+    const int grp = lane >> 4, l15 = lane & 15;
+    const int tiles_n = a.n / G::NT, tiles_m = (a.m + 255) / 256;
+    const int ntiles = tiles_n * tiles_m;
+    const int ks_per_tile = a.k / 64;
+    const auto rsx = pw_rsrc(a.x, (long long)a.m * a.k * 2);
+    const auto rsb = pw_rsrc(a.bp, (long long)a.k * a.n * 2);
+    const auto rsy = pw_rsrc(a.y, (long long)a.m * a.n * 2);
+    // staging slots.  Pixel rows: slot s = tid + 512 i -> row s >> 3, 16-byte part s & 7 (8 lanes = one 128-byte row piece).
+    // Bank: slot s = tid + 512 i -> k-slot s / NT, column s % NT (a k-slot's NT columns are contiguous in the pack).
+    int xrow[4], xlds[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int sl = tid + PL_T * i;
+        xrow[i] = sl >> 3;
+        xlds[i] = ((sl & 7) >> 2) * PL_XB + (sl >> 3) * 96 + (sl & 3) * 16;
+    }
+    const int xpart = (tid & 7) * 16;
+    int wsrc[G::WSL], wlds[G::WSL];
+#pragma unroll
+    for (int i = 0; i < G::WSL; ++i) {
+        const int sl = tid + PL_T * i;
+        const int j = sl / G::NT, n = sl - j * G::NT;
+        wsrc[i] = (j * a.n + n) * 16;
+        wlds[i] = 2 * PL_XB + (j >> 2) * G::WB + ((j & 3) * G::NT + n) * 16;
+    }
+    u32x4 xr[4], wr[G::WSL];
+    int it = blockIdx.x, iks = 0;                    // cursor of the next stage to issue (tile, k-stage)
+#define PL_ISSUE                                                                                                 \
+    {                                                                                                            \
+        const int tq_ = min(it, ntiles - 1);          /* past the end: re-read the last stage, never stored */   \
+        const int tm_ = tq_ / tiles_n, tn_ = tq_ - tm_ * tiles_n;                                                \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                          \
+            const int mrow_ = tm_ * 256 + xrow[i];                                                               \
+            xr[i] = __builtin_amdgcn_raw_buffer_load_b128(rsx, mrow_ < a.m ? (unsigned)(mrow_ * a.k * 2 + xpart) : PW_OOB, \
+                                                          (unsigned)(iks * 128), 0);                             \
+        }                                                                                                        \
+        const unsigned wb_ = (unsigned)((iks * 8 * a.n + tn_ * G::NT) * 16);                                     \
+        _Pragma("unroll") for (int i = 0; i < G::WSL; ++i)                                                       \
+            wr[i] = __builtin_amdgcn_raw_buffer_load_b128(rsb, (unsigned)wsrc[i], wb_, 0);                       \
+        if (++iks == ks_per_tile) { iks = 0; it += gridDim.x; }                                                  \
+    }
+    const int xfo = (wm * 64 + l15) * 96 + grp * 16;                           // + mt * 16 * 96 (+ chunk * PL_XB)
+    const int wfo = 2 * PL_XB + (grp * G::NT + wn * NW * 16 + l15) * 16;       // + nt * 256 (+ chunk * WB)
+    PL_ISSUE
+    int buf = 0;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        f32x4 acc[4][NW];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < ks_per_tile; ++ks) {
+            char* sb = smem + buf * G::STAGE;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(sb + xlds[i]) = xr[i];
+#pragma unroll
+            for (int i = 0; i < G::WSL; ++i) *reinterpret_cast<u32x4*>(sb + wlds[i]) = wr[i];
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            PL_ISSUE
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                frag xf[4], wf[NW];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) xf[mt] = *reinterpret_cast<const frag*>(sb + c * PL_XB + xfo + mt * 16 * 96);
+#pragma unroll
+                for (int nt = 0; nt < NW; ++nt) wf[nt] = *reinterpret_cast<const frag*>(sb + c * G::WB + wfo + nt * 256);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NW; ++nt) acc[mt][nt] = P::mma(wf[nt], xf[mt], acc[mt][nt]);
+            }
+            buf ^= 1;
+        }
+        const int tm = t / tiles_n, tn = t - tm * tiles_n;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int mrow = tm * 256 + wm * 64 + mt * 16 + l15;
+            const unsigned yo = mrow < a.m ? (unsigned)((mrow * a.n + tn * G::NT + wn * NW * 16 + (grp & 1) * 16 + (grp >> 1) * 8) * 2) : PW_OOB;
+#pragma unroll
+            for (int np = 0; np < NW / 2; ++np) {
+                const u32x2 pa = P::pack4(acc[mt][2 * np]), pb = P::pack4(acc[mt][2 * np + 1]);
+                const u32x2 s0 = __builtin_amdgcn_permlane16_swap(pa[0], pb[0], false, false);
+                const u32x2 s1 = __builtin_amdgcn_permlane16_swap(pa[1], pb[1], false, false);
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, rsy, yo + np * 64, 0, 0);
+            }
+        }
+    }
+#undef PL_ISSUE
+}
+
 // Bank operands from the fp32 Keras kernel W[3][3][Cin][Cout] (HWIO):
 //   forward  bank  B[k = ci][n = tap * Cout + co]  -> bf[ci / KV][tap * Cout + co][KV]
 //   backward bank  B^T[k = tap * Cout + co][n = ci] -> bd[(tap * Cout + co) / KV][ci][KV]
@@ -645,6 +762,30 @@ extern "C" int ad_pw_gemm(const void* x, const void* bank, void* y, int64_t m, i
     PwArgs a;
     a.x = (const char*)x; a.bp = (const char*)bank; a.y = (char*)y;
     a.m = (int)m; a.k = k; a.n = n;
+    a.nb_per_wg = 0;
+    if (ad_is_half(dtype) && m >= 2048 && (n % 192 == 0 || n % 128 == 0)) {       // LDS-tiled persistent kernel
+        hipStream_t s = (hipStream_t)stream;
+        const int nw = n % 192 == 0 ? 6 : 4;
+        const int ntiles = (int)((m + 255) / 256) * (n / (32 * nw));
+        const int grid = ntiles < ad_num_cu() ? ntiles : ad_num_cu();
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pw_gemm_lds_kernel<bf16_t, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PlGeo<6>::STAGE);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pw_gemm_lds_kernel<f16_t, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PlGeo<6>::STAGE);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pw_gemm_lds_kernel<bf16_t, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PlGeo<4>::STAGE);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pw_gemm_lds_kernel<f16_t, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PlGeo<4>::STAGE);
+            attr = true;
+        }
+        if (nw == 6) {
+            if (dtype == AD_BF16) pw_gemm_lds_kernel<bf16_t, 6><<<grid, PL_T, 2 * PlGeo<6>::STAGE, s>>>(a);
+            else pw_gemm_lds_kernel<f16_t, 6><<<grid, PL_T, 2 * PlGeo<6>::STAGE, s>>>(a);
+        } else {
+            if (dtype == AD_BF16) pw_gemm_lds_kernel<bf16_t, 4><<<grid, PL_T, 2 * PlGeo<4>::STAGE, s>>>(a);
+            else pw_gemm_lds_kernel<f16_t, 4><<<grid, PL_T, 2 * PlGeo<4>::STAGE, s>>>(a);
+        }
+        AD_LAUNCH_CHECK("ad_pw_gemm (lds)");
+        return AD_OK;
+    }
     const int mtiles = (int)((m + 255) / 256), nblk = n / 64;
     // all output blocks of a pixel tile in one workgroup (its pixel rows stay in L1) unless that leaves CUs idle
     int per = nblk;

@@ -30,7 +30,10 @@ def relerr(got, want):
 @pytest.mark.parametrize("dtype", [F32, BF16, F16])
 # pixels, cin, cout.  The last shape gives a workgroup TWO output blocks (125 pixel tiles x 18 blocks): in fp32 the second
 # block's accumulator set-up follows the first block's 16-byte stores directly (the store-data hazard noted in pw_gemm_kernel)
-@pytest.mark.parametrize("shape", [(1, 64, 64), (300, 128, 64), (513, 192, 128), (2000, 64, 64), (31752, 128, 128)])
+# From 2 048 pixels on the 16-bit types take the LDS-tiled persistent kernel (tile 256 x 192 for the bank's 9 Cout columns,
+# 256 x 128 for dx's Cin columns; ragged last pixel tile, several tiles per workgroup, 2 .. 18 k-stages).
+@pytest.mark.parametrize("shape", [(1, 64, 64), (300, 128, 64), (513, 192, 128), (2000, 64, 64), (31752, 128, 128), (5000, 256, 64),
+                                   (70001, 128, 64)])
 def test_pointwise_gemm(device, dtype, shape):
     """ad_pw_gemm: ragged pixel counts (not a multiple of the 64-pixel wave tile), several k chunks / output blocks."""
     from adunet_amd import ops
