@@ -55,15 +55,22 @@ struct Geo {
 // 64 images x 4 x 4)
 static bool pick_geo(int n, int h, int w, Geo* g, int max_nph = 1 << 30) {
     static const int cand[5][3] = {{0, 4, 4}, {2, 3, 3}, {4, 2, 2}, {6, 1, 1}, {8, 0, 0}};
-    long best = -1;
+    // Cost of a geometry = tiles x halo pixels per tile (what a tile loads and stages; its 256 output pixels cost the same
+    // MFMA work in every geometry), with the 16 x 16 tiles -- the only ones the wave-specialised kernels take, at about twice
+    // the generic kernel's rate -- weighted 0.6.  (Until r03 the rule was "fewest tiles": a 154-wide map then ran as 16
+    // images x 4 x 4 tiles, 3 042 tiles against 3 200, on the generic kernel with 2.25 halo pixels per output pixel: 0.17 of
+    // peak where the 16 x 16 geometry gives 0.5; likewise the 56- and 34-wide levels of the 0.6 pyramid.)
+    double best = -1.0;
     const int pad = (h > 1 || w > 1) ? 2 : 0;
     for (int i = 0; i < 5; ++i) {
         int ti = 1 << cand[i][0], th = 1 << cand[i][1], tw = 1 << cand[i][2];
         if (i == 4 && !(h == 1 && w == 1)) continue;
-        if (ti * (th + pad) * (tw + pad) > max_nph) continue;
+        const int nph = ti * (th + pad) * (tw + pad);
+        if (nph > max_nph) continue;
         long cnt = (long)((n + ti - 1) / ti) * ((h + th - 1) / th) * ((w + tw - 1) / tw);
-        if (best < 0 || cnt < best) {
-            best = cnt;
+        const double cost = (double)cnt * nph * (i == 0 ? 0.6 : 1.0);
+        if (best < 0 || cost < best) {
+            best = cost;
             g->lti = cand[i][0]; g->lth = cand[i][1]; g->ltw = cand[i][2];
         }
     }
