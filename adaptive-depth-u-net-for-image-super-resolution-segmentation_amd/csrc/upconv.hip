@@ -483,6 +483,7 @@ struct GatherArgs {
     const char* y; const float* bias; char* out;
     const int* sy; const float* wy; const int* sx; const float* wx;
     int h, w, oh, ow, c, relu, rows;      // rows: output rows per strip
+    int slab;                             // LDS bytes of one staged bank-row piece (multiple of 16)
 };
 
 constexpr int GF_MAXROWS = 64;
@@ -515,15 +516,29 @@ template <typename E> struct VecH16 {
 template <> struct VecH<bf16_t> : VecH16<bf16_t> {};
 template <> struct VecH<f16_t> : VecH16<f16_t> {};
 
-template <typename T, int GW>
+template <typename T, int GW, int NSL>
 __global__ __launch_bounds__(256) void upconv_gather_fwd_kernel(GatherArgs a) {
     constexpr int EPT = VecH<T>::N;
-    const int vecs = a.c / EPT;
+    constexpr int TSZ = (int)sizeof(T);
+    extern __shared__ __attribute__((aligned(16))) char gsm[];
+    const int vecs = a.c / EPT;                        // divides 256 (launcher)
+    const int nox = 256 / vecs;                        // output columns of this workgroup
     const int oy0 = blockIdx.y * a.rows, oy1 = min(oy0 + a.rows, a.oh), nn = blockIdx.z;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const bool live = i < a.ow * vecs;
-    const int ox = live ? i / vecs : 0, v = live ? i - ox * vecs : 0;
-    // horizontal taps of the three shifted columns
+    const int ox0 = blockIdx.x * nox;
+    const int oxl = threadIdx.x / vecs, v = threadIdx.x - oxl * vecs;
+    const int ox = min(ox0 + oxl, a.ow - 1);
+    const bool live = ox0 + oxl < a.ow;
+    // The low-resolution columns this workgroup reads: ONE contiguous piece of every bank row (columns xlo .. xhi, nine
+    // taps, all channels), staged in LDS by all threads with 16-byte loads -- the 18 vectors a thread needs per
+    // low-resolution row are then LDS reads, and the global loads of the NEXT row are few enough (NSL per thread) to stay
+    // in flight in registers across the output rows in between.
+    const int xlo = a.sx[max(ox0 - 1, 0)];
+    const int xhi = min(a.sx[min(ox0 + nox, a.ow - 1)] + 1, a.w - 1);
+    const int slab_bytes = (xhi - xlo + 1) * 9 * a.c * TSZ;
+    char* sbuf = gsm;                                  // [2][a.slab] bytes
+    float (*s_w)[12] = reinterpret_cast<float (*)[12]>(gsm + 2 * a.slab);
+    int* s_adv = reinterpret_cast<int*>(gsm + 2 * a.slab + GF_MAXROWS * 48);
+    // horizontal taps of the three shifted columns: LDS byte offsets inside the slab
     float fx[3][2];
     int xoff[3][2];
 #pragma unroll
@@ -534,44 +549,52 @@ __global__ __launch_bounds__(256) void upconv_gather_fwd_kernel(GatherArgs a) {
         const int x0 = a.sx[ccl];
         fx[d][0] = ok ? a.wx[2 * ccl] : 0.f;
         fx[d][1] = ok ? a.wx[2 * ccl + 1] : 0.f;
-        xoff[d][0] = (x0 * 9 + d) * a.c + v * EPT;
-        xoff[d][1] = (min(x0 + 1, a.w - 1) * 9 + d) * a.c + v * EPT;
+        xoff[d][0] = (((x0 - xlo) * 9 + d) * a.c + v * EPT) * TSZ;
+        xoff[d][1] = (((min(x0 + 1, a.w - 1) - xlo) * 9 + d) * a.c + v * EPT) * TSZ;
     }
     float bv[EPT];
 #pragma unroll
     for (int e = 0; e < EPT; ++e) bv[e] = a.bias ? a.bias[v * EPT + e] : 0.f;
-    const T* yn = reinterpret_cast<const T*>(a.y) + (size_t)nn * a.h * a.w * 9 * a.c;
+    const long long ybytes = (long long)a.h * a.w * 9 * a.c * TSZ;                  // one image of the bank (< 2 GiB: launcher)
+    const auto rsy = pw_rsrc(a.y + (size_t)nn * ybytes, ybytes);
     float hs[3][GW][EPT];
-    // H_dy[q] for the three dy into window slot SLOT: 18 loads, then the arithmetic.  (Measured and withdrawn: keeping the
-    // 18 vectors of the NEXT window row in flight across the output rows in between -- 256 registers, one wave per SIMD
-    // less, 0.45 -> 0.49 ms on the 64 -> 256 level: this kernel lives on occupancy, hence also the 8-byte vectors.)
-    VecH<T> pend[3][3][2];
+    u32x4 pend[NSL];
 #define GF_ISSUE(Q)                                                                                        \
     {                                                                                                      \
-        const T* row_ = yn + (size_t)min((Q), a.h - 1) * a.w * 9 * a.c;                                    \
-        _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_)                                                   \
-            _Pragma("unroll") for (int d_ = 0; d_ < 3; ++d_)                                               \
-                _Pragma("unroll") for (int b_ = 0; b_ < 2; ++b_) pend[s_][d_][b_].load(row_ + xoff[d_][b_] + s_ * 3 * a.c); \
+        const unsigned rb_ = (unsigned)((min((Q), a.h - 1) * a.w + xlo) * 9 * a.c * TSZ);                  \
+        _Pragma("unroll") for (int i_ = 0; i_ < NSL; ++i_) {                                               \
+            const int o_ = (threadIdx.x + 256 * i_) * 16;                                                  \
+            pend[i_] = __builtin_amdgcn_raw_buffer_load_b128(rsy, o_ < slab_bytes ? rb_ + o_ : PW_OOB, 0, 0); \
+        }                                                                                                  \
     }
-#define GF_TAKE(SLOT)                                                                                      \
+#define GF_STAGE(BUF)                                                                                      \
     {                                                                                                      \
+        _Pragma("unroll") for (int i_ = 0; i_ < NSL; ++i_) {                                               \
+            const int o_ = (threadIdx.x + 256 * i_) * 16;                                                  \
+            if (o_ < a.slab) *reinterpret_cast<u32x4*>(sbuf + (BUF) * a.slab + o_) = pend[i_];             \
+        }                                                                                                  \
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                    \
+    }
+#define GF_TAKE(BUF, SLOT)                                                                                 \
+    {                                                                                                      \
+        const char* sl_ = sbuf + (BUF) * a.slab;                                                           \
         _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_) {                                                 \
+            VecH<T> ld_[3][2];                                                                             \
+            _Pragma("unroll") for (int d_ = 0; d_ < 3; ++d_)                                               \
+                _Pragma("unroll") for (int b_ = 0; b_ < 2; ++b_) ld_[d_][b_].load(sl_ + xoff[d_][b_] + s_ * 3 * a.c * TSZ); \
             _Pragma("unroll") for (int e_ = 0; e_ < EPT; ++e_) hs[s_][SLOT][e_] = 0.f;                     \
             _Pragma("unroll") for (int d_ = 0; d_ < 3; ++d_)                                               \
                 _Pragma("unroll") for (int b_ = 0; b_ < 2; ++b_) {                                         \
                     float t_[EPT];                                                                         \
-                    pend[s_][d_][b_].to_f32(t_);                                                           \
+                    ld_[d_][b_].to_f32(t_);                                                                \
                     _Pragma("unroll") for (int e_ = 0; e_ < EPT; ++e_) hs[s_][SLOT][e_] += fx[d_][b_] * t_[e_]; \
                 }                                                                                          \
         }                                                                                                  \
     }
-#define GF_ROW(Q, SLOT) GF_ISSUE(Q) GF_TAKE(SLOT)
     // Per-row table values of the strip, staged in LDS once: the window advance of each output row and, per vertical tap
-    // dy, the weights of the four window rows (two of them non-zero; all zero where row oy + dy is outside the image).
+    // dy, the weights of the window rows (two of them non-zero; all zero where row oy + dy is outside the image).
     // Read back as LDS broadcasts: table loads from global memory inside the row loop would sit in the same vmcnt queue as
     // the row stores and turn every row into three dependent memory round trips.
-    __shared__ __attribute__((aligned(16))) float s_w[GF_MAXROWS][12];
-    __shared__ int s_adv[GF_MAXROWS];
     for (int r = threadIdx.x; r < oy1 - oy0; r += 256) {
         const int oy = oy0 + r;
         const int qb = a.sy[max(oy - 1, 0)];
@@ -587,15 +610,15 @@ __global__ __launch_bounds__(256) void upconv_gather_fwd_kernel(GatherArgs a) {
         }
     }
     int qbase = a.sy[max(oy0 - 1, 0)];                 // the window holds rows qbase .. qbase + GW - 1 (workgroup-uniform)
-    // (the scheduling barriers keep hipcc from issuing the 72 loads of the four initial rows at once: 144 registers)
-    GF_ROW(qbase, 0) __builtin_amdgcn_sched_barrier(0);
-    GF_ROW(qbase + 1, 1) __builtin_amdgcn_sched_barrier(0);
-    GF_ROW(qbase + 2, 2)
-    if constexpr (GW == 4) {
-        __builtin_amdgcn_sched_barrier(0);
-        GF_ROW(qbase + 3, 3)
+    int cur = 0;                                       // LDS buffer the next staged row goes to
+    GF_ISSUE(qbase)
+#pragma unroll
+    for (int k = 0; k < GW; ++k) {                     // fill the window; row qbase + GW is left in flight
+        GF_STAGE(cur)
+        GF_ISSUE(qbase + k + 1)
+        GF_TAKE(cur, k)
+        cur ^= 1;
     }
-    __syncthreads();
     T* on = reinterpret_cast<T*>(a.out) + ((size_t)nn * a.oh * a.ow + ox) * a.c + v * EPT;
     for (int r = 0; r < oy1 - oy0; ++r) {
         for (int adv = __builtin_amdgcn_readfirstlane(s_adv[r]); adv > 0; --adv) {    // slide: drop row qbase, add row qbase + GW
@@ -605,8 +628,11 @@ __global__ __launch_bounds__(256) void upconv_gather_fwd_kernel(GatherArgs a) {
                 for (int k = 0; k + 1 < GW; ++k)
 #pragma unroll
                     for (int e = 0; e < EPT; ++e) hs[s_][k][e] = hs[s_][k + 1][e];
-            GF_ROW(qbase + GW, GW - 1)
+            GF_STAGE(cur)                               // row qbase + GW: its loads were issued one slide ago
             ++qbase;
+            GF_ISSUE(qbase + GW)
+            GF_TAKE(cur, GW - 1)
+            cur ^= 1;
         }
         float o[EPT];
 #pragma unroll
@@ -630,8 +656,8 @@ __global__ __launch_bounds__(256) void upconv_gather_fwd_kernel(GatherArgs a) {
             st.store(on + (size_t)(oy0 + r) * a.ow * a.c);
         }
     }
-#undef GF_ROW
 #undef GF_ISSUE
+#undef GF_STAGE
 #undef GF_TAKE
 }
 
@@ -858,30 +884,49 @@ extern "C" int ad_pw_wgrad(const void* x, const void* dybank, float* dw_hwio, in
     return AD_OK;
 }
 
+extern "C" int ad_upconv_gather_fwd_supported(int c, int slab_cols, int dtype) {
+    if (!ad_dtype_ok(dtype) || c <= 0 || slab_cols <= 0) return 0;
+    const int ept = ad_is_half(dtype) ? 4 : 2, tsz = ad_is_half(dtype) ? 2 : 4;
+    if (c % ept || 256 % (c / ept)) return 0;                               // 8-byte channel vectors, a divisor of 256 per column
+    return (long long)slab_cols * 9 * c * tsz <= 12 * 256 * 16;            // <= 12 staging slots per thread (48 KB per row piece)
+}
+
 extern "C" int ad_upconv_gather_fwd(const void* ybank, const float* bias, void* out, const int* sy, const float* wy,
-                                    const int* sx, const float* wx, int window, int n, int h, int w, int oh, int ow, int c,
-                                    int relu, int dtype, void* stream) {
+                                    const int* sx, const float* wx, int window, int slab_cols, int n, int h, int w, int oh,
+                                    int ow, int c, int relu, int dtype, void* stream) {
     AD_REQUIRE(ad_dtype_ok(dtype), "ad_upconv_gather_fwd: bad dtype %d", dtype);
-    const int ept = ad_is_half(dtype) ? 8 : 4;
+    const int ept = ad_is_half(dtype) ? 4 : 2, tsz = ad_is_half(dtype) ? 2 : 4;
     AD_REQUIRE(ybank && out && sy && wy && sx && wx, "ad_upconv_gather_fwd: NULL operand");
-    AD_REQUIRE(n > 0 && h > 0 && w > 0 && oh >= h && ow >= w && c > 0 && c % ept == 0,
+    AD_REQUIRE(n > 0 && h > 0 && w > 0 && oh >= h && ow >= w && c > 0,
                "ad_upconv_gather_fwd: bad shape n=%d %dx%d -> %dx%d c=%d", n, h, w, oh, ow, c);
-    AD_REQUIRE((long long)h * w * 9 * c < (1LL << 31) && (long long)oh * ow * c < (1LL << 31),
-               "ad_upconv_gather_fwd: an image of more than 2^31 elements");
+    AD_REQUIRE(ad_upconv_gather_fwd_supported(c, slab_cols, dtype),
+               "ad_upconv_gather_fwd: c=%d / slab_cols=%d not supported (ask ad_upconv_gather_fwd_supported)", c, slab_cols);
+    AD_REQUIRE((long long)h * w * 9 * c * tsz < (1LL << 31) && (long long)oh * ow * c < (1LL << 31),
+               "ad_upconv_gather_fwd: an image of 2 GiB or more");
     GatherArgs a;
     a.y = (const char*)ybank; a.bias = bias; a.out = (char*)out;
     a.sy = sy; a.wy = wy; a.sx = sx; a.wx = wx;
     a.h = h; a.w = w; a.oh = oh; a.ow = ow; a.c = c; a.relu = relu;
     AD_REQUIRE(window == 3 || window == 4, "ad_upconv_gather_fwd: window=%d (3: sy advances by at most 1 over two rows; 4: by 2)", window);
-    // strips: long enough to amortise the four window rows a strip starts with, short enough to fill the chip (>= ~16
-    // workgroups per CU in all)
-    const int bx = (ow * (c / (ept / 2)) + 255) / 256;           // 8-byte channel vectors
+    a.slab = (slab_cols * 9 * c * tsz + 15) / 16 * 16;
+    const int nsl = (a.slab / 16 + 255) / 256;                                // staging slots per thread: 1 .. 8
+    // strips: long enough to amortise the window rows a strip starts with, short enough to fill the chip
+    const int nox = 256 / (c / ept);
+    const int bx = (ow + nox - 1) / nox;
     int rows = 64;
     while (rows > 16 && (long long)bx * ((oh + rows - 1) / rows) * n < 4096) rows /= 2;
     a.rows = rows;
     dim3 grid(bx, (oh + rows - 1) / rows, n);
-    if (window == 3) { AD_DISPATCH_DTYPE(dtype, T_, upconv_gather_fwd_kernel<T_, 3><<<grid, 256, 0, (hipStream_t)stream>>>(a);) }
-    else { AD_DISPATCH_DTYPE(dtype, T_, upconv_gather_fwd_kernel<T_, 4><<<grid, 256, 0, (hipStream_t)stream>>>(a);) }
+    const size_t lds = 2 * (size_t)a.slab + GF_MAXROWS * 48 + GF_MAXROWS * 4;
+    hipStream_t s = (hipStream_t)stream;
+#define GF_LAUNCH(GW_, NSL_) { AD_DISPATCH_DTYPE(dtype, T_, upconv_gather_fwd_kernel<T_, GW_, NSL_><<<grid, 256, lds, s>>>(a);) }
+    if (lds > 64 * 1024) {      // the 12-slot variants stage up to 2 x 48 KB
+        AD_DISPATCH_DTYPE(dtype, T_, (void)hipFuncSetAttribute(reinterpret_cast<const void*>(upconv_gather_fwd_kernel<T_, 3, 12>), hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
+                          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(upconv_gather_fwd_kernel<T_, 4, 12>), hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);)
+    }
+    if (window == 3) { if (nsl <= 2) GF_LAUNCH(3, 2) else if (nsl <= 4) GF_LAUNCH(3, 4) else if (nsl <= 8) GF_LAUNCH(3, 8) else GF_LAUNCH(3, 12) }
+    else { if (nsl <= 2) GF_LAUNCH(4, 2) else if (nsl <= 4) GF_LAUNCH(4, 4) else if (nsl <= 8) GF_LAUNCH(4, 8) else GF_LAUNCH(4, 12) }
+#undef GF_LAUNCH
     AD_LAUNCH_CHECK("ad_upconv_gather_fwd");
     return AD_OK;
 }

@@ -487,8 +487,8 @@ class Model:
                     continue
                 cs, lvl = step[1], step[2]
                 src = self.sizes[lvl + 1]
-                if (src >= self.FACTORED_MIN_SOURCE and cs.cin % 128 == 0 and cs.cout % 64 == 0
-                        and self._upconv_tables(src, cs.hw).ok):
+                if (src >= int(os.environ.get("ADUNET_FACTORED_MIN_SOURCE", self.FACTORED_MIN_SOURCE)) and cs.cin % 128 == 0 and cs.cout % 64 == 0
+                        and self._upconv_tables(src, cs.hw).ok and self._upconv_tables(src, cs.hw).gather_fwd_ok(cs.cout, self.dtype)):
                     names.append(cs.name)
         self._factored_names = names
         return names

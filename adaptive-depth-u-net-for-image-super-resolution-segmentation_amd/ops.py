@@ -412,6 +412,7 @@ class UpconvTables:
         if not self.ok:
             return
         self.window = 3 if len(fy[0]) < 3 or int((fy[0][2:] - fy[0][:-2]).max()) <= 1 else 4
+        self._sx_host, self._slab_cols = np.asarray(fx[0], np.int64), {}
         ty, tx = rt.aa_spans_transposed(h, oh), rt.aa_spans_transposed(w, ow)
         self.kyt, self.kxt = ty[1].shape[1], tx[1].shape[1]
         self.ok = bool(_lib.load().ad_upconv_gather_bwd_supported(self.kxt)) and self.kyt <= 30
@@ -420,6 +421,24 @@ class UpconvTables:
         dev_f = lambda a: torch.tensor(np.ascontiguousarray(a, dtype=np.float32), device=device)
         self.sy, self.wy, self.sx, self.wx = dev_i(fy[0]), dev_f(fy[1]), dev_i(fx[0]), dev_f(fx[1])
         self.ryt, self.wyt, self.cxt, self.wxt = dev_i(ty[0]), dev_f(ty[1]), dev_i(tx[0]), dev_f(tx[1])
+
+
+    def slab_cols(self, nox: int) -> int:
+        """Most low-resolution columns that `nox` adjacent output columns and their +-1 neighbours read (the piece of a bank
+        row one workgroup of ad_upconv_gather_fwd stages in LDS)."""
+        if nox not in self._slab_cols:
+            sx, ow, w = self._sx_host, self.ow, self.w
+            ox0 = np.arange(0, ow, nox)
+            lo = sx[np.maximum(ox0 - 1, 0)]
+            hi = np.minimum(sx[np.minimum(ox0 + nox, ow - 1)] + 1, w - 1)
+            self._slab_cols[nox] = int((hi - lo + 1).max())
+        return self._slab_cols[nox]
+
+    def gather_fwd_ok(self, c: int, dtype: torch.dtype) -> bool:
+        ept = 4 if dtype != torch.float32 else 2
+        if c % ept or 256 % (c // ept):
+            return False
+        return bool(_lib.load().ad_upconv_gather_fwd_supported(c, self.slab_cols(256 // (c // ept)), dt(dtype)))
 
 
 def pw_supported(m: int, k: int, n: int, dtype: torch.dtype) -> bool:
@@ -457,9 +476,12 @@ def upconv_gather_fwd(ybank: torch.Tensor, bias: Optional[torch.Tensor], tab: Up
     c = c9 // 9
     assert (h, w) == (tab.h, tab.w)
     out = torch.empty((n, tab.oh, tab.ow, c), dtype=ybank.dtype, device=ybank.device)
+    ept = 4 if ybank.dtype != torch.float32 else 2
+    if c % ept or 256 % (c // ept):
+        raise ValueError(f"upconv_gather_fwd: {c} channels (a divisor of {256 * ept} in steps of {ept} is needed)")
     with _timed("upconv_gather_fwd", 0.0, float((ybank.numel() + out.numel()) * ybank.element_size())):
         check(_lib.load().ad_upconv_gather_fwd(_p(ybank), _p(bias), _p(out), _p(tab.sy), _p(tab.wy), _p(tab.sx), _p(tab.wx),
-                                               tab.window, n, h, w, tab.oh, tab.ow, c, int(relu), dt(ybank.dtype), _stream()),
+                                               tab.window, tab.slab_cols(256 // (c // ept)), n, h, w, tab.oh, tab.ow, c, int(relu), dt(ybank.dtype), _stream()),
               "ad_upconv_gather_fwd")
     return out
 

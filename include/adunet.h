@@ -374,7 +374,9 @@ int ad_resample_ln_bwd(const void* d_low, const void* dskip, const void* z, cons
  *   ad_upconv_gather_fwd   out[n,oy,ox,c] = act(bias[c] + sum_{dy,dx in -1..1} [oy+dy, ox+dx inside] sum_{a,b<2}
  *                              wy[2(oy+dy)+a] wx[2(ox+dx)+b] ybank[n, sy[oy+dy]+a, sx[ox+dx]+b, (dy+1)*3+(dx+1), c])
  *                     two-tap tables of the up-resize (second index clamped where its weight is 0), fp32 arithmetic;
- *                     sy non-decreasing with sy[r+1] - sy[r-1] <= window - 2, window in {3, 4} low-resolution rows.
+ *                     sy non-decreasing with sy[r+1] - sy[r-1] <= window - 2, window in {3, 4} low-resolution rows;
+ *                     slab_cols = the most low-resolution columns any group of 256 / (c / V) adjacent output columns (and
+ *                     their +-1 neighbours) reads, V = channels per 8 bytes: the piece of a bank row a workgroup stages in LDS.
  *   ad_upconv_gather_bwd   dybank = gather^T(g): tables of the TRANSPOSED resize (first reading row / column and kyt / kxt
  *                     weights per low-resolution index); kxt as ad_upconv_gather_bwd_supported() accepts. */
 int ad_pw_supported(int64_t m, int k, int n, int dtype);
@@ -389,9 +391,10 @@ int ad_pw_wgrad_supported(int64_t m, int cin, int cout, int dtype);
 size_t ad_pw_wgrad_ws_bytes(int64_t m, int cin, int cout);
 int ad_pw_wgrad(const void* x, const void* dybank, float* dw_hwio, int64_t m, int cin, int cout, void* ws, size_t ws_bytes,
                 int dtype, void* stream);
+int ad_upconv_gather_fwd_supported(int c, int slab_cols, int dtype);
 int ad_upconv_gather_fwd(const void* ybank, const float* bias, void* out, const int* sy, const float* wy,
-                         const int* sx, const float* wx, int window, int n, int h, int w, int oh, int ow, int c, int relu,
-                         int dtype, void* stream);
+                         const int* sx, const float* wx, int window, int slab_cols, int n, int h, int w, int oh, int ow,
+                         int c, int relu, int dtype, void* stream);
 int ad_upconv_gather_bwd_supported(int kxt);
 int ad_upconv_gather_bwd(const void* g, void* dybank, const int* ryt, const float* wyt, int kyt, const int* cxt,
                          const float* wxt, int kxt, int n, int h, int w, int oh, int ow, int c, int dtype,

@@ -65,6 +65,8 @@ GATHER = [  # n, h, H, c
     (1, 9, 15, 64),
     (1, 7, 7, 64),         # identity resize
     (1, 5, 23, 64),        # ratio 4.6: ten transposed taps
+    (2, 34, 56, 512),      # two output columns per workgroup, a 36 KB row piece: the 12-slot staging variant
+    (1, 6, 10, 256),
 ]
 
 
@@ -76,6 +78,9 @@ def test_gather_forward_and_transpose(device, dtype, case):
     rng = np.random.default_rng(sum(case))
     tab = ops.UpconvTables(h, h, hh, hh, device)
     assert tab.ok
+    if not tab.gather_fwd_ok(c, dtype):          # (fp32 with 512 channels: the row piece exceeds the staging window;
+        assert dtype == F32 and c >= 512         #  the model then keeps the resize -> conv pair for that level)
+        pytest.skip("row piece larger than the kernel stages")
     yb = rnd(rng.standard_normal((n, h, h, 9, c)), dtype)
     b = rng.standard_normal(c).astype(np.float32).astype(np.float64)
     want = ref.upconv_gather_fwd(yb, b, hh, hh)
