@@ -279,7 +279,8 @@ def conv3x3_ln_relu_fwd(x1: torch.Tensor, x2: Optional[torch.Tensor], w_packed: 
     lib = _lib.load()
     need = lib.ad_conv3x3_fwd_ws_bytes(n, h, w, c1 + c2, cout, dt(x1.dtype))
     ws = _conv_workspace(x1.device, need) if need else None
-    with _timed("conv3x3_ln_relu_fwd", 2.0 * n * h * w * 9 * (c1 + c2) * cout):   # fused launches, own family
+    with _timed("conv3x3_ln_relu_fwd", 2.0 * n * h * w * 9 * (c1 + c2) * cout,    # fused launches, own family
+                float(n * h * w * ((c1 + c2 + 2 * cout) * x1.element_size() + 8))):
         check(lib.ad_conv3x3_ln_relu_fwd(_p(x1), c1, _p(x2), c2, _p(w_packed), _p(bias), _p(gamma), _p(beta), eps,
                                          _p(z), _p(act), _p(mean), _p(rstd), n, h, w, cout,
                                          ws.ptr if ws else None, ws.nbytes if ws else 0, dt(x1.dtype), _stream()),
@@ -303,7 +304,7 @@ def conv3x3_c3_ln_relu_fwd(x: torch.Tensor, w_hwio: torch.Tensor, bias: Optional
     act = torch.empty_like(z)
     mean = torch.empty(n * h * w, dtype=torch.float32, device=x.device)
     rstd = torch.empty(n * h * w, dtype=torch.float32, device=x.device)
-    with _timed("conv3x3_c3_ln_relu_fwd", 2.0 * n * h * w * 27 * 64):
+    with _timed("conv3x3_c3_ln_relu_fwd", 2.0 * n * h * w * 27 * 64, float(n * h * w * (12 + 2 * 64 * z.element_size() + 8))):
         check(_lib.load().ad_conv3x3_c3_ln_relu_fwd(_p(x), _p(w_hwio), _p(bias), _p(gamma), _p(beta), eps, _p(z), _p(act),
                                                     _p(mean), _p(rstd), n, h, w, dt(dtype), _stream()),
               "ad_conv3x3_c3_ln_relu_fwd")

@@ -75,7 +75,7 @@ def pmc_record(workload, dtype, batch):
     import glob
     import re
     cands = glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json"))
-    cands.sort(key=lambda p: int(re.search(r"r(\d+)_pmc_traffic", os.path.basename(p)).group(1)))     # r10 after r02
+    cands.sort(key=lambda p: (int(re.search(r"r(\d+)\w*_pmc_traffic", os.path.basename(p)).group(1)), p))   # r10 after r02
     if (workload, dtype, batch) != ("K2p", "bf16", 64) or not cands:
         return None
     with open(cands[-1]) as f:

@@ -1,0 +1,28 @@
+#!/bin/bash
+# Evidence for profiles/ in one gpurun call (on the GPU box): tools/evidence.sh <tag>   e.g. tools/evidence.sh r03
+#   1. two single-counter PMC passes (FETCH_SIZE, WRITE_SIZE) over 3 eager train steps of the headline workload
+#   2. the plain bench line with the per-op-family table (un-profiled; this is the number that counts)
+#   3. the same bench under rocprofv3 --kernel-trace --stats
+#   4. breakdown tables of the reference's own Experiment-2 shapes
+# Everything lands in gpurun_out/<tag>/; copy what is to be judged into profiles/ afterwards.
+set -o pipefail
+tag=${1:-r03}
+out=gpurun_out/$tag
+mkdir -p "$out"
+root=${GRAFT_REPO_ROOT:-$PWD}
+cd /tmp && export TMPDIR=/tmp && cd "$root"
+for ctr in FETCH_SIZE WRITE_SIZE; do
+    d=$out/pmc_$(echo $ctr | tr 'A-Z' 'a-z')
+    rm -rf "$d"
+    rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d "$d" -- python3 bench.py --eager --steps 2 --warmup 1 --no-cpu-baseline --no-micro > "$out/pmc_$ctr.log" 2>&1 || exit 1
+done
+python3 tools/pmc_summary.py "$out/pmc_fetch_size" "$out/pmc_write_size" "$out/pmc_traffic.json" 3 > "$out/pmc_summary.txt" || exit 1
+cp "$out/pmc_traffic.json" profiles/${tag}_pmc_traffic.json          # bench.py quotes it (stamped) from here on
+python3 bench.py --breakdown > "$out/bench.json" 2> "$out/op_breakdown.txt" || exit 1
+rm -rf "$out/prof"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof" -- python3 bench.py --no-cpu-baseline > "$out/bench_under_rocprof.json" 2> "$out/bench_under_rocprof.err" || exit 1
+cp "$(ls $out/prof/*/*_kernel_stats.csv | head -1)" "$out/kernel_stats.csv"
+for w in E2s06 E2s07; do
+    python3 bench.py --workload $w --steps 10 --warmup 3 --breakdown --no-cpu-baseline --no-micro > "$out/bench_$w.json" 2> "$out/op_breakdown_$w.txt" || exit 1
+done
+tail -3 "$out/pmc_summary.txt"; cat "$out/bench.json" | head -c 600; echo
