@@ -186,3 +186,19 @@ def test_oracle_softmax_head_of_build_unet():
     # one class: unchanged sigmoid head
     o1 = SegUNetOracle(16, 8, 2, "ln", "convT")
     assert o1.param_shapes["mask_logits/kernel"] == (1, 1, 8, 1)
+
+
+def test_multitask_routing_follows_the_experiment_table():
+    """Config 5's per-sample depth (adunet_amd.multitask): the Experiment-2 table of
+    run_experiment_adaptive_depth.sh:47-55 where it has a row, the reference's heuristic elsewhere, clamped to 2..6."""
+    from adunet_amd import multitask as M
+    from adunet_amd.run_experiment_adaptive_depth import DEPTH_FOR_SCALE
+    assert {f"{s:.2f}": d for s, d in M.EXPERIMENT2_DEPTH.items()} == DEPTH_FOR_SCALE
+    assert [M.route_depth(s) for s in (0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8)] == [2, 2, 3, 3, 4, 5, 5]       # 0.2: table says 1, clamped
+    assert M.route_depth(0.45) == 4 and M.route_depth(0.25) == 2 and M.route_depth(0.9) == 6               # heuristic, clamped
+    with pytest.raises(ValueError):
+        M.route_depth(1.5)
+    rng = np.random.default_rng(0)
+    samples = [(s, rng.random((8, 8, 3)), rng.random((8, 8, 3))) for s in (0.5, 0.3, 0.5, 0.6, 0.5)]
+    got = [(k, a.shape[0]) for k, a, _ in M.bucket_by_depth(samples, batch_size=2)]
+    assert got == [((0.5, 3), 2), ((0.5, 3), 1), ((0.3, 2), 1), ((0.6, 4), 1)]

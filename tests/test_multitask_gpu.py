@@ -1,0 +1,82 @@
+"""BASELINE config 5 (adaptive per-sample depth 2-6, mixed SR + seg multitask, fp16) as adunet_amd.multitask defines it.
+The reference has no such code path (one static graph per run, independent models per depth,
+Super_resolution/sbatch_scripts/run_experiment_adaptive_depth.sh:47-55), so there is no oracle for the schedule: the tests
+are properties -- every routed sub-step is BITWISE the stand-alone model's step (whose arithmetic the other test files
+check against the oracle), the models of the bank do not disturb each other, and the precision policy is the reference's
+mixed_float16 with per-model dynamic loss scaling."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+P = 32
+
+
+def sr_batch(rng, n=2):
+    hr = rng.random((n, P, P, 3), dtype=np.float32)
+    lr = np.clip(hr + 0.05 * rng.standard_normal(hr.shape).astype(np.float32), 0, 1).astype(np.float32)
+    return lr, hr
+
+
+def seg_batch(rng, n=2):
+    return rng.random((n, P, P, 3), dtype=np.float32), (rng.random((n, P, P, 1)) < 0.4).astype(np.float32)
+
+
+def standalone_sr(scale, depth, dtype, device):
+    from adunet_amd.model import Adam, build_losses_and_metrics, build_super_resolution_unet
+    m, _ = build_super_resolution_unet(scale, depth_override=depth, input_size=P, dtype=dtype, device=device, seed=1234)
+    loss, metrics = build_losses_and_metrics("charbonnier")
+    m.compile(optimizer=Adam(learning_rate=1e-3), loss=loss, metrics=metrics)
+    return m
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("graphed", [False, True])
+def test_interleaved_tasks_equal_the_stand_alone_models(device, dtype, graphed):
+    from adunet_amd import multitask as M, seg_model as S
+    from adunet_amd.model import LossScaleOptimizer
+    rng = np.random.default_rng(3)
+    bank = M.AdaptiveDepthBank(input_size=P, dtype=dtype, device=device, learning_rate=1e-3, seg_depth=2)
+    a1, a2, b1, s1, s2 = sr_batch(rng), sr_batch(rng), sr_batch(rng), seg_batch(rng), seg_batch(rng)
+    stream = [("sr", 0.5, *a1), ("seg", *s1), ("sr", 0.3, *b1), ("sr", 0.5, *a2), ("seg", *s2)]
+    hist = bank.fit(stream, graphed=graphed)
+    torch.cuda.synchronize()
+    assert {k: len(v) for k, v in hist.items()} == {("sr", 0.5, 3): 2, ("sr", 0.3, 2): 1, ("seg",): 2}
+    assert bank.steps == {("sr", 0.5, 3): 2, ("sr", 0.3, 2): 1, ("seg",): 2}
+    # the routed steps, replayed on stand-alone models with the same seed: bitwise the same parameters afterwards
+    ref = standalone_sr(0.5, 3, dtype, device)
+    ref.train_on_batch(*a1)
+    ref.train_on_batch(*a2)
+    assert torch.equal(ref.P, bank.sr[(0.5, 3)].P)
+    ref2 = standalone_sr(0.3, 2, dtype, device)
+    ref2.train_on_batch(*b1)
+    assert torch.equal(ref2.P, bank.sr[(0.3, 2)].P)
+    proto = S.PROTOCOLS["A"]
+    seg = S.build_adaptive_depth_unet(P, 64, 2, dtype=dtype, device=device, seed=1234)
+    seg.compile(optimizer=S.build_optimizer(proto, 100, 1), loss=proto.loss_builder())
+    seg.train_on_batch(*s1)
+    seg.train_on_batch(*s2)
+    assert torch.equal(seg.P, bank.seg.P)
+    # precision policy: mixed_float16 wraps every model's optimizer in a dynamic LossScaleOptimizer, bf16 does not
+    for m in bank.models():
+        assert isinstance(m.optimizer, LossScaleOptimizer) == (dtype == torch.float16)
+    assert all(np.isfinite(v).all() for v in hist.values())
+
+
+def test_bucketed_stream_trains_one_model_per_depth(device):
+    """A mixed stream of per-sample scales, bucketed: every batch goes to the model of its (scale, depth); depths 2-6 only."""
+    from adunet_amd import multitask as M
+    rng = np.random.default_rng(5)
+    scales = [0.5, 0.3, 0.5, 0.5, 0.3, 0.5, 0.3]
+    samples = [(s,) + tuple(t[0] for t in sr_batch(rng, 1)) for s in scales]
+    bank = M.AdaptiveDepthBank(input_size=P, dtype=torch.bfloat16, device=device)
+    seen = []
+    for key, lr, hr in M.bucket_by_depth(samples, batch_size=2, input_size=P):
+        out = bank.train_on_batch("sr", key[0], lr, hr)
+        seen.append((out[0], lr.shape[0]))
+        assert np.isfinite(float(out[1]))
+    assert seen == [((0.5, 3), 2), ((0.3, 2), 2), ((0.5, 3), 2), ((0.3, 2), 1)]
+    assert set(bank.sr) == {(0.5, 3), (0.3, 2)}
+    with pytest.raises(ValueError):
+        bank.train_on_batch("detect", 0.5, *sr_batch(rng))
