@@ -701,7 +701,12 @@ __device__ __forceinline__ void ws_pack_tile(const f32x4 (&acc)[4][4], const flo
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, mean), rsm, so, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, rstd), rsr, so, 0, 0);
         }
-        const f32x2 mean2 = {mean, mean}, rstd2 = {rstd, rstd};
+        // normalisation as two fused multiply-adds per pair, xhat = v * rstd + (-mean * rstd), y = xhat * gamma + beta
+        // (r03; subtract / multiply / fma before: one packed instruction per pair less), ReLU on the PACKED 16-bit result
+        // (v_pk_max_i16 against 0: a set sign bit is a negative int16 for bf16 and half alike) instead of one v_med3 per
+        // element: 64 of ~436 VALU instructions per item
+        const f32x2 rstd2 = {rstd, rstd}, nmr2 = {-mean * rstd, -mean * rstd};
+        typedef short s16x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
         for (int np = 0; np < 2; ++np) {
             union { typename Half16<E>::v4 h; u32x2 u; } pa, pb, qa, qb;
@@ -720,10 +725,12 @@ __device__ __forceinline__ void ws_pack_tile(const f32x4 (&acc)[4][4], const flo
                 pa.h[2 * h] = (E)va.x; pa.h[2 * h + 1] = (E)va.y;
                 pb.h[2 * h] = (E)vb.x; pb.h[2 * h + 1] = (E)vb.y;
                 if (EPI == 2) {
-                    const f32x2 ya = relu2(__builtin_elementwise_fma((va - mean2) * rstd2, h ? ga.zw : ga.xy, h ? ba.zw : ba.xy));
-                    const f32x2 yb = relu2(__builtin_elementwise_fma((vb - mean2) * rstd2, h ? gb4.zw : gb4.xy, h ? bb.zw : bb.xy));
+                    const f32x2 ya = __builtin_elementwise_fma(__builtin_elementwise_fma(va, rstd2, nmr2), h ? ga.zw : ga.xy, h ? ba.zw : ba.xy);
+                    const f32x2 yb = __builtin_elementwise_fma(__builtin_elementwise_fma(vb, rstd2, nmr2), h ? gb4.zw : gb4.xy, h ? bb.zw : bb.xy);
                     qa.h[2 * h] = (E)ya.x; qa.h[2 * h + 1] = (E)ya.y;
                     qb.h[2 * h] = (E)yb.x; qb.h[2 * h + 1] = (E)yb.y;
+                    qa.u[h] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, qa.u[h]), s16x2{0, 0}));
+                    qb.u[h] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, qb.u[h]), s16x2{0, 0}));
                 }
             }
             const u32x2 s0 = __builtin_amdgcn_permlane16_swap(pa.u[0], pb.u[0], false, false);
@@ -1035,7 +1042,10 @@ __device__ __forceinline__ void ws_mma_role_lnb(const ConvArgs& a, const char* x
         // bf16: the second half's operands are fetched here, behind the arithmetic of the first two m-tiles (471 us per
         // full-resolution launch; fetched after the first m-tile: 488 us).  fp16 needs more conversion temporaries and
         // spills with that many registers live: it fetches after the first m-tile (234 registers, no spill).
-        constexpr bool FETCH_EARLY = !ad_same_type<E, f16_t>::value;
+        // r03: with the normalisation / dz arithmetic folded into fused multiply-adds (below) the early fetch no longer fits
+        // bf16 either (256 registers + 60 bytes of scratch: 566 us); fetched after the first m-tile, both types run without
+        // spills, bf16 at 458 us against 465 us for the r02 arithmetic with the early fetch (same box, tools/time_lnb.py)
+        constexpr bool FETCH_EARLY = false;
         if (FETCH_EARLY) {
             __builtin_amdgcn_sched_barrier(0);
             fetch(2);
@@ -1050,7 +1060,7 @@ __device__ __forceinline__ void ws_mma_role_lnb(const ConvArgs& a, const char* x
             }
             const unsigned pvo_mt = pvo_of(mt);
             const bool valid = pvo_mt != WR_OOB;
-            const float mean = mu[mt], rstd = rs[mt];
+            const float rstd = rs[mt], nmr = -mu[mt] * rstd;     // xhat = z * rstd + (-mean * rstd): one fma per element (r03)
             float xh[16], gg[16];
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -1062,7 +1072,7 @@ __device__ __forceinline__ void ws_mma_role_lnb(const ConvArgs& a, const char* x
                 zz.u = zq[mt * 4 + nt];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float h = ((float)zz.h[q] - mean) * rstd;
+                    const float h = fmaf((float)zz.h[q], rstd, nmr);
                     const float yv = h * gaa[q] + bea[q];
                     const float dl = (valid && yv > 0.f) ? acc[mt][nt][q] : 0.f;
                     cg[nt * 4 + q] += dl * h;
@@ -1074,16 +1084,17 @@ __device__ __forceinline__ void ws_mma_role_lnb(const ConvArgs& a, const char* x
                     gg[nt * 4 + q] = gv;
                 }
             }
-            s1 = sum_lane_groups(s1) * (1.f / 64.f);
-            s2 = sum_lane_groups(s2) * (1.f / 64.f);
+            // dz = rstd (g - mean(g) - xhat mean(g xhat)) as two fused multiply-adds per element on per-pixel products (r03)
+            s1 = sum_lane_groups(s1) * (-rstd / 64.f);
+            s2 = sum_lane_groups(s2) * (-rstd / 64.f);
 #pragma unroll
             for (int np = 0; np < 2; ++np) {
                 union { h4 h; u32x2 u; } pa, pb;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int ja = (2 * np) * 4 + q, jb = (2 * np + 1) * 4 + q;
-                    pa.h[q] = (E)(rstd * (gg[ja] - s1 - xh[ja] * s2));
-                    pb.h[q] = (E)(rstd * (gg[jb] - s1 - xh[jb] * s2));
+                    pa.h[q] = (E)fmaf(xh[ja], s2, fmaf(gg[ja], rstd, s1));
+                    pb.h[q] = (E)fmaf(xh[jb], s2, fmaf(gg[jb], rstd, s1));
                     cz[ja] += (float)pa.h[q];           // the conv bias gradient sums dz as stored (what wgrad sees)
                     cz[jb] += (float)pb.h[q];
                 }
