@@ -707,6 +707,7 @@ __device__ __forceinline__ void ws_pack_tile(const f32x4 (&acc)[4][4], const flo
         // element: 64 of ~436 VALU instructions per item
         const f32x2 rstd2 = {rstd, rstd}, nmr2 = {-mean * rstd, -mean * rstd};
         typedef short s16x2 __attribute__((ext_vector_type(2)));
+        typedef E e16x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
         for (int np = 0; np < 2; ++np) {
             union { typename Half16<E>::v4 h; u32x2 u; } pa, pb, qa, qb;
@@ -727,10 +728,11 @@ __device__ __forceinline__ void ws_pack_tile(const f32x4 (&acc)[4][4], const flo
                 if (EPI == 2) {
                     const f32x2 ya = __builtin_elementwise_fma(__builtin_elementwise_fma(va, rstd2, nmr2), h ? ga.zw : ga.xy, h ? ba.zw : ba.xy);
                     const f32x2 yb = __builtin_elementwise_fma(__builtin_elementwise_fma(vb, rstd2, nmr2), h ? gb4.zw : gb4.xy, h ? bb.zw : bb.xy);
-                    qa.h[2 * h] = (E)ya.x; qa.h[2 * h + 1] = (E)ya.y;
-                    qb.h[2 * h] = (E)yb.x; qb.h[2 * h + 1] = (E)yb.y;
-                    qa.u[h] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, qa.u[h]), s16x2{0, 0}));
-                    qb.u[h] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, qb.u[h]), s16x2{0, 0}));
+                    // (built as values, not through the union: writing .h elements and reading .u back in the same iteration
+                    // was folded to the h = 0 pair by hipcc)
+                    const e16x2 ta = {(E)ya.x, (E)ya.y}, tb = {(E)yb.x, (E)yb.y};
+                    qa.u[h] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, ta), s16x2{0, 0}));
+                    qb.u[h] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, tb), s16x2{0, 0}));
                 }
             }
             const u32x2 s0 = __builtin_amdgcn_permlane16_swap(pa.u[0], pb.u[0], false, false);
