@@ -18,6 +18,14 @@ def test_library_exports_every_declared_symbol():
     assert lib.ad_version() >= 1
     assert lib.ad_cin_granule(_lib.AD_BF16) == 32 and lib.ad_cin_granule(_lib.AD_F32) == 16
     assert lib.ad_conv3x3_wgrad_ws_bytes(2, 16, 16, 64, 64, _lib.AD_BF16) > 0
+    # explicit options instead of environment reads inside the library; shape queries of the r03 entry points
+    assert lib.ad_get_option(b"no_map4") == 0 and lib.ad_set_option(b"no_map4", 1) == 0 and lib.ad_get_option(b"no_map4") == 1
+    assert lib.ad_set_option(b"no_map4", 0) == 0 and lib.ad_set_option(b"bogus", 1) != 0 and lib.ad_get_option(b"bogus") == -1
+    assert lib.ad_device_cus() % 64 == 0 and lib.ad_device_cus() >= 64
+    assert lib.ad_pw_supported(4096, 128, 576, _lib.AD_BF16) == 1 and lib.ad_pw_supported(4096, 96, 576, _lib.AD_BF16) == 0
+    assert lib.ad_pw_wgrad_supported(4096, 128, 64, _lib.AD_BF16) == 1 and lib.ad_pw_wgrad_supported(4096, 128, 64, _lib.AD_F32) == 0
+    assert lib.ad_upconv_gather_fwd_supported(64, 7, _lib.AD_BF16) == 1 and lib.ad_upconv_gather_fwd_supported(1024, 4, _lib.AD_BF16) == 0
+    assert lib.ad_upconv_gather_bwd_supported(8) == 1 and lib.ad_upconv_gather_bwd_supported(15) == 0
 
 
 def test_missing_library_fails_loudly(monkeypatch):

@@ -321,7 +321,8 @@ CONFIGS = [
     # depth table :47-55): fractional pyramids through the wave-specialised kernels, odd widths in the skip junctions
     ("E2s06-b8", 0.6, 4, 256, 8, (BF16,)),   # 256/154/93/56/34, 64..1024 channels
     ("E2s06-b2", 0.6, 4, 256, 2, (F32,)),
-    ("E2s07-b2", 0.7, 5, 256, 2, (F32, BF16)),   # 256/180/126/89/63/45, 2048-channel bottleneck (138 M parameters)
+    ("E2s07-b2", 0.7, 5, 256, 2, (BF16,)),       # 256/180/126/89/63/45, 2048-channel bottleneck (138 M parameters)
+    ("E2s07-b1", 0.7, 5, 256, 1, (F32,)),        # (fp32 runs the generic kernels at any batch: one image halves the oracle's work)
 ]
 BIG_LAUNCH_CONFIGS = {"K2p-b8", "E2s06-b8"}              # batch 8: >= 1 work item per CU at full resolution
 CASES = [(c, dt_) for c in CONFIGS for dt_ in c[5]]
