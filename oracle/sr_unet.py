@@ -27,9 +27,16 @@ class Storage:
     runs that Conv2D -> LayerNormalization link as one kernel (statistics from the fp32 accumulators) or as two
     (statistics from the stored conv output); the tests ask the library itself."""
 
-    def __init__(self, round=None, fused=None):
+    def __init__(self, round=None, fused=None, factored=None):
+        """factored(conv) -> bool: the product runs that decoder up-conv in its factored form (nine 1x1 convolutions on the
+        low-resolution map + interpolating gather, ops.upconv_*): the tensor it stores between the two kernels is the bank
+        Y = x W_tap, not the up-resized activation, so that is where this mode rounds."""
         self._round = round
         self._fused = fused
+        self._factored = factored
+
+    def factored(self, conv) -> bool:
+        return False if self._factored is None else bool(self._factored(conv))
 
     def q(self, x):
         return x if self._round is None else self._round(x)
@@ -189,14 +196,21 @@ class SRUNetOracle:
                 skips.append(x)
                 x = q(ops.resize_aa_fwd(x, step[2], step[2]))
             elif kind == "up":
-                h = x.shape[1]
-                tape.append(("up", h))
-                x = q(ops.resize_aa_fwd(x, step[2], step[2]))
+                pending_up = step[2]               # the resize belongs to the up-conv that follows (train_adaptive_unet.py:258-259)
             elif kind == "upconv":
                 conv = step[1]
-                zpre = ops.conv2d_same_fwd(x, q(params[conv + "/kernel"]), params[conv + "/bias"])
-                a = q(ops.relu_fwd(zpre))
-                tape.append(("ca", conv, x, a, zpre))
+                if st.factored(conv):
+                    # same function, other association (ops.upconv_*): the stored intermediate is the 1x1 bank
+                    ybank = q(ops.upconv_bank_fwd(x, q(params[conv + "/kernel"])))
+                    zpre = ops.upconv_gather_fwd(ybank, params[conv + "/bias"], pending_up, pending_up)
+                    a = q(ops.relu_fwd(zpre))
+                    tape.append(("caf", conv, x, a, zpre))
+                else:
+                    tape.append(("up", x.shape[1]))
+                    x = q(ops.resize_aa_fwd(x, pending_up, pending_up))
+                    zpre = ops.conv2d_same_fwd(x, q(params[conv + "/kernel"]), params[conv + "/bias"])
+                    a = q(ops.relu_fwd(zpre))
+                    tape.append(("ca", conv, x, a, zpre))
                 x = a
             elif kind == "concat":
                 skip = skips[step[1]]
@@ -246,6 +260,13 @@ class SRUNetOracle:
                 d, dw, db = ops.conv2d_same_bwd(xin, q(params[conv + "/kernel"]), dz)
                 d = q(d)
                 grads[conv + "/kernel"], grads[conv + "/bias"] = dw, db
+            elif kind == "caf":
+                _, conv, xin, a, zpre = rec
+                dz = ops.relu_bwd(d, a) if kink == 0.0 else d * (zpre > kink)
+                dyb = q(ops.upconv_gather_bwd(dz, xin.shape[1], xin.shape[2]))
+                d, dw = ops.upconv_bank_bwd(xin, q(params[conv + "/kernel"]), dyb)
+                d = q(d)
+                grads[conv + "/kernel"], grads[conv + "/bias"] = dw, dz.reshape(-1, dz.shape[-1]).sum(axis=0)
             elif kind == "concat":
                 _, c1, lvl = rec
                 dskips[lvl] = d[..., c1:]

@@ -46,7 +46,7 @@ def fp16_storage(model, n):
                 fused[cs.name] = True
             else:
                 fused[cs.name] = bool(lib.ad_conv3x3_ln_relu_is_fused(n, cs.hw, cs.hw, c1, c2, cs.cout, ops.dt(model.dtype)))
-    return Storage(ref.fp16_round, lambda conv, *shape: fused[conv])
+    return Storage(ref.fp16_round, lambda conv, *shape: fused[conv], factored=lambda conv: conv in model._factored_upconvs())
 
 
 def rel(got, want):

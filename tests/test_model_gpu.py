@@ -58,7 +58,7 @@ def storage_of(model, n):
                 fused[cs.name] = True                      # dedicated first-layer kernel: always conv + LayerNorm in one
             else:
                 fused[cs.name] = bool(lib.ad_conv3x3_ln_relu_is_fused(n, cs.hw, cs.hw, c1, c2, cs.cout, ops.dt(model.dtype)))
-    return Storage(ref.bf16_round, lambda conv, *shape: fused[conv])
+    return Storage(ref.bf16_round, lambda conv, *shape: fused[conv], factored=lambda conv: conv in model._factored_upconvs())
 
 
 def rel(got, want):

@@ -49,3 +49,21 @@ def test_gather_is_the_transpose_of_its_backward():
     lhs = (ref.upconv_gather_fwd(y, None, 8, 8) * g).sum()
     rhs = (y * ref.upconv_gather_bwd(g, 5, 5)).sum()
     assert abs(lhs - rhs) < 1e-10 * abs(lhs)
+
+
+def test_whole_model_oracle_is_the_same_function_in_factored_form():
+    """SRUNetOracle with every decoder up-conv in the factored association (Storage(factored=...), no rounding) returns
+    the loss and every gradient of the reference graph's form: the two differ only in where a reduced-precision run rounds."""
+    from oracle.sr_unet import SRUNetOracle, Storage
+    rng = np.random.default_rng(0)
+    for scale, depth, p in ((0.5, 2, 32), (0.6, 3, 40)):
+        o = SRUNetOracle(scale, depth, p)
+        params = {k: v.astype(np.float64) for k, v in o.init_params(rng, head_uniform=0.05).items()}
+        hr = rng.random((2, p, p, 3))
+        lr = np.clip(hr + 0.05 * rng.standard_normal(hr.shape), 0, 1)
+        l0, g0, out0, _ = o.loss_and_grads(params, lr, hr)
+        l1, g1, out1, _ = o.loss_and_grads(params, lr, hr, storage=Storage(None, None, factored=lambda conv: True))
+        assert abs(l0 - l1) < 1e-13 and np.abs(out0 - out1).max() < 1e-12
+        assert set(g0) == set(g1)
+        for k in g0:
+            assert np.abs(g0[k] - g1[k]).max() <= 1e-11 * (np.abs(g0[k]).max() + 1e-30), k
