@@ -316,7 +316,7 @@ def conv3x3_c3_wgrad(x: torch.Tensor, dz: torch.Tensor, dw_out: torch.Tensor, ws
     n, h, w, _ = x.shape
     lib = _lib.load()
     ws.ensure(lib.ad_conv3x3_c3_wgrad_ws_bytes(n, h, w))
-    with _timed("conv3x3_c3_wgrad", 2.0 * n * h * w * 27 * 64):
+    with _timed("conv3x3_c3_wgrad", 2.0 * n * h * w * 27 * 64, float(n * h * w * (12 + 64 * dz.element_size()))):
         check(lib.ad_conv3x3_c3_wgrad(_p(x), _p(dz), _p(dw_out), n, h, w, ws.ptr, ws.nbytes, dt(dz.dtype), _stream()),
               "ad_conv3x3_c3_wgrad")
 

@@ -291,9 +291,17 @@ def main():
             cnt = sum(summ.get(k, (0, 0.0))[0] for k in names)
             ms = sum(summ.get(k, (0, 0.0))[1] for k in names) * per_step
             fl = sum(timer.work(k) for k in names) * per_step - minus
+            nb = sum(timer.nbytes(k) for k in names) * per_step
+            # both roofs for every family: MFMA (TFLOP/s, frac of the dense bf16 peak) and HBM (algorithmic bytes -- each
+            # operand tensor once -- over the same time; frac of 8 TB/s).  A family whose `hbm_frac` sits near the ~0.55 a
+            # mixed read / write stream reaches on this part (6.3 TB/s float4 copy = 0.79) is on the HBM roof, whatever its
+            # MFMA fraction says
             return {"launches_per_step": cnt * per_step, "gflop_per_step": fl / 1e9, "ms_per_step": ms,
                     "tflops": fl / ms / 1e9 if ms > 0 else None,
-                    "frac": fl / ms / 1e9 / PEAK_BF16_TFLOPS if ms > 0 else None}
+                    "frac": fl / ms / 1e9 / PEAK_BF16_TFLOPS if ms > 0 else None,
+                    "algorithmic_gb_per_step": nb / 1e9, "hbm_tb_per_s": nb / ms / 1e9 if ms > 0 else None,
+                    "hbm_frac": nb / ms / 1e9 / 8.0 if ms > 0 else None,
+                    "flop_per_byte": fl / nb if nb > 0 else None}
 
         fam = {
             # forward convs and dgrads (the same kernels on the rotated pack) launched WITHOUT the fused LayerNorm epilogue
