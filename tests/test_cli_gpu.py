@@ -145,6 +145,9 @@ def test_bench_plain_and_under_torchrun_agree(device):
         # the line names the conv family with the largest share of the step
         assert rf["family"] == max(rf["families"], key=lambda k: rf["families"][k]["ms_per_step"])
         assert rf["executed_gflop_per_step"] < rf["algorithmic_gflop_per_step"]      # the factored up-convs
+        # both roofs per family: the LayerNorm-forward launches move their operand bytes at 3-6 TB/s (the HBM side of the ridge)
+        assert all({"hbm_tb_per_s", "flop_per_byte", "share_of_step"} <= set(f) for f in rf["families"].values())
+        assert 2.5 < rf["families"]["fused_ln_fwd"]["hbm_tb_per_s"] < 8.0
 
 
 def test_bench_starts_two_gloo_ranks_on_one_gpu(device):
