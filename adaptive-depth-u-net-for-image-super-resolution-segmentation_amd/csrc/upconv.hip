@@ -12,7 +12,8 @@
 //   2. a gather at the high resolution that interpolates and shifts, out[p] = relu(b + sum_tap (U Y_tap)[p + tap])
 //      (upconv_gather_fwd_kernel: fp32 arithmetic, HBM-bound: reads Y through the L2, writes the activation once);
 // and backwards as the transposes: dY = gather^T(dz) (upconv_gather_bwd_kernel), dx = dY Bank^T (pw_gemm_kernel again)
-// and dBank = x^T dY (the 1x1 case of conv3x3_wgrad), re-ordered into the Keras kernel gradient by bank_grad_kernel.
+// and dBank = x^T dY (pw_wgrad_kernel; on the fp32 path the 1x1 case of conv3x3_wgrad + bank_grad_kernel), written
+// straight into the Keras kernel gradient's layout.
 // Neither the up-resized activation (K2' level 0: 1.07 GB per step in bf16) nor its gradient exists in memory: five
 // passes over a full-resolution 2 nf-channel tensor and 15/16 of the up-conv's FLOPs (ratio 4) are gone.
 // Restated tap by tap in oracle/ops.py (upconv_bank_* / upconv_gather_*), whose equality with
@@ -667,7 +668,9 @@ __global__ __launch_bounds__(256) void upconv_gather_fwd_kernel(GatherArgs a) {
 // KYT / KXT rows / columns from there on).  A thread owns one (low-resolution column, channel vector) of one
 // low-resolution row: it walks the KYT + 2 gradient rows that reach that row, forms per row the three horizontally
 // contracted sums (one per dx, from KXT + 2 loads) and adds them to the 3 x 3 tap accumulators with the rows' vertical
-// weights (workgroup-uniform).  KX2 >= kxt + 2 bounds the column window in registers.
+// weights (workgroup-uniform).  KX2 >= kxt + 2 bounds the column window in registers.  (Measured and withdrawn: 8-byte
+// channel vectors as in the forward gather -- 164 instead of 224 registers, a third wave per SIMD, twice the load
+// instructions: 0.274 -> 0.314 ms on the 64 -> 256 level.)
 struct GatherBwdArgs {
     const char* g; char* dy;
     const int* ryt; const float* wyt; int kyt;      // [h], [h][kyt]
