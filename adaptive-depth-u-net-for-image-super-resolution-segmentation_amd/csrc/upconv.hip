@@ -487,6 +487,22 @@ struct GatherArgs {
     int slab;                             // LDS bytes of one staged bank-row piece (multiple of 16)
 };
 
+// Workgroups are dealt to the 8 XCDs round-robin in launch order and every XCD has its own L2: XCD k takes the k-th
+// contiguous eighth of the (x, y, z) grid, so that the strips of the forward gather that share bank rows and columns run
+// behind ONE L2 (3 - 15 % per launch on the Experiment-2 levels, 2 % on the x4 levels).  The transpose does NOT use it: it
+// is bound by its arithmetic, not by the rows adjacent workgroups re-read (2.0x its operand bytes from HBM,
+// profiles/r03_pmc_summary.txt) -- the mapping gave 4 % at batch 64 and cost 25 % at batch 8, where it puts one image
+// on each XCD and all eight walk the same offsets of their images in step.
+__device__ __forceinline__ void xcd_block(int& bx, int& by, int& bz) {
+    const unsigned gx = gridDim.x, gy = gridDim.y, nb = gx * gy * gridDim.z;
+    unsigned l = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const unsigned per = nb >> 3;
+    if (l < per * 8) l = (l & 7) * per + (l >> 3);       // (the last nb % 8 workgroups keep their place)
+    bx = (int)(l % gx);
+    by = (int)((l / gx) % gy);
+    bz = (int)(l / (gx * gy));
+}
+
 constexpr int GF_MAXROWS = 64;
 constexpr int GB_MAXKY = 30;   // most transposed vertical taps the backward gather stages
 
@@ -524,8 +540,10 @@ __global__ __launch_bounds__(256) void upconv_gather_fwd_kernel(GatherArgs a) {
     extern __shared__ __attribute__((aligned(16))) char gsm[];
     const int vecs = a.c / EPT;                        // divides 256 (launcher)
     const int nox = 256 / vecs;                        // output columns of this workgroup
-    const int oy0 = blockIdx.y * a.rows, oy1 = min(oy0 + a.rows, a.oh), nn = blockIdx.z;
-    const int ox0 = blockIdx.x * nox;
+    int bx, by, nn;
+    xcd_block(bx, by, nn);
+    const int oy0 = by * a.rows, oy1 = min(oy0 + a.rows, a.oh);
+    const int ox0 = bx * nox;
     const int oxl = threadIdx.x / vecs, v = threadIdx.x - oxl * vecs;
     const int ox = min(ox0 + oxl, a.ow - 1);
     const bool live = ox0 + oxl < a.ow;
@@ -670,7 +688,10 @@ __global__ __launch_bounds__(256) void upconv_gather_fwd_kernel(GatherArgs a) {
 // contracted sums (one per dx, from KXT + 2 loads) and adds them to the 3 x 3 tap accumulators with the rows' vertical
 // weights (workgroup-uniform).  KX2 >= kxt + 2 bounds the column window in registers.  (Measured and withdrawn: 8-byte
 // channel vectors as in the forward gather -- 164 instead of 224 registers, a third wave per SIMD, twice the load
-// instructions: 0.274 -> 0.314 ms on the 64 -> 256 level.)
+// instructions: 0.274 -> 0.314 ms on the 64 -> 256 level.  Also withdrawn: the gradient rows staged in LDS as in the forward
+// gather, with 16- and with 8-byte vectors at two to four waves per SIMD -- 0.264 / 0.296 against 0.262 ms.  Per wave and row
+// the kernel issues ~250 vector instructions (156 v_pk_fma_f32, the bf16 unpacking, addresses): ~0.13 ms of issue time per
+// launch at two waves per SIMD, which the loads only partly hide; neither fewer load instructions nor more waves moved it.)
 struct GatherBwdArgs {
     const char* g; char* dy;
     const int* ryt; const float* wyt; int kyt;      // [h], [h][kyt]
