@@ -171,6 +171,44 @@ def test_conv3x3_wgrad(device, ws, dtype, shape):
     assert torch.equal(dw, dw2), "wgrad must be bitwise deterministic"
 
 
+# Weight gradients on maps of a few pixels at the channel counts the pyramids' deepest levels have (the x4 pyramid's 4 x 4
+# and 1 x 1 levels, K2's 8 x 8 and 2 x 2).  (r03: a GEMM-form kernel for these -- x^T times nine shifted copies of dz, one
+# launch, no slab -- was measured at 44-50 us against the tiled kernels' 34 us on 64 x 4 x 4, 1 024 -> 512 and withdrawn.)
+SMALL_WGRAD_SHAPES = [
+    (64, 4, 4, 512, 512, 512),   # the x4 pyramid's 4 x 4 decoder level: two inputs, dw written without a slab
+    (64, 4, 4, 512, 0, 512),     # fewer channel blocks: four pixel splits + the slab reduce
+    (64, 1, 1, 1024, 0, 1024),   # 1 x 1 maps: only the centre tap is non-zero
+    (16, 8, 8, 128, 64, 64),     # K2 (P512, b16): 8 x 8; the second input starts on a 64-channel block
+    (16, 2, 2, 256, 0, 128),
+    (7, 3, 5, 64, 64, 64),       # odd extents
+    (1, 1, 1, 64, 0, 64),
+    (3, 16, 16, 64, 0, 128),
+]
+
+
+@pytest.mark.parametrize("dtype", [BF16, F16])
+@pytest.mark.parametrize("shape", SMALL_WGRAD_SHAPES)
+def test_conv3x3_wgrad_small_maps(device, ws, dtype, shape):
+    from adunet_amd import ops
+    n, h, w, c1, c2, cout = shape
+    cin = c1 + c2
+    rng = np.random.default_rng(sum(shape))
+    x = rnd(rng.standard_normal((n, h, w, cin)), dtype)
+    dz = rnd(rng.standard_normal((n, h, w, cout)), dtype)
+    _, want, _ = ref.conv2d_same_bwd(x, np.zeros((3, 3, cin, cout)), dz, need_dx=False)
+    x1 = to_dev(x[..., :c1], dtype, device)
+    x2 = to_dev(x[..., c1:], dtype, device) if c2 else None
+    dzd = to_dev(dz, dtype, device)
+    dw = torch.full((3, 3, cin, cout), float("nan"), dtype=F32, device=device)
+    ops.conv3x3_wgrad(x1, x2, dzd, dw, cin, ws)
+    assert relerr(dw, want) < 1e-3
+    if h == 1 and w == 1:
+        assert float(dw[0].abs().max()) == 0.0 and float(dw[2].abs().max()) == 0.0     # taps off the centre see only padding
+    dw3 = torch.full((3, 3, cin, cout), float("nan"), dtype=F32, device=device)
+    ops.conv3x3_wgrad(x1, x2, dzd, dw3, cin, ws)
+    assert torch.equal(dw, dw3), "wgrad must be bitwise deterministic"
+
+
 def _random_conv_shapes(count):
     rng = np.random.default_rng(2026)
     out = []
