@@ -197,6 +197,11 @@ def main():
         raise SystemExit(launch_ranks(args.gpus))
     if world != args.gpus:
         args.gpus = world
+    # stdout carries exactly ONE line, the JSON record: libraries that write to file descriptor 1 (RCCL prints a version
+    # banner there when its first communicator is created) are pointed at stderr for the rest of the run
+    sys.stdout.flush()
+    record_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     # one rank per GPU; under --backend gloo the ranks may outnumber the GPUs and share them round-robin
     dev_index = local_rank if args.backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(dev_index)
@@ -416,7 +421,7 @@ def main():
             line["micro"] = micro_kernel(device)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(scale, depth, patch, args.workload)
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line), file=record_out, flush=True)
     if use_dist:
         try:
             model._dp.close()

@@ -132,6 +132,9 @@ def test_bench_plain_and_under_torchrun_agree(device):
                                "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py")] + flags,
                               capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert dist_run.returncode == 0, dist_run.stderr[-2000:]
+    # stdout is the ONE JSON line and nothing else (RCCL's version banner, written to file descriptor 1 when the first
+    # communicator is created, is sent to stderr by bench.py)
+    assert len(plain.stdout.strip().splitlines()) == 1 and len(dist_run.stdout.strip().splitlines()) == 1, dist_run.stdout[:2000]
     a = json.loads(plain.stdout.strip().splitlines()[-1])
     b = json.loads(dist_run.stdout.strip().splitlines()[-1])
     assert a["metric"] == b["metric"] and a["config"]["workload"] == b["config"]["workload"] and a["n_gpus"] == b["n_gpus"] == 1
@@ -164,8 +167,8 @@ def test_bench_starts_two_gloo_ranks_on_one_gpu(device):
                           "--warmup", "1", "--batch", "8", "--no-cpu-baseline", "--no-micro"],
                          capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert run.returncode == 0, run.stderr[-3000:]
-    lines = [l for l in run.stdout.strip().splitlines() if l.startswith("{")]
-    assert len(lines) == 1, run.stdout[-2000:]
+    lines = run.stdout.strip().splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), run.stdout[-2000:]
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["ranks"] == 2 and rec["dist_backend"] == "gloo" and "rccl_ranks" not in rec
     assert rec["config"]["global_batch"] == 16 and rec["config"]["parallelism"] == "dp2"
