@@ -317,6 +317,9 @@ CONFIGS = [
     # batch 8: enough tiles for the wave-specialised launches incl. the fused ReLU-grad / LayerNorm-backward dgrads; fp16 is
     # the reference's GPU policy (train_adaptive_unet.py:471-477).  (fp32 runs the generic kernels at any batch: see K2p.)
     ("K2p-b8", 0.25, 4, 256, 8, (BF16, F16)),
+    # BASELINE config 2 as written (P512): pyramid 512/128/32/8/2 -- the 8 x 8 and 2 x 2 levels take other small-map routes than
+    # K2p's 4 x 4 / 1 x 1; two images of 512^2 are as many pixels as K2p-b8
+    ("K2-b2", 0.25, 4, 512, 2, (BF16,)),
     # the reference's own Experiment-2 shapes (Super_resolution/sbatch_scripts/run_experiment_adaptive_depth.sh:36-66,
     # depth table :47-55): fractional pyramids through the wave-specialised kernels, odd widths in the skip junctions
     ("E2s06-b8", 0.6, 4, 256, 8, (BF16,)),   # 256/154/93/56/34, 64..1024 channels
@@ -324,7 +327,7 @@ CONFIGS = [
     ("E2s07-b2", 0.7, 5, 256, 2, (BF16,)),       # 256/180/126/89/63/45, 2048-channel bottleneck (138 M parameters)
     ("E2s07-b1", 0.7, 5, 256, 1, (F32,)),        # (fp32 runs the generic kernels at any batch: one image halves the oracle's work)
 ]
-BIG_LAUNCH_CONFIGS = {"K2p-b8", "E2s06-b8"}              # batch 8: >= 1 work item per CU at full resolution
+BIG_LAUNCH_CONFIGS = {"K2p-b8", "E2s06-b8", "K2-b2"}              # batch 8: >= 1 work item per CU at full resolution
 CASES = [(c, dt_) for c in CONFIGS for dt_ in c[5]]
 
 
