@@ -153,6 +153,21 @@ def micro_kernel(device, iters=50):
     return out
 
 
+# Measured on MI355X at the end of r03 (profiles/r03_clock_power.txt, profiles/r03_mfma_power.txt): every dense conv
+# launch runs at the socket's power cap with the clock lowered to 1.66-2.0 GHz, so its time is its energy.  Idle socket 315 W;
+# an MFMA-only loop 2 050 TFLOP/s at ~1 300 W -> 0.48 pJ per FLOP; a device copy 5.2 TB/s at 859 W -> 104 pJ per HBM byte.
+POWER_MODEL = {"cap_w": 1400.0, "idle_w": 315.0, "pj_per_flop": 0.48, "pj_per_hbm_byte": 104.0,
+               "ridge_flop_per_byte": 104.0 / 0.48,
+               "source": "profiles/r03_clock_power.txt, profiles/r03_mfma_power.txt (rocm-smi; DESIGN 4.7a)"}
+
+
+def power_floor_ms(flop: float, nbytes: float) -> float:
+    """Time the socket's power cap allows for `flop` of bf16 matrix arithmetic plus `nbytes` of HBM traffic (ms)."""
+    m = POWER_MODEL
+    joule = (m["pj_per_flop"] * flop + m["pj_per_hbm_byte"] * nbytes) * 1e-12
+    return joule / (m["cap_w"] - m["idle_w"]) * 1e3
+
+
 def launch_ranks(n: int) -> int:
     """`python -m torch.distributed.run --nnodes=1 --nproc-per-node n ... bench.py <same flags>` as a child process."""
     import socket
@@ -306,7 +321,11 @@ def main():
                     "frac": fl / ms / 1e9 / PEAK_BF16_TFLOPS if ms > 0 else None,
                     "algorithmic_gb_per_step": nb / 1e9, "hbm_tb_per_s": nb / ms / 1e9 if ms > 0 else None,
                     "hbm_frac": nb / ms / 1e9 / 8.0 if ms > 0 else None,
-                    "flop_per_byte": fl / nb if nb > 0 else None}
+                    "flop_per_byte": fl / nb if nb > 0 else None,
+                    # third roof: these launches draw the socket's full power cap (POWER_MODEL): the time their matrix
+                    # arithmetic and HBM bytes cost at the cap, and measured / that
+                    "power_floor_ms_per_step": power_floor_ms(fl, nb),
+                    "frac_of_power_floor": power_floor_ms(fl, nb) / ms if ms > 0 else None}
 
         fam = {
             # forward convs and dgrads (the same kernels on the rotated pack) launched WITHOUT the fused LayerNorm epilogue
@@ -402,6 +421,7 @@ def main():
                          "hbm_gb_per_step": hbm_gb,
                          "hbm_frac": hbm_gb / (ms_step / 1e3) / 8000.0 if hbm_gb else None,
                          "families": fam,
+                         "power_model": POWER_MODEL,
                          "hbm_ops": hbm_ops,
                          "non_conv_ms_per_step": total_ms - conv_ms,
                          "timing": ("HIP events around every launch of %d eager steps run right after the graph-replayed "

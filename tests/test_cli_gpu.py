@@ -151,6 +151,11 @@ def test_bench_plain_and_under_torchrun_agree(device):
         # both roofs per family: the LayerNorm-forward launches move their operand bytes at 3-6 TB/s (the HBM side of the ridge)
         assert all({"hbm_tb_per_s", "flop_per_byte", "share_of_step"} <= set(f) for f in rf["families"].values())
         assert 2.5 < rf["families"]["fused_ln_fwd"]["hbm_tb_per_s"] < 8.0
+        # third roof (the conv launches run at the socket's power cap): no family beats the time its FLOPs and bytes cost at
+        # the cap, the plain conv / wgrad families come close to it
+        assert rf["power_model"]["cap_w"] == 1400.0
+        for name in ("fused_ln_fwd", "wgrad", "dgrad_ln_bwd_fused", "dgrad_relu_fused"):
+            assert 0.3 < rf["families"][name]["frac_of_power_floor"] < 1.05, (name, rf["families"][name])
 
 
 def test_bench_starts_two_gloo_ranks_on_one_gpu(device):
