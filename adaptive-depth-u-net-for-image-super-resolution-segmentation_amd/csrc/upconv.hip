@@ -188,7 +188,7 @@ template <int NW> struct PlGeo {
     static constexpr int WSL = 8 * NT / PL_T;               // bank slots per thread and stage (3 or 2)
 };
 
-template <typename E, int NW>
+template <typename E, int NW, int DEPTH>
 __global__ __launch_bounds__(PL_T, 1) void pw_gemm_lds_kernel(PwArgs a) {
     typedef PwPol<E> P;
     typedef typename P::frag frag;
@@ -222,25 +222,47 @@ __global__ __launch_bounds__(PL_T, 1) void pw_gemm_lds_kernel(PwArgs a) {
         wsrc[i] = (j * a.n + n) * 16;
         wlds[i] = 2 * PL_XB + (j >> 2) * G::WB + ((j & 3) * G::NT + n) * 16;
     }
-    u32x4 xr[4], wr[G::WSL];
+    // DEPTH stages of loads are in flight in registers (DEPTH = 2 where a tile has an even number of k-stages: slots by stage
+    // parity, static): a stage is ~0.9 us of MFMAs per SIMD, less than the latency of its loads when K is long (one stage
+    // ahead: 763 TFLOP/s at K = 1 024)
+    u32x4 xr[DEPTH][4], wr[DEPTH][G::WSL];
     int it = blockIdx.x, iks = 0;                    // cursor of the next stage to issue (tile, k-stage)
-#define PL_ISSUE                                                                                                 \
+#define PL_ISSUE(SLOT)                                                                                           \
     {                                                                                                            \
         const int tq_ = min(it, ntiles - 1);          /* past the end: re-read the last stage, never stored */   \
         const int tm_ = tq_ / tiles_n, tn_ = tq_ - tm_ * tiles_n;                                                \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                          \
             const int mrow_ = tm_ * 256 + xrow[i];                                                               \
-            xr[i] = __builtin_amdgcn_raw_buffer_load_b128(rsx, mrow_ < a.m ? (unsigned)(mrow_ * a.k * 2 + xpart) : PW_OOB, \
-                                                          (unsigned)(iks * 128), 0);                             \
+            xr[SLOT][i] = __builtin_amdgcn_raw_buffer_load_b128(rsx, mrow_ < a.m ? (unsigned)(mrow_ * a.k * 2 + xpart) : PW_OOB, \
+                                                                (unsigned)(iks * 128), 0);                       \
         }                                                                                                        \
         const unsigned wb_ = (unsigned)((iks * 8 * a.n + tn_ * G::NT) * 16);                                     \
         _Pragma("unroll") for (int i = 0; i < G::WSL; ++i)                                                       \
-            wr[i] = __builtin_amdgcn_raw_buffer_load_b128(rsb, (unsigned)wsrc[i], wb_, 0);                       \
+            wr[SLOT][i] = __builtin_amdgcn_raw_buffer_load_b128(rsb, (unsigned)wsrc[i], wb_, 0);                 \
         if (++iks == ks_per_tile) { iks = 0; it += gridDim.x; }                                                  \
+    }
+#define PL_STAGE(SLOT)                                                                                           \
+    {                                                                                                            \
+        char* sb = smem + buf * G::STAGE;                                                                        \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(sb + xlds[i]) = xr[SLOT][i];     \
+        _Pragma("unroll") for (int i = 0; i < G::WSL; ++i) *reinterpret_cast<u32x4*>(sb + wlds[i]) = wr[SLOT][i]; \
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                          \
+        PL_ISSUE(SLOT)                                                                                           \
+        _Pragma("unroll") for (int c = 0; c < 2; ++c) {                                                          \
+            frag xf[4], wf[NW];                                                                                  \
+            _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                     \
+                xf[mt] = *reinterpret_cast<const frag*>(sb + c * PL_XB + xfo + mt * 16 * 96);                    \
+            _Pragma("unroll") for (int nt = 0; nt < NW; ++nt)                                                    \
+                wf[nt] = *reinterpret_cast<const frag*>(sb + c * G::WB + wfo + nt * 256);                        \
+            _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                     \
+                _Pragma("unroll") for (int nt = 0; nt < NW; ++nt) acc[mt][nt] = P::mma(wf[nt], xf[mt], acc[mt][nt]); \
+        }                                                                                                        \
+        buf ^= 1;                                                                                                \
     }
     const int xfo = (wm * 64 + l15) * 96 + grp * 16;                           // + mt * 16 * 96 (+ chunk * PL_XB)
     const int wfo = 2 * PL_XB + (grp * G::NT + wn * NW * 16 + l15) * 16;       // + nt * 256 (+ chunk * WB)
-    PL_ISSUE
+    PL_ISSUE(0)
+    if (DEPTH == 2) PL_ISSUE(DEPTH - 1)
     int buf = 0;
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         f32x4 acc[4][NW];
@@ -248,27 +270,9 @@ __global__ __launch_bounds__(PL_T, 1) void pw_gemm_lds_kernel(PwArgs a) {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < NW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int ks = 0; ks < ks_per_tile; ++ks) {
-            char* sb = smem + buf * G::STAGE;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(sb + xlds[i]) = xr[i];
-#pragma unroll
-            for (int i = 0; i < G::WSL; ++i) *reinterpret_cast<u32x4*>(sb + wlds[i]) = wr[i];
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            PL_ISSUE
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                frag xf[4], wf[NW];
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) xf[mt] = *reinterpret_cast<const frag*>(sb + c * PL_XB + xfo + mt * 16 * 96);
-#pragma unroll
-                for (int nt = 0; nt < NW; ++nt) wf[nt] = *reinterpret_cast<const frag*>(sb + c * G::WB + wfo + nt * 256);
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < NW; ++nt) acc[mt][nt] = P::mma(wf[nt], xf[mt], acc[mt][nt]);
-            }
-            buf ^= 1;
+        for (int ks = 0; ks < ks_per_tile; ks += DEPTH) {
+            PL_STAGE(0)
+            if (DEPTH == 2) PL_STAGE(DEPTH - 1)
         }
         const int tm = t / tiles_n, tn = t - tm * tiles_n;
 #pragma unroll
@@ -285,6 +289,7 @@ __global__ __launch_bounds__(PL_T, 1) void pw_gemm_lds_kernel(PwArgs a) {
         }
     }
 #undef PL_ISSUE
+#undef PL_STAGE
 }
 
 // Bank operands from the fp32 Keras kernel W[3][3][Cin][Cout] (HWIO):
@@ -818,21 +823,26 @@ extern "C" int ad_pw_gemm(const void* x, const void* bank, void* y, int64_t m, i
         const int nw = n % 192 == 0 ? 6 : 4;
         const int ntiles = (int)((m + 255) / 256) * (n / (32 * nw));
         const int grid = ntiles < ad_num_cu() ? ntiles : ad_num_cu();
-        static bool attr = false;
-        if (!attr) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pw_gemm_lds_kernel<bf16_t, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PlGeo<6>::STAGE);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pw_gemm_lds_kernel<f16_t, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PlGeo<6>::STAGE);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pw_gemm_lds_kernel<bf16_t, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PlGeo<4>::STAGE);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pw_gemm_lds_kernel<f16_t, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PlGeo<4>::STAGE);
-            attr = true;
-        }
+        // two stages of loads in flight where a tile has >= 4 k-stages that pair up (K = 128, two stages a tile: 10 % slower)
+        const int depth = (k / 64) % 2 == 0 && k >= 256 ? 2 : 1;
+#define PL_LAUNCH(E_, NW_, D_)                                                                                       \
+    {                                                                                                                \
+        static bool attr_ = false;                                                                                   \
+        if (!attr_) {                                                                                                \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pw_gemm_lds_kernel<E_, NW_, D_>),                \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PlGeo<NW_>::STAGE);            \
+            attr_ = true;                                                                                            \
+        }                                                                                                            \
+        pw_gemm_lds_kernel<E_, NW_, D_><<<grid, PL_T, 2 * PlGeo<NW_>::STAGE, s>>>(a);                                \
+    }
         if (nw == 6) {
-            if (dtype == AD_BF16) pw_gemm_lds_kernel<bf16_t, 6><<<grid, PL_T, 2 * PlGeo<6>::STAGE, s>>>(a);
-            else pw_gemm_lds_kernel<f16_t, 6><<<grid, PL_T, 2 * PlGeo<6>::STAGE, s>>>(a);
+            if (dtype == AD_BF16) { if (depth == 2) PL_LAUNCH(bf16_t, 6, 2) else PL_LAUNCH(bf16_t, 6, 1) }
+            else { if (depth == 2) PL_LAUNCH(f16_t, 6, 2) else PL_LAUNCH(f16_t, 6, 1) }
         } else {
-            if (dtype == AD_BF16) pw_gemm_lds_kernel<bf16_t, 4><<<grid, PL_T, 2 * PlGeo<4>::STAGE, s>>>(a);
-            else pw_gemm_lds_kernel<f16_t, 4><<<grid, PL_T, 2 * PlGeo<4>::STAGE, s>>>(a);
+            if (dtype == AD_BF16) { if (depth == 2) PL_LAUNCH(bf16_t, 4, 2) else PL_LAUNCH(bf16_t, 4, 1) }
+            else { if (depth == 2) PL_LAUNCH(f16_t, 4, 2) else PL_LAUNCH(f16_t, 4, 1) }
         }
+#undef PL_LAUNCH
         AD_LAUNCH_CHECK("ad_pw_gemm (lds)");
         return AD_OK;
     }
