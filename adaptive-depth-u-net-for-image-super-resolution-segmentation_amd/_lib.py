@@ -81,11 +81,13 @@ SIGNATURES = {
     "ad_pw_bank_elems": (_sz, [_i, _i]),
     "ad_pw_bank_pack": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp]),
     "ad_pw_gemm": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
+    "ad_pw_gemm_variant": (_i, [_i64, _i, _i, _i]),
     "ad_pw_bank_grad": (_i, [_vp, _i, _i, _vp, _vp]),
     "ad_pw_wgrad_supported": (_i, [_i64, _i, _i, _i]),
     "ad_pw_wgrad_ws_bytes": (_sz, [_i64, _i, _i]),
     "ad_pw_wgrad": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _sz, _i, _vp]),
     "ad_upconv_gather_fwd_supported": (_i, [_i, _i, _i]),
+    "ad_upconv_slab_cols": (_i, [_vp, _i, _i, _i, _i]),
     "ad_upconv_gather_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "ad_upconv_gather_bwd_supported": (_i, [_i]),
     "ad_upconv_gather_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),

@@ -3,6 +3,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <atomic>
 
 static thread_local char g_err[512] = "";
 
@@ -19,13 +20,20 @@ extern "C" int ad_version(void) { return 1; }
 // ---- the only process-wide state of the library besides the last error string: the CU count of the device (read once)
 // and the options a caller sets explicitly
 int ad_num_cu() {
-    static int ncu = 0;
-    if (ncu == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v >= 64)
+    // per device (a process may drive several, one thread each): the count sizes every persistent grid, workspace and the XCD
+    // tile order.  Relaxed atomics: racing first calls compute the same value.
+    static std::atomic<int> cache[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    const int slot = dev < 16 ? dev : 15;
+    int ncu = cache[slot].load(std::memory_order_relaxed);
+    if (ncu == 0 || dev >= 15) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v >= 64)
             ncu = v / 64 * 64;          // whole groups of 8 XCDs x 8 (the XCD-aware work order deals tiles in such groups)
         else
-            ncu = 256;                  // MI355X / MI350X
+            ncu = 256;                  // no device visible (the CPU-only build check) or fewer than 64 CUs: MI355X / MI350X geometry
+        cache[slot].store(ncu, std::memory_order_relaxed);
     }
     return ncu;
 }

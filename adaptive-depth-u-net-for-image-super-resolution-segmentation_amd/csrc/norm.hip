@@ -85,8 +85,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                                                      T* __restrict__ dz, float* __restrict__ part, int64_t npix, int c) {
     constexpr int EPT = ElemTraits<T>::EPT;
     constexpr int PPB = 256 / G;
+    // G = 128 (4 096 channels in 16 bits: the bottleneck of a depth-6 model): TWO waves own a pixel, so that a thread keeps the
+    // 32 channels of the 2 048-channel case (with one wave per pixel and NV = 8 the five per-channel register arrays alone
+    // are 320 registers: that instantiation spilled 84-92 registers in r03).  The per-pixel sums then cross the wave pair through
+    // LDS, which needs the same number of barriers in every thread: the pixel loop runs a uniform trip count for G = 128.
+    constexpr bool PAIR = G == 128;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = reinterpret_cast<float*>(smem);  // [PPB][3][c]
+    __shared__ float xch[2][4];
     const int tid = threadIdx.x;
     const int gl = tid % G, gp = tid / G;
     float gam[NV][EPT], bet[NV][EPT];
@@ -106,12 +112,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     // blocks per CU already keep the memory system busy and the extra registers cost occupancy -- so U stays 1.
     constexpr int U = 1;
     const int64_t step = (int64_t)gridDim.x * PPB;
-    for (int64_t pix0 = (int64_t)blockIdx.x * PPB + gp; pix0 < npix; pix0 += U * step) {
+    for (int64_t pix0 = (int64_t)blockIdx.x * PPB + gp; PAIR ? pix0 - gp < npix : pix0 < npix; pix0 += U * step) {
         Vec16<T> lz[U][NV], ld[U][NV];
         float mu_u[U], rs_u[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int64_t pix = pix0 + u * step < npix ? pix0 + u * step : pix0;      // past the end: re-read, never stored
+            // past the end: re-read, never stored (PAIR: the second pixel group of the last pass re-reads the first group's pixel)
+            const int64_t pix = pix0 + u * step < npix ? pix0 + u * step : (PAIR ? pix0 - gp : pix0);
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 lz[u][v].load(z + pix * c + (v * G + gl) * EPT);
@@ -123,7 +130,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t pix = pix0 + u * step;
-            if (pix >= npix) break;
+            const bool live = pix < npix;
+            if (!PAIR && !live) break;
             float xh[NV][EPT], g[NV][EPT];
             const float mu = mu_u[u], rs = rs_u[u];
             float s1 = 0.f, s2 = 0.f;
@@ -140,6 +148,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                         float h = (zz[e] - mu) * rs;
                         float yv = h * gam[v][e] + bet[v][e];
                         float dl = (MODE == 0 && !(yv > 0.f)) ? 0.f : dd[e];
+                        if (PAIR && !live) dl = 0.f;
                         xh[v][e] = h;
                         a_g[v][e] += dl * h;
                         a_b[v][e] += dl;
@@ -151,8 +160,18 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                 }
             }
             if (MODE != 2) {
-                s1 = group_sum<G>(s1) * inv_c;
-                s2 = group_sum<G>(s2) * inv_c;
+                if constexpr (PAIR) {
+                    s1 = group_sum<64>(s1);
+                    s2 = group_sum<64>(s2);
+                    if ((tid & 63) == 0) { xch[0][tid >> 6] = s1; xch[1][tid >> 6] = s2; }
+                    __syncthreads();
+                    s1 = (xch[0][2 * gp] + xch[0][2 * gp + 1]) * inv_c;
+                    s2 = (xch[1][2 * gp] + xch[1][2 * gp + 1]) * inv_c;
+                    __syncthreads();
+                } else {
+                    s1 = group_sum<G>(s1) * inv_c;
+                    s2 = group_sum<G>(s2) * inv_c;
+                }
             }
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
@@ -164,11 +183,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                 }
                 Vec16<T> st;
                 st.from_f32(o);
-                st.store(dz + pix * c + (v * G + gl) * EPT);
+                if (!PAIR || live) st.store(dz + pix * c + (v * G + gl) * EPT);
                 float back[EPT];  // dbias sums the values as stored (what the conv wgrad sees)
                 st.to_f32(back);
 #pragma unroll
-                for (int e = 0; e < EPT; ++e) a_z[v][e] += back[e];
+                for (int e = 0; e < EPT; ++e) a_z[v][e] += (PAIR && !live) ? 0.f : back[e];
             }
         }
     }
@@ -220,9 +239,10 @@ struct RowCfg {
     int nv, g;
 };
 
-static bool row_cfg(int c, int ept, RowCfg* r) {
+static bool row_cfg(int c, int ept, RowCfg* r, bool bwd = false) {
     if (c <= 0 || c % ept) return false;
     int vecs = c / ept;
+    if (bwd && ept == 8 && vecs == 512) { r->nv = 4; r->g = 128; return true; }     // two waves per pixel (ln_bwd_kernel, PAIR)
     int nv = (vecs + 63) / 64;
     if (nv != 1 && nv != 2 && nv != 4 && nv != 8) return false;
     if (vecs % nv) return false;
@@ -258,6 +278,17 @@ static int bwd_blocks(int64_t npix, int g) {
         default: { constexpr int NV_ = 8; constexpr int G_ = 64; __VA_ARGS__ } break; \
     }
 
+// backward: 8 vectors per thread exist for fp32 only (32 channels per thread; 16-bit rows of that width take g = 128, nv = 4)
+#define DISPATCH_NVG_BWD(...)                                                      \
+    switch (cfg.nv) {                                                              \
+        case 1: { constexpr int NV_ = 1; DISPATCH_G(__VA_ARGS__) } break;          \
+        case 2: { constexpr int NV_ = 2; constexpr int G_ = 64; __VA_ARGS__ } break; \
+        case 4: { constexpr int NV_ = 4;                                           \
+                  if (cfg.g == 128) { if constexpr (sizeof(T) == 2) { constexpr int G_ = 128; __VA_ARGS__ } }       \
+                  else { constexpr int G_ = 64; __VA_ARGS__ } } break;             \
+        default: { if constexpr (sizeof(T) == 4) { constexpr int NV_ = 8; constexpr int G_ = 64; __VA_ARGS__ } } break; \
+    }
+
 template <typename T>
 int ln_fwd_launch(const void* z, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                   int64_t npix, int c, float eps, int relu, hipStream_t s) {
@@ -277,13 +308,13 @@ int ln_bwd_launch(const void* dy, const void* z, const float* mean, const float*
                   const float* beta, void* dz, float* dgamma, float* dbeta, float* dbias, int64_t npix, int c,
                   void* ws, size_t ws_bytes, hipStream_t s) {
     RowCfg cfg;
-    if (!row_cfg(c, ElemTraits<T>::EPT, &cfg)) return ad_set_error(AD_ERR_ARG, "layernorm bwd: unsupported c=%d", c);
+    if (!row_cfg(c, ElemTraits<T>::EPT, &cfg, true)) return ad_set_error(AD_ERR_ARG, "layernorm bwd: unsupported c=%d", c);
     int blocks = bwd_blocks(npix, cfg.g);
     size_t need = (size_t)blocks * 3 * c * sizeof(float);
     if (!ws || ws_bytes < need) return ad_set_error(AD_ERR_WS, "layernorm bwd: workspace %zu < %zu", ws_bytes, need);
     size_t lds = (size_t)(256 / cfg.g) * 3 * c * sizeof(float);
     if (lds > 160 * 1024) return ad_set_error(AD_ERR_ARG, "layernorm bwd: c=%d needs %zu B LDS", c, lds);
-    DISPATCH_NVG(
+    DISPATCH_NVG_BWD(
         auto kern = ln_bwd_kernel<T, NV_, G_, MODE>;
         if (lds > 64 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,

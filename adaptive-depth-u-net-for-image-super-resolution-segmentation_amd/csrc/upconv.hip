@@ -19,6 +19,7 @@
 // Restated tap by tap in oracle/ops.py (upconv_bank_* / upconv_gather_*), whose equality with
 // relu(conv2d(resize(x))) and its gradients is tests/test_oracle_factored_upconv.py.
 #include "common.h"
+#include <atomic>
 
 namespace {
 
@@ -810,6 +811,17 @@ extern "C" int ad_pw_bank_pack(const float* w_hwio, int cin, int cout, void* ban
     return AD_OK;
 }
 
+// which kernel ad_pw_gemm launches for a shape: 0 = fragments straight from L2 (fp32, few pixels, odd widths), 1 = LDS-tiled
+// persistent kernel with one k-stage of loads in flight, 2 = the same with two (K >= 256 in stage pairs).  Tests ask it to
+// make sure a parity case reaches the variant it is meant for.
+static int pw_gemm_variant(int64_t m, int k, int n, int dtype) {
+    if (!(ad_is_half(dtype) && m >= 2048 && (n % 192 == 0 || n % 128 == 0))) return 0;
+    return (k / 64) % 2 == 0 && k >= 256 ? 2 : 1;
+}
+extern "C" int ad_pw_gemm_variant(int64_t m, int k, int n, int dtype) {
+    return ad_pw_supported(m, k, n, dtype) ? pw_gemm_variant(m, k, n, dtype) : -1;
+}
+
 extern "C" int ad_pw_gemm(const void* x, const void* bank, void* y, int64_t m, int k, int n, int dtype, void* stream) {
     AD_REQUIRE(ad_pw_supported(m, k, n, dtype), "ad_pw_gemm: unsupported m=%lld k=%d n=%d dtype=%d (ask ad_pw_supported)",
                (long long)m, k, n, dtype);
@@ -818,13 +830,14 @@ extern "C" int ad_pw_gemm(const void* x, const void* bank, void* y, int64_t m, i
     a.x = (const char*)x; a.bp = (const char*)bank; a.y = (char*)y;
     a.m = (int)m; a.k = k; a.n = n;
     a.nb_per_wg = 0;
-    if (ad_is_half(dtype) && m >= 2048 && (n % 192 == 0 || n % 128 == 0)) {       // LDS-tiled persistent kernel
+    const int variant = pw_gemm_variant(m, k, n, dtype);
+    if (variant > 0) {                                                              // LDS-tiled persistent kernel
         hipStream_t s = (hipStream_t)stream;
         const int nw = n % 192 == 0 ? 6 : 4;
         const int ntiles = (int)((m + 255) / 256) * (n / (32 * nw));
         const int grid = ntiles < ad_num_cu() ? ntiles : ad_num_cu();
         // two stages of loads in flight where a tile has >= 4 k-stages that pair up (K = 128, two stages a tile: 10 % slower)
-        const int depth = (k / 64) % 2 == 0 && k >= 256 ? 2 : 1;
+        const int depth = variant;
 #define PL_LAUNCH(E_, NW_, D_)                                                                                       \
     {                                                                                                                \
         static bool attr_ = false;                                                                                   \
@@ -925,6 +938,25 @@ extern "C" int ad_upconv_gather_fwd_supported(int c, int slab_cols, int dtype) {
     return (long long)slab_cols * 9 * c * tsz <= 12 * 256 * 16;            // <= 12 staging slots per thread (48 KB per row piece)
 }
 
+// Host-side: the slab_cols argument of ad_upconv_gather_fwd for a horizontal table `sx_host` (a HOST copy of the sx the launch
+// will pass), so that callers do not restate the kernel's staging rule; -1 when the table is not a non-decreasing map into [0, w).
+extern "C" int ad_upconv_slab_cols(const int* sx_host, int w, int ow, int c, int dtype) {
+    if (!sx_host || w <= 0 || ow <= 0 || c <= 0 || !ad_dtype_ok(dtype)) return -1;
+    const int ept = ad_is_half(dtype) ? 4 : 2;
+    if (c % ept || 256 % (c / ept)) return -1;
+    for (int i = 0; i < ow; ++i)
+        if (sx_host[i] < 0 || sx_host[i] >= w || (i && sx_host[i] < sx_host[i - 1])) return -1;
+    const int nox = 256 / (c / ept);
+    int most = 0;
+    for (int ox0 = 0; ox0 < ow; ox0 += nox) {                 // the same xlo / xhi the kernel derives per workgroup
+        const int lo = sx_host[ox0 > 0 ? ox0 - 1 : 0];
+        int hi = sx_host[ox0 + nox < ow ? ox0 + nox : ow - 1] + 1;
+        if (hi > w - 1) hi = w - 1;
+        if (hi - lo + 1 > most) most = hi - lo + 1;
+    }
+    return most;
+}
+
 extern "C" int ad_upconv_gather_fwd(const void* ybank, const float* bias, void* out, const int* sy, const float* wy,
                                     const int* sx, const float* wx, int window, int slab_cols, int n, int h, int w, int oh,
                                     int ow, int c, int relu, int dtype, void* stream) {
@@ -953,10 +985,20 @@ extern "C" int ad_upconv_gather_fwd(const void* ybank, const float* bias, void* 
     dim3 grid(bx, (oh + rows - 1) / rows, n);
     const size_t lds = 2 * (size_t)a.slab + GF_MAXROWS * 48 + GF_MAXROWS * 4;
     hipStream_t s = (hipStream_t)stream;
-#define GF_LAUNCH(GW_, NSL_) { AD_DISPATCH_DTYPE(dtype, T_, upconv_gather_fwd_kernel<T_, GW_, NSL_><<<grid, 256, lds, s>>>(a);) }
-    if (lds > 64 * 1024) {      // the 12-slot variants stage up to 2 x 48 KB
-        AD_DISPATCH_DTYPE(dtype, T_, (void)hipFuncSetAttribute(reinterpret_cast<const void*>(upconv_gather_fwd_kernel<T_, 3, 12>), hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
-                          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(upconv_gather_fwd_kernel<T_, 4, 12>), hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);)
+    // every instantiation can need more than the 64 KB default: 2 x slab + tables exceeds it from slab > 31 104 bytes on, which the
+    // 8-slot variants reach (scale 0.8 / depth 5, level 2: 132 -> 164 at 256 channels stages 2 x 32 256 bytes), so the limit is
+    // raised on the instantiation that is launched, once each
+#define GF_LAUNCH(GW_, NSL_)                                                                                              \
+    {                                                                                                                     \
+        AD_DISPATCH_DTYPE(dtype, T_,                                                                                      \
+            static std::atomic<bool> big_(false);                                                                         \
+            if (lds > 48 * 1024 && !big_.load(std::memory_order_acquire)) {                                               \
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(upconv_gather_fwd_kernel<T_, GW_, NSL_>),           \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024) != hipSuccess)            \
+                    return ad_set_error(AD_ERR_LAUNCH, "ad_upconv_gather_fwd: cannot raise the dynamic LDS limit to %zu bytes", lds); \
+                big_.store(true, std::memory_order_release);                                                              \
+            }                                                                                                             \
+            upconv_gather_fwd_kernel<T_, GW_, NSL_><<<grid, 256, lds, s>>>(a);)                                           \
     }
     if (window == 3) { if (nsl <= 2) GF_LAUNCH(3, 2) else if (nsl <= 4) GF_LAUNCH(3, 4) else if (nsl <= 8) GF_LAUNCH(3, 8) else GF_LAUNCH(3, 12) }
     else { if (nsl <= 2) GF_LAUNCH(4, 2) else if (nsl <= 4) GF_LAUNCH(4, 4) else if (nsl <= 8) GF_LAUNCH(4, 8) else GF_LAUNCH(4, 12) }

@@ -424,22 +424,19 @@ class UpconvTables:
         self.ryt, self.wyt, self.cxt, self.wxt = dev_i(ty[0]), dev_f(ty[1]), dev_i(tx[0]), dev_f(tx[1])
 
 
-    def slab_cols(self, nox: int) -> int:
-        """Most low-resolution columns that `nox` adjacent output columns and their +-1 neighbours read (the piece of a bank
-        row one workgroup of ad_upconv_gather_fwd stages in LDS)."""
-        if nox not in self._slab_cols:
-            sx, ow, w = self._sx_host, self.ow, self.w
-            ox0 = np.arange(0, ow, nox)
-            lo = sx[np.maximum(ox0 - 1, 0)]
-            hi = np.minimum(sx[np.minimum(ox0 + nox, ow - 1)] + 1, w - 1)
-            self._slab_cols[nox] = int((hi - lo + 1).max())
-        return self._slab_cols[nox]
+    def slab_cols(self, c: int, dtype: torch.dtype) -> int:
+        """Most low-resolution columns the output columns of one workgroup of ad_upconv_gather_fwd (and their +-1 neighbours)
+        read: the piece of a bank row it stages in LDS.  Computed by the library from the host copy of the table the launch
+        passes (ad_upconv_slab_cols), so the staging rule lives in one place; -1 = table / channel count not acceptable."""
+        key = (c, dtype)
+        if key not in self._slab_cols:
+            sx = np.ascontiguousarray(self._sx_host, dtype=np.int32)
+            self._slab_cols[key] = int(_lib.load().ad_upconv_slab_cols(sx.ctypes.data, self.w, self.ow, c, dt(dtype)))
+        return self._slab_cols[key]
 
     def gather_fwd_ok(self, c: int, dtype: torch.dtype) -> bool:
-        ept = 4 if dtype != torch.float32 else 2
-        if c % ept or 256 % (c // ept):
-            return False
-        return bool(_lib.load().ad_upconv_gather_fwd_supported(c, self.slab_cols(256 // (c // ept)), dt(dtype)))
+        cols = self.slab_cols(c, dtype)
+        return cols > 0 and bool(_lib.load().ad_upconv_gather_fwd_supported(c, cols, dt(dtype)))
 
 
 def pw_supported(m: int, k: int, n: int, dtype: torch.dtype) -> bool:
@@ -482,7 +479,7 @@ def upconv_gather_fwd(ybank: torch.Tensor, bias: Optional[torch.Tensor], tab: Up
         raise ValueError(f"upconv_gather_fwd: {c} channels (a divisor of {256 * ept} in steps of {ept} is needed)")
     with _timed("upconv_gather_fwd", 0.0, float((ybank.numel() + out.numel()) * ybank.element_size())):
         check(_lib.load().ad_upconv_gather_fwd(_p(ybank), _p(bias), _p(out), _p(tab.sy), _p(tab.wy), _p(tab.sx), _p(tab.wx),
-                                               tab.window, tab.slab_cols(256 // (c // ept)), n, h, w, tab.oh, tab.ow, c, int(relu), dt(ybank.dtype), _stream()),
+                                               tab.window, tab.slab_cols(c, ybank.dtype), n, h, w, tab.oh, tab.ow, c, int(relu), dt(ybank.dtype), _stream()),
               "ad_upconv_gather_fwd")
     return out
 

@@ -383,6 +383,9 @@ int ad_pw_supported(int64_t m, int k, int n, int dtype);
 size_t ad_pw_bank_elems(int cin, int cout);
 int ad_pw_bank_pack(const float* w_hwio, int cin, int cout, void* bank_fwd, void* bank_bwd, int dtype, void* stream);
 int ad_pw_gemm(const void* x, const void* bank, void* y, int64_t m, int k, int n, int dtype, void* stream);
+/* the kernel ad_pw_gemm launches for a shape: 0 fragments from L2, 1 / 2 LDS-tiled with one / two k-stages of loads in flight
+ * (-1: unsupported shape); for tests that must reach a given variant */
+int ad_pw_gemm_variant(int64_t m, int k, int n, int dtype);
 int ad_pw_bank_grad(const float* dw9, int cin, int cout, float* dw_hwio, void* stream);
 /* dW[3][3][Cin][Cout] (Keras layout, fp32) = re-ordered x^T dybank over the m pixels, in one pass over x and dybank
  * (16-bit types, Cin % 128 == 0, Cout % 64 == 0: ad_pw_wgrad_supported; elsewhere ad_conv3x3_wgrad + ad_pw_bank_grad).
@@ -392,6 +395,9 @@ size_t ad_pw_wgrad_ws_bytes(int64_t m, int cin, int cout);
 int ad_pw_wgrad(const void* x, const void* dybank, float* dw_hwio, int64_t m, int cin, int cout, void* ws, size_t ws_bytes,
                 int dtype, void* stream);
 int ad_upconv_gather_fwd_supported(int c, int slab_cols, int dtype);
+/* slab_cols for a horizontal table (HOST copy of sx: ow entries, non-decreasing, inside [0, w)); -1 if the table or c is not
+ * acceptable.  Callers take the value from here instead of restating the kernel's staging rule. */
+int ad_upconv_slab_cols(const int* sx_host, int w, int ow, int c, int dtype);
 int ad_upconv_gather_fwd(const void* ybank, const float* bias, void* out, const int* sy, const float* wy,
                          const int* sx, const float* wx, int window, int slab_cols, int n, int h, int w, int oh, int ow,
                          int c, int relu, int dtype, void* stream);

@@ -24,3 +24,12 @@ def device():
 def ws(device):
     from adunet_amd import ops
     return ops.Workspace(device)
+
+
+def free_port() -> int:
+    """A TCP port that is free on 127.0.0.1 right now (rendezvous of the multi-process tests: fixed port numbers collide
+    with a neighbour's run or with a socket of the previous test still in TIME_WAIT)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]

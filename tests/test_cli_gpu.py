@@ -5,6 +5,8 @@ import json
 import numpy as np
 import pytest
 
+from conftest import free_port
+
 pytestmark = pytest.mark.gpu
 
 
@@ -129,7 +131,7 @@ def test_bench_plain_and_under_torchrun_agree(device):
                            env=env, cwd=root)
     assert plain.returncode == 0, plain.stderr[-2000:]
     dist_run = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
-                               "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py")] + flags,
+                               "127.0.0.1", "--master-port", str(free_port()), os.path.join(root, "bench.py")] + flags,
                               capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert dist_run.returncode == 0, dist_run.stderr[-2000:]
     # stdout is the ONE JSON line and nothing else (RCCL's version banner, written to file descriptor 1 when the first

@@ -26,6 +26,12 @@ def test_library_exports_every_declared_symbol():
     assert lib.ad_pw_wgrad_supported(4096, 128, 64, _lib.AD_BF16) == 1 and lib.ad_pw_wgrad_supported(4096, 128, 64, _lib.AD_F32) == 0
     assert lib.ad_upconv_gather_fwd_supported(64, 7, _lib.AD_BF16) == 1 and lib.ad_upconv_gather_fwd_supported(1024, 4, _lib.AD_BF16) == 0
     assert lib.ad_upconv_gather_bwd_supported(8) == 1 and lib.ad_upconv_gather_bwd_supported(15) == 0
+    # the forward gather's staging rule lives in the library: x4 table 64 -> 256 at 64 channels = 16 output columns
+    # per workgroup + neighbours read 6 low-resolution columns; a table that goes backwards / out of range is refused
+    sx = np.clip((np.arange(256) - 1.5) // 4, 0, 63).astype(np.int32)
+    assert lib.ad_upconv_slab_cols(sx.ctypes.data, 64, 256, 64, _lib.AD_BF16) == 6
+    assert lib.ad_upconv_slab_cols(sx[::-1].copy().ctypes.data, 64, 256, 64, _lib.AD_BF16) == -1
+    assert lib.ad_upconv_slab_cols(sx.ctypes.data, 32, 256, 64, _lib.AD_BF16) == -1
 
 
 def test_missing_library_fails_loudly(monkeypatch):

@@ -1,0 +1,71 @@
+"""Guards on the generated gfx950 code of the shipped library (CPU test: hipcc cross-compiles, llvm-objdump reads).
+
+1. The store-data hazard of DESIGN 4.6 (found in r03 by the 2 048-channel audit): a 16- / 12-byte `buffer_store` whose
+   `soffset` operand is an SGPR reads its data registers late, LLVM's hazard recogniser exempts exactly that form, and the
+   next VALU write to those registers lands first -- address words in 1 of 10^4 output elements, differently every run.
+   The cure was to keep per-tile offsets in the vector offset / immediate.  Nothing but this test re-checks it after the
+   next kernel edit: no `buffer_store_dwordx3/x4` in the library may have a register as `soffset`.
+2. Register spills: a kernel that spills runs from scratch memory (5x slower, cdna_hip_programming.md rule 20) without
+   any test failing.  Every kernel's code-object metadata must show `vgpr_spill_count == 0`, except an explicit allow-list.
+"""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+# kernels allowed to spill (mangled-name substrings), with the reason.  Empty since r04: the two widest-channel
+# `ln_bwd_kernel<.., 8, 64, 0>` instantiations (84-92 spilled registers in r03) were re-cut.
+SPILL_ALLOWED = ()
+
+
+@pytest.fixture(scope="module")
+def code_objects(tmp_path_factory):
+    from adunet_amd import _lib
+    objdump = os.path.join(LLVM, "llvm-objdump")
+    if not (os.path.exists(objdump) and os.path.exists(_lib.LIB_PATH)):
+        pytest.skip("llvm-objdump or the built library is missing")
+    d = tmp_path_factory.mktemp("isa")
+    lib = shutil.copy(_lib.LIB_PATH, d / "lib.so")           # (--offloading extracts beside its input file)
+    subprocess.run([objdump, "--offloading", str(lib)], check=True, capture_output=True, cwd=d)
+    objs = sorted(p for p in d.iterdir() if "gfx950" in p.name)
+    assert len(objs) >= 8, [p.name for p in d.iterdir()]       # one code object per .hip source with kernels
+    return objs
+
+
+def test_no_wide_buffer_store_takes_its_offset_from_an_sgpr(code_objects):
+    pat = re.compile(r"\bbuffer_store_dwordx[34]\s+v\[\d+:\d+\],\s*\S+,\s*s\[\d+:\d+\],\s*(\S+)")
+    nstores, bad = 0, []
+    for obj in code_objects:
+        asm = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", str(obj)], check=True, capture_output=True, text=True).stdout
+        for line in asm.splitlines():
+            m = pat.search(line)
+            if m:
+                nstores += 1
+                if not re.fullmatch(r"-?\d+|0x[0-9a-fA-F]+", m.group(1)):
+                    bad.append(line.strip()[:100])
+    assert nstores > 300, nstores                               # the scan saw the conv / upconv epilogues (448 in r03)
+    assert not bad, (len(bad), bad[:5])
+
+
+def test_no_kernel_spills_registers(code_objects):
+    spilled, nkernels = [], 0
+    for obj in code_objects:
+        notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", str(obj)], check=True, capture_output=True, text=True).stdout
+        name = None
+        for line in notes.splitlines():
+            m = re.match(r"\s*\.name:\s*(\S+)", line)
+            if m:
+                name = m.group(1)
+            m = re.match(r"\s*\.vgpr_spill_count:\s*(\d+)", line)
+            if m and name:
+                nkernels += 1
+                if int(m.group(1)) and not any(a in name for a in SPILL_ALLOWED):
+                    spilled.append((name, int(m.group(1))))
+                name = None
+    assert nkernels > 150, nkernels
+    assert not spilled, spilled

@@ -74,6 +74,7 @@ def audit_sr_step(model, lr, hr):
     G = {k: v.astype(np.float64) for k, v in model.get_grads().items()}
     n = lr.shape[0]
     seen = set()
+    pw_variants = set()       # which bank-GEMM kernels the factored up-convs of this model launch (ad_pw_gemm_variant)
     # mixed_float16 (train_adaptive_unet.py:471-477): the head's backward multiplies the loss gradient by the dynamic loss
     # scale (a power of two, so exact); every gradient behind it, parameter gradients included, carries the factor
     sc = model._scaler()
@@ -122,6 +123,9 @@ def audit_sr_step(model, lr, hr):
         elif kind == "fwd_bank":
             # factored up-conv (csrc/upconv.hip), step 1: nine 1x1 convolutions on the low-resolution map
             _, _, xin, yb = rec
+            m_, k_ = xin.numel() // xin.shape[-1], xin.shape[-1]
+            pw_variants.add(lib.ad_pw_gemm_variant(m_, k_, yb.shape[-1], ops.dt(model.dtype)))          # Y = x Bank
+            pw_variants.add(lib.ad_pw_gemm_variant(m_, yb.shape[-1], k_, ops.dt(model.dtype)))          # dx = dY Bank^T (bwd_caf)
             want = ref.upconv_bank_fwd(f64(xin), q(W[name + "/kernel"]))
             check_stored(yb, want.reshape(yb.shape), name + " 1x1 bank", bf16)
         elif kind == "fwd_gather":
@@ -279,7 +283,7 @@ def audit_sr_step(model, lr, hr):
     # (a fused dgrad + LayerNorm backward adds a record of its own next to the two "bwd_cla" records it spans; a factored
     # up-conv's backward is one record where the resize + conv pair has two)
     nrec = sum(r[0] != "bwd_dgrad_ln" for r in records) + sum(r[0] == "bwd_caf" for r in records)
-    return nrec, ("fused_relu_grad" in seen, "bwd_dgrad_ln" in seen), sum(r[0] == "bwd_caf" for r in records)
+    return nrec, ("fused_relu_grad" in seen, "bwd_dgrad_ln" in seen), sum(r[0] == "bwd_caf" for r in records), pw_variants
 
 
 def check_stored_masked(got, want, ok_pixels, what, store):
@@ -322,9 +326,10 @@ CONFIGS = [
     ("K2-b2", 0.25, 4, 512, 2, (BF16,)),
     # the reference's own Experiment-2 shapes (Super_resolution/sbatch_scripts/run_experiment_adaptive_depth.sh:36-66,
     # depth table :47-55): fractional pyramids through the wave-specialised kernels, odd widths in the skip junctions
-    ("E2s06-b8", 0.6, 4, 256, 8, (BF16,)),   # 256/154/93/56/34, 64..1024 channels
+    # fp16 is what the reference ran these rows in (train_adaptive_simple.sbatch default --mixed_precision)
+    ("E2s06-b8", 0.6, 4, 256, 8, (BF16, F16)),   # 256/154/93/56/34, 64..1024 channels
     ("E2s06-b2", 0.6, 4, 256, 2, (F32,)),
-    ("E2s07-b2", 0.7, 5, 256, 2, (BF16,)),       # 256/180/126/89/63/45, 2048-channel bottleneck (138 M parameters)
+    ("E2s07-b2", 0.7, 5, 256, 2, (BF16, F16)),   # 256/180/126/89/63/45, 2048-channel bottleneck (138 M parameters)
     ("E2s07-b1", 0.7, 5, 256, 1, (F32,)),        # (fp32 runs the generic kernels at any batch: one image halves the oracle's work)
 ]
 BIG_LAUNCH_CONFIGS = {"K2p-b8", "E2s06-b8", "K2-b2"}              # batch 8: >= 1 work item per CU at full resolution
@@ -336,7 +341,7 @@ def test_every_step_of_the_model_against_the_oracle(device, cfg, dtype):
     _, scale, depth, p, n, _ = cfg
     model = build(scale, depth, p, dtype, device)
     lr, hr = synth(np.random.default_rng(4321), n, p)
-    nrec, (fused_relu, fused_ln), nfactored = audit_sr_step(model, lr, hr)
+    nrec, (fused_relu, fused_ln), nfactored, pw_variants = audit_sr_step(model, lr, hr)
     # decoder levels whose source map is at least 16 pixels wide run the up-conv in the factored form, in every dtype --
     # except where a workgroup's piece of a bank row exceeds the forward gather's staging window (fp32 from 512 output
     # channels on, 16-bit from 1 024: the deepest levels of the 0.6 / 0.7 pyramids), which keep the resize + 3x3 pair
@@ -344,6 +349,10 @@ def test_every_step_of_the_model_against_the_oracle(device, cfg, dtype):
     wide = 512 if dtype == torch.float32 else 1024
     assert nfactored == sum(sz >= 16 and cs.cout < wide for sz, cs in
                             zip(model.sizes[1:], [st[1] for st in reversed(model._plan) if st[0] == "upconv"])), (nfactored, model.sizes)
+    if cfg[0] in ("E2s06-b8", "E2s07-b2") and dtype != torch.float32:
+        # the deep Experiment-2 levels (K = 256 ... 4 608) are the only audited shapes whose bank GEMMs take the LDS-tiled kernel
+        # with TWO k-stages of loads in flight (K2p's GEMMs have K = 128 / 576: one stage)
+        assert 2 in pw_variants and 1 in pw_variants, pw_variants
     if cfg[0] in BIG_LAUNCH_CONFIGS:  # the weights-resident kernels with the fused ReLU-grad / LayerNorm-backward epilogues
         assert fused_relu and fused_ln, (fused_relu, fused_ln)
     # forward: 2 convs per block (2 depth + 2 blocks), depth up-convs, 2 depth resizes, head; backward: the same again

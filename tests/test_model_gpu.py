@@ -11,6 +11,8 @@ bf16 path is held to 3e-2 per gradient tensor, 1e-2 on outputs and 0.01 dB on PS
 """
 import numpy as np
 import pytest
+
+from conftest import free_port
 import torch
 
 from oracle import ops as ref
@@ -184,6 +186,9 @@ FULL_SIZE = [
     ("K2p", 0.25, 4, 256, 64),
     ("K2", 0.25, 4, 512, 16),
     ("R3", 0.5, 3, 256, 64),
+    # the two Experiment-2 workloads of bench.WORKLOADS (run_experiment_adaptive_depth.sh:36-66) at their bench batches
+    ("E2s06", 0.6, 4, 256, 32),
+    ("E2s07", 0.7, 5, 256, 8),
 ]
 
 
@@ -377,7 +382,7 @@ def test_segmented_graph_step_under_data_parallel(device, native):
     from adunet_amd.model import Adam, build_losses_and_metrics, build_super_resolution_unet
     from adunet_amd.parallel import DataParallel
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29741")
+    os.environ.setdefault("MASTER_PORT", str(free_port()))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     created = not dist.is_initialized()
     if created:
@@ -440,15 +445,21 @@ def test_fit_replays_graphs_and_matches_eager_fit(device, monkeypatch):
     assert torch.equal(results[0][1], results[1][1])
 
 
-def test_two_rank_data_parallel_on_one_gpu_equals_single_process(device):
+@pytest.mark.parametrize("dt_name", ["f32", "bf16", "f16"])
+def test_two_rank_data_parallel_on_one_gpu_equals_single_process(device, dt_name):
     """World size 2 on real device tensors (gloo transport; RCCL refuses two ranks on one GPU): each rank trains on half of
-    every batch, eagerly and through the segmented graph replay; both must equal one process on the whole batch."""
+    every batch, eagerly and through the segmented graph replay; both must equal one process on the whole batch.  In fp16
+    (the reference's policy, train_adaptive_unet.py:471-477) ONE rank's half batch overflows in one step: both ranks must skip
+    it, halve the loss scale and keep identical scaler state and weights (the finiteness check follows the all-reduce)."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29673", os.path.join(root, "tools", "dp2_gloo_gpu_check.py")]
+           "--master-port", str(free_port()), os.path.join(root, "tools", "dp2_gloo_gpu_check.py"), "--dtype", dt_name]
     res = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     assert "eager == graph bitwise: True" in res.stdout
+    assert res.stdout.count("ranks hold identical weights and scaler state: True") == 2
+    if dt_name == "f16":
+        assert res.stdout.count("skipped 1") == 2, res.stdout[-1500:]

@@ -67,6 +67,12 @@ GATHER = [  # n, h, H, c
     (1, 5, 23, 64),        # ratio 4.6: ten transposed taps
     (2, 34, 56, 512),      # two output columns per workgroup, a 36 KB row piece: the 12-slot staging variant
     (1, 6, 10, 256),
+    # 2 x row piece + tables beyond the 64 KB default dynamic-LDS limit on the EIGHT-slot variant (until r03 only the
+    # 12-slot instantiations had the limit raised).  Scale 0.8 / depth 5, level 2 of the reference's Experiment 2
+    # (run_experiment_adaptive_depth.sh:47-55): 132 -> 164 at 256 channels stages 2 x 32 256 bytes in 16 bits;
+    # 208 -> 231 at 128 channels is the fp32 shape that crosses the limit
+    (1, 132, 164, 256),
+    (1, 208, 231, 128),
 ]
 
 

@@ -4,34 +4,51 @@ logic of DataParallel + segmented graph replay on real device tensors.  Each ran
 result must equal one process training on the whole batch (LayerNorm has no cross-sample statistic).
 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29671 \
-        tools/dp2_gloo_gpu_check.py
+        tools/dp2_gloo_gpu_check.py [--dtype f32|bf16|f16]
+
+--dtype f16 is the reference's policy (mixed_float16 + Keras dynamic loss scaling, train_adaptive_unet.py:471-477) and adds
+the case the exchange order exists for: in step 1 ONE rank's half batch overflows (an input of 1e30 becomes inf in half
+precision, its gradients NaN).  The finiteness check runs AFTER the all-reduce (model._apply_gradients), so both ranks must
+see the non-finite sum, both skip the step, halve the scale, and end with identical scaler state and identical weights.
 """
-import os, sys
+import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, torch.distributed as dist
 from adunet_amd.model import Adam, build_losses_and_metrics, build_super_resolution_unet
 from adunet_amd.parallel import DataParallel
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f16"])
+args = ap.parse_args()
+dtype = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[args.dtype]
 
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dev = torch.device("cuda:0")
 torch.cuda.set_device(0)
 dist.init_process_group("gloo", rank=rank, world_size=world)
 rng = np.random.default_rng(5)
-steps = 3
+steps = 4
 per = 2
+OVERFLOW_STEP, OVERFLOW_RANK = 1, 1
 batches = []
-for _ in range(steps):
+for i in range(steps):
     hr = rng.random((per * world, 32, 32, 3), dtype=np.float32)
     lr = np.clip(hr + 0.05 * rng.standard_normal(hr.shape, dtype=np.float32), 0, 1).astype(np.float32)
+    if dtype == torch.float16 and i == OVERFLOW_STEP:
+        lr[OVERFLOW_RANK * per, 5, 7, 1] = 1e30           # lands in rank 1's half only
     batches.append((lr, hr))
 
 def make():
-    m, _ = build_super_resolution_unet(0.5, depth_override=2, input_size=32, dtype=torch.float32, device=dev)
+    m, _ = build_super_resolution_unet(0.5, depth_override=2, input_size=32, dtype=dtype, device=dev)
     loss, metrics = build_losses_and_metrics("charbonnier")
     m.compile(optimizer=Adam(1e-3), loss=loss, metrics=metrics)
     m._require_device()
     m.set_weights(m.initial_weights(np.random.default_rng(1), head_uniform=0.05))
     return m
+
+def scaler_state(m):
+    sc = m._scaler()
+    return sc.state.clone() if sc is not None else torch.zeros(8, device=dev)
 
 results = {}
 for mode in ("eager", "graph"):
@@ -45,24 +62,44 @@ for mode in ("eager", "graph"):
     for lr, hr in batches:
         step(lr[sl], hr[sl])
     torch.cuda.synchronize()
-    results[mode] = m.P.clone()
+    results[mode] = (m.P.clone(), scaler_state(m))
     del m, step
+
+# every rank must hold the same weights and the same scaler state (bitwise): compare through rank 0
+ok = True
+for mode, (p, st) in results.items():
+    both_p = [torch.empty_like(p.cpu()) for _ in range(world)]
+    both_s = [torch.empty_like(st.cpu()) for _ in range(world)]
+    dist.all_gather(both_p, p.cpu())
+    dist.all_gather(both_s, st.cpu())
+    same = all(torch.equal(both_p[0], q) for q in both_p[1:]) and all(torch.equal(both_s[0], q) for q in both_s[1:])
+    if rank == 0:
+        print(f"{mode}: ranks hold identical weights and scaler state: {same}", flush=True)
+    ok &= same
 ref = None
 if rank == 0:
     m = make()                               # one process, whole batch
     for lr, hr in batches:
         m.train_on_batch(lr, hr)
-    ref = m.P.clone()
-ok = True
-if rank == 0:
-    for mode, p in results.items():
+    torch.cuda.synchronize()
+    ref, ref_state = m.P.clone(), scaler_state(m)
+    # fp32: summation order of the two halves only.  16-bit: the same roundings per sample (samples are independent), so still
+    # only the fp32 order of the weight-gradient sums -- but Adam divides by sqrt(v), which lifts a last-bit difference in a tiny
+    # gradient to a visible step; bound by a fraction of one step (lr = 1e-3) relative to the weights' scale
+    tol = 1e-5 if dtype == torch.float32 else 2e-4
+    for mode, (p, st) in results.items():
         err = float((p - ref).abs().max() / ref.abs().max())
         print(f"{mode}: max |P_dp - P_single| / max|P| = {err:.3e}", flush=True)
-        ok &= err < 1e-5
-    print("eager == graph bitwise:", bool(torch.equal(results["eager"], results["graph"])), flush=True)
-    ok &= bool(torch.equal(results["eager"], results["graph"]))
+        ok &= err < tol and bool(torch.isfinite(p).all())
+        if dtype == torch.float16:
+            s = st.cpu().tolist()
+            print(f"{mode}: loss scale {s[0]:.0f}, applied {int(s[4])}, skipped {int(s[5])}", flush=True)
+            # one skipped step (the overflow on ONE rank), scale halved once, the other steps applied -- as the single process
+            ok &= s[0] == 2.0 ** 14 and int(s[4]) == steps - 1 and int(s[5]) == 1 and torch.equal(st, ref_state)
+    print("eager == graph bitwise:", bool(torch.equal(results["eager"][0], results["graph"][0])), flush=True)
+    ok &= bool(torch.equal(results["eager"][0], results["graph"][0])) and bool(torch.equal(results["eager"][1], results["graph"][1]))
 t = torch.tensor([1.0 if ok else 0.0])
-dist.broadcast(t, src=0)
+dist.all_reduce(t, op=dist.ReduceOp.MIN)
 dist.barrier()
 dist.destroy_process_group()
 sys.exit(0 if t.item() == 1.0 else 1)
