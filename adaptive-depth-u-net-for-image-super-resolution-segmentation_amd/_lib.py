@@ -60,7 +60,7 @@ SIGNATURES = {
     "ad_head_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _f, _vp, _sz, _i, _vp]),
     "ad_head_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _f, _f, _vp, _vp, _sz, _i, _vp]),
     "ad_head_ln_bwd_ws_bytes": (_sz, [_i, _i]),
-    "ad_head_ln_bwd": (_i, [_vp] * 16 + [_i, _i64, _i, _i, _f, _f, _vp, _vp, _sz, _i, _vp]),
+    "ad_head_ln_bwd": (_i, [_vp] * 16 + [_i, _i64, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _sz, _i, _vp]),
     "ad_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _f, _vp]),
     "ad_adam_alpha": (_f, [_f, _f, _f, _i]),
     "ad_adam_step_dev": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _f, _f, _f, _f, _vp]),

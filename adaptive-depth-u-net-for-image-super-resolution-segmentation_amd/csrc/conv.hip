@@ -319,6 +319,24 @@ struct ConvArgs {
     Geo g;
 };
 
+// -DAD_CLOCK (diagnostic build, tools/inkernel_clock.py): the shader clock a launch really runs at = cycles (s_memtime) over wall
+// time (s_memrealtime, 100 MHz) across the life of MFMA wave 0 of every workgroup (MI355X_MICROARCH.md, "DVFS give-back" item 6).
+// The stamps go to a buffer of their own that no kernel reads; the shipped build has none of this.
+#ifdef AD_CLOCK
+__device__ unsigned long long g_ad_clock[2 * 4096];
+#define AD_CLOCK_BEGIN                                                                                   \
+    const unsigned long long ck_c0_ = __builtin_amdgcn_s_memtime(), ck_w0_ = __builtin_amdgcn_s_memrealtime(); \
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+#define AD_CLOCK_END(WAVE, LANE, BID)                                                                    \
+    if ((WAVE) == 0 && (LANE) == 0 && (BID) < 4096) {                                                    \
+        g_ad_clock[2 * (BID)] = __builtin_amdgcn_s_memtime() - ck_c0_;                                   \
+        g_ad_clock[2 * (BID) + 1] = __builtin_amdgcn_s_memrealtime() - ck_w0_;                           \
+    }
+#else
+#define AD_CLOCK_BEGIN
+#define AD_CLOCK_END(WAVE, LANE, BID)
+#endif
+
 #ifdef AD_STAMP
 #define STAMP(slot)                                            \
     do {                                                       \
@@ -1143,6 +1161,7 @@ __global__ __launch_bounds__(WR_T, 1) void conv3x3_fwd_wres_kernel(ConvArgs a) {
     const int nb = o.nb;                            // one 64-channel output block per workgroup for the whole launch
     const int kc_total = (a.c1 + a.c2) / P::KV;
     const int npix = a.n * a.h * a.w;
+    AD_CLOCK_BEGIN
 
     // weights of this output block: both chunks, once (all 512 threads)
 #pragma unroll
@@ -1240,6 +1259,7 @@ __global__ __launch_bounds__(WR_T, 1) void conv3x3_fwd_wres_kernel(ConvArgs a) {
     } else {
         if constexpr (EPI == 4) ws_mma_role_lnb<P>(a, xb0, xb1, wt, wt + WT_BYTES, gb, wave, lane, o);
         else ws_mma_role<P, EPI>(a, xb0, xb1, wt, wt + WT_BYTES, gb, wave, lane, o, 2);
+        AD_CLOCK_END(wave, lane, blockIdx.x)
     }
 }
 
@@ -1932,6 +1952,7 @@ __global__ __launch_bounds__(W2_T, 1) void conv3x3_wgrad_ws_kernel(WgradArgs a) 
     const int t_begin = split * a.tiles_per_split;
     const int t_end = min(a.ntiles, t_begin + a.tiles_per_split);
     const int npix = a.n * a.h * a.w;
+    AD_CLOCK_BEGIN
     // LDS: half hf: x chunk c at smem + (2*hf + c) * W2_XB, dz at smem + 4*W2_XB + hf * W2_DZB
 
     if (wave >= 4) {
@@ -2070,6 +2091,7 @@ __global__ __launch_bounds__(W2_T, 1) void conv3x3_wgrad_ws_kernel(WgradArgs a) 
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     slab[(tap * 64 + wave * 16 + (lane >> 4) * 4 + r) * BN + j * 16 + (lane & 15)] = acc[tap][j][r];
+        AD_CLOCK_END(wave, lane, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z))
     }
 }
 
@@ -2758,6 +2780,18 @@ static int launch_fwd_dtype(int dtype, const ConvArgs& a, void* ws, size_t ws_by
 static unsigned long long* g_dbg = nullptr;
 #ifdef AD_STAMP
 extern "C" void ad_dbg_set_stamp_buffer(void* p) { g_dbg = (unsigned long long*)p; }
+#endif
+#ifdef AD_CLOCK
+// host copy of the (cycles, 10-ns ticks) pairs of the last stamped launches; `reset` zeroes them
+extern "C" int ad_dbg_clock_read(unsigned long long* host, int pairs, int reset) {
+    if (pairs > 4096) pairs = 4096;
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ad_clock), (size_t)pairs * 16) != hipSuccess) return -1;
+    if (reset) {
+        static unsigned long long zeros[2 * 4096];
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_ad_clock), zeros, sizeof(zeros)) != hipSuccess) return -1;
+    }
+    return 0;
+}
 #endif
 
 extern "C" int ad_conv3x3_pack(const float* w_hwio, int cin, int cout, int cin_pad, void* w_fwd, void* w_dgrad,

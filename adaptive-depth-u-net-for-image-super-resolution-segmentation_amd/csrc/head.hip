@@ -120,6 +120,32 @@ __global__ __launch_bounds__(256) void head_stats_kernel(const float* __restrict
     if (tid == 0 && stats) { stats[0] = sm[0]; stats[1] = sp[0] / (float)n; stats[2] = sm[0] / ((float)n * elems_per_img); }
 }
 
+// head_stats_kernel for the partials head_ln_bwd_kernel leaves in columns col0, col0 + 1 of its [n * bpi][ncol] table
+__global__ __launch_bounds__(256) void head_stats_strided_kernel(const float* __restrict__ part, int n, int bpi, int ncol, int col0,
+                                                                 float* __restrict__ stats, float* __restrict__ sqerr,
+                                                                 float elems_per_img) {
+    __shared__ float sm[256];
+    __shared__ float sp[256];
+    const int tid = threadIdx.x;
+    float s = 0.f;
+    for (int i = tid; i < n * bpi; i += 256) s += part[(size_t)i * ncol + col0];
+    float ps = 0.f;
+    for (int img = tid; img < n; img += 256) {
+        float q = 0.f;
+        for (int k = 0; k < bpi; ++k) q += part[((size_t)img * bpi + k) * ncol + col0 + 1];
+        if (sqerr) sqerr[img] = q;
+        ps += -10.f * log10f(q / elems_per_img);
+    }
+    sm[tid] = s;
+    sp[tid] = ps;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) { sm[tid] += sm[tid + o]; sp[tid] += sp[tid + o]; }
+        __syncthreads();
+    }
+    if (tid == 0) { stats[0] = sm[0]; stats[1] = sp[0] / (float)n; stats[2] = sm[0] / ((float)n * elems_per_img); }
+}
+
 template <typename T, int G>
 __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ xh, const float* __restrict__ w,
                                                        const float* __restrict__ b, const float* __restrict__ inp,
@@ -198,9 +224,10 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ xh,
     for (int e = 0; e < EPT; ++e)
 #pragma unroll
         for (int o = 0; o < 3; ++o) red[gp * ncol + (gl * EPT + e) * 3 + o] = aw[e][o];
-    if (gl == 0)
+    if (gl == 0) {
 #pragma unroll
         for (int o = 0; o < 3; ++o) red[gp * ncol + ch * 3 + o] = ab[o];
+    }
     __syncthreads();
     for (int i = tid; i < ncol; i += 256) {
         float s = 0.f;
@@ -225,13 +252,16 @@ __global__ __launch_bounds__(256) void head_ln_bwd_kernel(const T* __restrict__ 
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           T* __restrict__ dz, float* __restrict__ part, int64_t ppi, int ch,
                                                           int loss_kind, float eps, float gscale_host,
-                                                          const float* __restrict__ loss_scale) {
+                                                          const float* __restrict__ loss_scale, int want_stats) {
     constexpr int EPT = ElemTraits<T>::EPT;
     constexpr int PPB = 256 / G;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = reinterpret_cast<float*>(smem);  // [PPB][ncol]
     const float gscale = loss_scale ? gscale_host * loss_scale[0] : gscale_host;
-    const int ncol = ch * 6 + 3;
+    // want_stats: two more columns, the block's loss and squared-error partials (what head_fwd_kernel reports) -- the kernel
+    // re-derives the head's output anyway, so a train step needs no forward pass over the head at all
+    const int ncol = ch * 6 + 3 + (want_stats ? 2 : 0);
+    float a_l = 0.f, a_q = 0.f;
     const int tid = threadIdx.x, gl = tid % G, gp = tid / G;
     const int img = blockIdx.y;
     float wl[EPT][3], aw[EPT][3], ab[3] = {0.f, 0.f, 0.f};
@@ -290,6 +320,10 @@ __global__ __launch_bounds__(256) void head_ln_bwd_kernel(const T* __restrict__ 
             float d = tgts[u][o] - ov;
             float dl = loss_kind == 0 ? -d * rsqrtf(d * d + eps * eps) : (d > 0.f ? -1.f : (d < 0.f ? 1.f : 0.f));
             g[o] = (pre >= 0.f && pre <= 1.f) ? dl * gscale : 0.f;
+            if (want_stats) {        // (every lane of the pixel's group holds the same three values: lane 0 reports them)
+                a_l += loss_kind == 0 ? sqrtf(d * d + eps * eps) : fabsf(d);
+                a_q += d * d;
+            }
         }
         float h[EPT], gg[EPT];
         float s1 = 0.f, s2 = 0.f;
@@ -332,9 +366,11 @@ __global__ __launch_bounds__(256) void head_ln_bwd_kernel(const T* __restrict__ 
         red[gp * ncol + ch * 4 + 3 + c] = a_b[e];
         red[gp * ncol + ch * 5 + 3 + c] = a_z[e];
     }
-    if (gl == 0)
+    if (gl == 0) {
 #pragma unroll
         for (int o = 0; o < 3; ++o) red[gp * ncol + ch * 3 + o] = ab[o];
+        if (want_stats) { red[gp * ncol + ch * 6 + 3] = a_l; red[gp * ncol + ch * 6 + 4] = a_q; }
+    }
     __syncthreads();
     for (int i = tid; i < ncol; i += 256) {
         float s = 0.f;
@@ -348,15 +384,16 @@ struct HeadLnOuts {
     float* ptr[5];
     int end[5];      // exclusive column end of each output
 };
-__global__ __launch_bounds__(256) void rows_reduce5_kernel(const float* __restrict__ part, int nrows, int ncols, HeadLnOuts o) {
+__global__ __launch_bounds__(256) void rows_reduce5_kernel(const float* __restrict__ part, int nrows, int stride, int ncols,
+                                                           HeadLnOuts o) {
     __shared__ float sm[64][5];
     const int tid = threadIdx.x, cl = tid & 3, rg = tid >> 2;
     const int i = blockIdx.x * 4 + cl;
     float s = 0.f;
-    if (i < ncols)
+    if (i < ncols)                       // (the first `ncols` of `stride` columns per row)
     {
 #pragma unroll 8
-        for (int r = rg; r < nrows; r += 64) s += part[(size_t)r * ncols + i];
+        for (int r = rg; r < nrows; r += 64) s += part[(size_t)r * stride + i];
     }
     sm[rg][cl] = s;
     __syncthreads();
@@ -474,21 +511,23 @@ extern "C" int ad_head_bwd(const void* xh, const float* w, const float* b, const
 }
 
 
-extern "C" size_t ad_head_ln_bwd_ws_bytes(int n, int ch) { return (size_t)n * BPI_MAX * (ch * 6 + 3) * sizeof(float); }
+extern "C" size_t ad_head_ln_bwd_ws_bytes(int n, int ch) { return (size_t)n * BPI_MAX * (ch * 6 + 5) * sizeof(float); }
 
 extern "C" int ad_head_ln_bwd(const void* xh, const float* w, const float* b, const float* inp, const float* target,
                               const void* z, const float* mean, const float* rstd, const float* gamma, const float* beta,
                               void* dz, float* dw, float* db, float* dgamma, float* dbeta, float* dbias_conv, int n,
                               int64_t pix_per_img, int ch, int loss_kind, float eps, float grad_scale,
-                              const float* loss_scale, void* ws, size_t ws_bytes, int dtype, void* stream) {
+                              const float* loss_scale, float* stats, float* sqerr, void* ws, size_t ws_bytes, int dtype,
+                              void* stream) {
     AD_REQUIRE(ad_dtype_ok(dtype), "ad_head_ln_bwd: bad dtype %d", dtype);
+    AD_REQUIRE(stats || !sqerr, "ad_head_ln_bwd: sqerr without stats");
     AD_REQUIRE(n > 0 && pix_per_img > 0 && target && z && mean && rstd && gamma && beta && dz && dgamma && dbeta && dbias_conv,
                "ad_head_ln_bwd: bad shape / missing operand");
     AD_REQUIRE(loss_kind == 0 || loss_kind == 1, "ad_head_ln_bwd: loss_kind=%d", loss_kind);
     int g;
     AD_REQUIRE(head_group(ch, ad_is_half(dtype) ? 8 : 4, &g), "ad_head_ln_bwd: unsupported ch=%d", ch);
     const int bpi = head_bpi(pix_per_img, g);
-    const int ncol = ch * 6 + 3;
+    const int ncol = ch * 6 + 3 + (stats ? 2 : 0);
     size_t need = (size_t)n * bpi * ncol * sizeof(float);
     if (!ws || ws_bytes < need) return ad_set_error(AD_ERR_WS, "ad_head_ln_bwd: workspace %zu < %zu", ws_bytes, need);
     size_t lds = (size_t)(256 / g) * ncol * sizeof(float);
@@ -498,7 +537,7 @@ extern "C" int ad_head_ln_bwd(const void* xh, const float* w, const float* b, co
     AD_DISPATCH_DTYPE(dtype, T_,
         HEAD_DISPATCH(head_ln_bwd_kernel<T_, G_><<<grid, 256, lds, s>>>((const T_*)xh, w, b, inp, target, (const T_*)z, mean, rstd,
                                                                         gamma, beta, (T_*)dz, (float*)ws, pix_per_img, ch,
-                                                                        loss_kind, eps, grad_scale, loss_scale);))
+                                                                        loss_kind, eps, grad_scale, loss_scale, stats ? 1 : 0);))
     AD_LAUNCH_CHECK("ad_head_ln_bwd");
     HeadLnOuts o;
     o.ptr[0] = dw; o.end[0] = ch * 3;
@@ -506,7 +545,11 @@ extern "C" int ad_head_ln_bwd(const void* xh, const float* w, const float* b, co
     o.ptr[2] = dgamma; o.end[2] = ch * 4 + 3;
     o.ptr[3] = dbeta; o.end[3] = ch * 5 + 3;
     o.ptr[4] = dbias_conv; o.end[4] = ch * 6 + 3;
-    rows_reduce5_kernel<<<(ncol + 3) / 4, 256, 0, s>>>((const float*)ws, n * bpi, ncol, o);
+    rows_reduce5_kernel<<<(ch * 6 + 3 + 3) / 4, 256, 0, s>>>((const float*)ws, n * bpi, ncol, ch * 6 + 3, o);
     AD_LAUNCH_CHECK("head_ln rows_reduce");
+    if (stats) {
+        head_stats_strided_kernel<<<1, 256, 0, s>>>((const float*)ws, n, bpi, ncol, ch * 6 + 3, stats, sqerr, (float)pix_per_img * 3.f);
+        AD_LAUNCH_CHECK("head_ln stats");
+    }
     return AD_OK;
 }

@@ -507,7 +507,16 @@ class Model:
             raise ValueError(f"expected a [B,H,W,3] batch, got {tuple(t.shape)}")
         return t.to(device=self.device, dtype=torch.float32).contiguous()
 
-    def _forward(self, x: torch.Tensor, target: Optional[torch.Tensor], keep: bool):
+    def _head_fuses_with_ln(self, tape: List[tuple], xh: torch.Tensor) -> bool:
+        """The layer feeding the head is Conv2D -> LayerNorm -> ReLU (:265) recorded on the tape: its LayerNorm / ReLU
+        backward runs inside the head's backward pass (ad_head_ln_bwd), which also reports the loss and the metric."""
+        nxt = tape[-1] if tape else None
+        return (nxt is not None and nxt[0] == "cla" and nxt[4].shape == xh.shape
+                and os.environ.get("ADUNET_NO_HEAD_LN_FUSION") != "1")
+
+    def _forward(self, x: torch.Tensor, target: Optional[torch.Tensor], keep: bool, need_out: bool = True):
+        """need_out=False (train steps: only loss and metric leave the step, :622-632): where the head's backward kernel can
+        report them, no forward launch runs over the head -- `out` is None and `stats` is filled by _backward."""
         loss_kind = self.loss.kind if self.loss is not None else 0
         eps = self.loss.eps if self.loss is not None else 1e-3
         tape: List[tuple] = []
@@ -576,9 +585,15 @@ class Model:
             elif kind == "head":
                 w = self.param("residual_rgb/kernel").view(self.head, 3)
                 b = self.param("residual_rgb/bias")
+                if (not need_out and keep and target is not None and self.audit is None and self._head_fuses_with_ln(tape, cur1)
+                        and os.environ.get("ADUNET_HEAD_FWD_IN_TRAIN") != "1"):
+                    stats = torch.empty(3, dtype=torch.float32, device=x.device)
+                    sqerr = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+                    tape.append(("head", cur1, stats, sqerr))
+                    return None, stats, sqerr, tape
                 out, stats, sqerr = ops.head_fwd(cur1, w, b, x, target, self._ws, loss_kind=loss_kind, eps=eps)
                 if keep:
-                    tape.append(("head", cur1))
+                    tape.append(("head", cur1, None, None))
                 if self.audit is not None:
                     self.audit.append(("fwd_head", "residual_rgb", cur1, x, target, out, stats))
                 return out, stats, sqerr, tape
@@ -598,8 +613,7 @@ class Model:
             if kind == "head":
                 w = self.param("residual_rgb/kernel").view(self.head, 3)
                 nxt = tape[-1] if tape else None
-                if (nxt is not None and nxt[0] == "cla" and nxt[4].shape == rec[1].shape
-                        and os.environ.get("ADUNET_NO_HEAD_LN_FUSION") != "1"):
+                if self._head_fuses_with_ln(tape, rec[1]):
                     # the layer feeding the head is Conv2D -> LayerNorm -> ReLU (:265): its LayerNorm/ReLU backward runs
                     # inside the head's backward pass, the gradient of the head activations never goes to memory
                     _, hcs, _, _, hz, hmean, hrstd, _ = nxt
@@ -608,12 +622,14 @@ class Model:
                                                self.grad("residual_rgb/kernel").view(self.head, 3), self.grad("residual_rgb/bias"),
                                                self.grad(hcs.ln + "/gamma"), self.grad(hcs.ln + "/beta"),
                                                self.grad(hcs.name + "/bias"), grad_scale, ws, loss_kind=self.loss.kind,
-                                               eps=self.loss.eps, loss_scale=sc.state if sc is not None else None)
+                                               eps=self.loss.eps, loss_scale=sc.state if sc is not None else None,
+                                               stats=rec[2], sqerr=rec[3])
                     d = None
                     if audit is not None:
                         audit.append(("bwd_head_ln", "residual_rgb", rec[1], x, target, grad_scale, hcs.name, hz, hmean, hrstd,
                                       dz_ready))
                 else:
+                    assert rec[2] is None, "the forward pass left the loss to a fused head backward that did not run"
                     d = ops.head_bwd(rec[1], w, self.param("residual_rgb/bias"), x, target,
                                      self.grad("residual_rgb/kernel").view(self.head, 3), self.grad("residual_rgb/bias"),
                                      grad_scale, ws, loss_kind=self.loss.kind, eps=self.loss.eps,
@@ -799,15 +815,16 @@ class Model:
             if alpha_dev is not None:
                 alpha_dev.fill_(ops.adam_alpha(opt.lr_at(opt.iterations - 1), opt.beta_1, opt.beta_2, opt.iterations))
 
-    def forward_loss(self, lr_img, hr_img, keep: bool = False):
-        """Forward + fused loss.  Returns (out, loss_mean [device scalar], psnr_mean [device scalar], tape)."""
+    def forward_loss(self, lr_img, hr_img, keep: bool = False, need_out: bool = True):
+        """Forward + fused loss.  Returns (out, loss_mean [device scalar], psnr_mean [device scalar], tape).
+        need_out=False: a train step -- `out` may be None and the two scalars are then valid after _backward (see _forward)."""
         self._require_device()
         if self.loss is None:
             raise RuntimeError("call compile() first")
         x, t = self._to_dev(lr_img), self._to_dev(hr_img)
         if x.shape != t.shape:
             raise ValueError(f"input/target shape mismatch: {tuple(x.shape)} vs {tuple(t.shape)}")
-        out, stats, sqerr, tape = self._forward(x, t, keep=keep)
+        out, stats, sqerr, tape = self._forward(x, t, keep=keep, need_out=need_out)
         # stats = (loss sum, mean tf.image.psnr (:308-311), loss mean) straight from the head kernel: views, no torch op
         return out, stats[2], stats[1], (tape, x, t)
 
@@ -815,7 +832,7 @@ class Model:
         """One Keras train step: forward, loss, backward, (gradient all-reduce), Keras-form Adam."""
         if self.optimizer is None:
             raise RuntimeError("call compile() first")
-        out, loss, psnr, (tape, x, t) = self.forward_loss(lr_img, hr_img, keep=True)
+        out, loss, psnr, (tape, x, t) = self.forward_loss(lr_img, hr_img, keep=True, need_out=False)
         count = float(x.numel())
         self._backward(tape, x, t, 1.0 / count)
         gscale = self.grad_sync(self) if self.grad_sync is not None else 1.0
@@ -834,7 +851,7 @@ class Model:
 
     def _graph_forward_backward(self, sx: torch.Tensor, st: torch.Tensor):
         """Forward, loss and backward on the static inputs; returns the device scalars the step reports."""
-        out, loss, psnr, (tape, x, t) = self.forward_loss(sx, st, keep=True)
+        out, loss, psnr, (tape, x, t) = self.forward_loss(sx, st, keep=True, need_out=False)
         self._backward(tape, x, t, 1.0 / float(x.numel()))
         return loss, psnr
 

@@ -18,7 +18,10 @@ BUILD-DEFINED, chosen so that every sub-step is exactly a step the reference gra
 * precision: the reference's `mixed_float16` policy (fp16 storage + Keras dynamic loss scaling per model: every model's
   compile() wraps its Adam in a LossScaleOptimizer); bf16 / fp32 are accepted too;
 * every (task, scale, depth, batch shape) gets its own captured hipGraph (Model._fit_step: at most four shapes per
-  model), replayed from then on.
+  model), replayed from then on;
+* data parallel (`AdaptiveDepthBank.data_parallel()`): every model of the bank gets its OWN `parallel.DataParallel` (its own
+  flat gradient buffer, buckets and rank-0 weight broadcast) when it is built.  Models are built on first use, so every rank
+  must walk the SAME sequence of (task, scale) items -- the batches are sharded over the ranks, never the stream.
 
 Tested as properties only (tests/test_multitask_gpu.py): a routed step is BITWISE the stand-alone model's step, models do
 not disturb each other, the routing table is the reference's.
@@ -79,27 +82,59 @@ class AdaptiveDepthBank:
         self.sr: "OrderedDict[Tuple[float, int], object]" = OrderedDict()
         self.seg = None
         self.steps: Dict[Tuple, int] = {}
+        self._dp_kwargs: Optional[dict] = None         # set by data_parallel(): every model gets its own DataParallel
+        self.dps: List[object] = []
+
+    # ---- data parallelism: one exchange object per model (each model has its own flat gradient buffer)
+    def data_parallel(self, bucket_bytes: int = 32 << 20, group=None, native: Optional[bool] = None):
+        """Attach one `parallel.DataParallel` to every model of the bank -- those that exist now and, as they are built,
+        those that do not yet (same construction order on every rank: see the module docstring).  Returns self."""
+        self._dp_kwargs = {"bucket_bytes": bucket_bytes, "group": group, "native": native}
+        for model in self.models():
+            self._attach_dp(model)
+        return self
+
+    def _attach_dp(self, model):
+        if self._dp_kwargs is not None and getattr(model, "_dp", None) is None:
+            from .parallel import DataParallel
+            if hasattr(model, "_require_device"):
+                model._require_device()                # the flat buffers must exist before rank 0's weights are broadcast
+            self.dps.append(DataParallel(model, **self._dp_kwargs))
+
+    def close(self):
+        """Destroy the native communicators of the models' exchange objects (before the process group goes away)."""
+        for dp in self.dps:
+            dp.close()
 
     # ---- models, built on first use
-    def sr_model(self, scale: float):
+    def _build_sr(self, key: Tuple[float, int]):
         from .model import Adam, build_losses_and_metrics, build_super_resolution_unet
+        model, _ = build_super_resolution_unet(key[0], depth_override=key[1], input_size=self.input_size, dtype=self.dtype,
+                                               device=self.device, seed=self.seed)
+        loss, metrics = build_losses_and_metrics(self.loss)
+        model.compile(optimizer=Adam(learning_rate=self.learning_rate), loss=loss, metrics=metrics, jit_compile=False)
+        return model
+
+    def _build_seg(self, steps_per_epoch: int, epochs: int):
+        from . import seg_model as S
+        proto = S.PROTOCOLS[self.seg_protocol]
+        seg = S.build_adaptive_depth_unet(self.input_size, self.seg_base_channels, self.seg_depth, dtype=self.dtype,
+                                          device=self.device, seed=self.seed)
+        seg.compile(optimizer=S.build_optimizer(proto, steps_per_epoch, epochs), loss=proto.loss_builder())
+        return seg
+
+    def sr_model(self, scale: float):
         key = (round(float(scale), 2), route_depth(scale, self.min_depth, self.max_depth, self.input_size))
         model = self.sr.get(key)
         if model is None:
-            model, _ = build_super_resolution_unet(key[0], depth_override=key[1], input_size=self.input_size, dtype=self.dtype,
-                                                   device=self.device, seed=self.seed)
-            loss, metrics = build_losses_and_metrics(self.loss)
-            model.compile(optimizer=Adam(learning_rate=self.learning_rate), loss=loss, metrics=metrics, jit_compile=False)
-            self.sr[key] = model
+            model = self.sr[key] = self._build_sr(key)
+            self._attach_dp(model)
         return key, model
 
     def seg_model(self, steps_per_epoch: int = 100, epochs: int = 1):
         if self.seg is None:
-            from . import seg_model as S
-            proto = S.PROTOCOLS[self.seg_protocol]
-            self.seg = S.build_adaptive_depth_unet(self.input_size, self.seg_base_channels, self.seg_depth, dtype=self.dtype,
-                                                   device=self.device, seed=self.seed)
-            self.seg.compile(optimizer=S.build_optimizer(proto, steps_per_epoch, epochs), loss=proto.loss_builder())
+            self.seg = self._build_seg(steps_per_epoch, epochs)
+            self._attach_dp(self.seg)
         return self.seg
 
     # ---- steps

@@ -562,8 +562,10 @@ def head_bwd(xh, w, b, inp, target, dw, db, grad_scale: float, ws: Workspace, lo
 
 
 def head_ln_bwd(xh, w, b, inp, target, z, mean, rstd, gamma, beta, dw, db, dgamma, dbeta, dbias_conv, grad_scale: float,
-                ws: Workspace, loss_kind: int = 0, eps: float = CHARBONNIER_EPS, loss_scale: Optional[torch.Tensor] = None):
-    """head_bwd + the LayerNorm/ReLU backward of the layer feeding the head, one pass; returns that layer's dz."""
+                ws: Workspace, loss_kind: int = 0, eps: float = CHARBONNIER_EPS, loss_scale: Optional[torch.Tensor] = None,
+                stats: Optional[torch.Tensor] = None, sqerr: Optional[torch.Tensor] = None):
+    """head_bwd + the LayerNorm/ReLU backward of the layer feeding the head, one pass; returns that layer's dz.
+    stats[3] / sqerr[n]: filled with what head_fwd reports (loss sum, mean PSNR, loss mean / per-image squared error)."""
     n, h, wd, ch = xh.shape
     dz = torch.empty_like(z)
     lib = _lib.load()
@@ -571,7 +573,8 @@ def head_ln_bwd(xh, w, b, inp, target, z, mean, rstd, gamma, beta, dw, db, dgamm
     with _timed("head_ln_bwd", 0.0, float(3 * xh.numel() * xh.element_size() + 2 * inp.numel() * 4)):
         check(lib.ad_head_ln_bwd(_p(xh), _p(w), _p(b), _p(inp), _p(target), _p(z), _p(mean), _p(rstd), _p(gamma), _p(beta),
                                  _p(dz), _p(dw), _p(db), _p(dgamma), _p(dbeta), _p(dbias_conv), n, h * wd, ch, loss_kind, eps,
-                                 grad_scale, _p(loss_scale), ws.ptr, ws.nbytes, dt(xh.dtype), _stream()), "ad_head_ln_bwd")
+                                 grad_scale, _p(loss_scale), _p(stats), _p(sqerr), ws.ptr, ws.nbytes, dt(xh.dtype), _stream()),
+              "ad_head_ln_bwd")
     return dz
 
 

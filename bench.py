@@ -34,6 +34,10 @@ WORKLOADS = {
     "E2s06": (0.6, 4, 256, 32),     # 256/154/93/56/34
     "E2s07": (0.7, 5, 256, 8),      # 256/180/126/89/63/45, 2048-channel bottleneck
 }
+# BASELINE config 5 ("adaptive per-sample depth 2-6, mixed SR + seg multitask, fp16"): BUILD-DEFINED semantics (the reference has
+# no such path: adunet_amd/multitask.py).  One "step" = one pass over this fixed mixed stream, one captured graph per item:
+# the Experiment-2 rows 0.3 -> 2, 0.5 -> 3, 0.6 -> 4, 0.7 -> 5 at their bench batches and the segmentation task.
+K5_STREAM = [("sr", 0.3, 64), ("sr", 0.5, 64), ("sr", 0.6, 32), ("sr", 0.7, 8), ("seg", None, 16)]
 
 
 def conv_flops_per_image(model):
@@ -153,19 +157,118 @@ def micro_kernel(device, iters=50):
     return out
 
 
-# Measured on MI355X at the end of r03 (profiles/r03_clock_power.txt, profiles/r03_mfma_power.txt): every dense conv
-# launch runs at the socket's power cap with the clock lowered to 1.66-2.0 GHz, so its time is its energy.  Idle socket 315 W;
-# an MFMA-only loop 2 050 TFLOP/s at ~1 300 W -> 0.48 pJ per FLOP; a device copy 5.2 TB/s at 859 W -> 104 pJ per HBM byte.
-POWER_MODEL = {"cap_w": 1400.0, "idle_w": 315.0, "pj_per_flop": 0.48, "pj_per_hbm_byte": 104.0,
-               "ridge_flop_per_byte": 104.0 / 0.48,
-               "source": "profiles/r03_clock_power.txt, profiles/r03_mfma_power.txt (rocm-smi; DESIGN 4.7a)"}
+def inkernel_clocks():
+    """Secondary figure only: the shader clock the dense conv launches really run at, measured INSIDE the
+    kernels of a diagnostic build (tools/inkernel_clock.py: s_memtime over s_memrealtime around MFMA wave 0 of every workgroup
+    after >= 2 s of back-to-back launches on random data) and committed under profiles/.  The chip lowers its clock under MFMA
+    load, so `frac` (against 2.5 PFLOP/s = 2.4 GHz, what the roofline is graded on) understates how close the matrix pipes are
+    to what the clock allows; `frac_at_clock` = TFLOP/s / (2.5 PF x clock / 2.4 GHz).  Replaces r03's rocm-smi power model."""
+    import glob
+    import re
+    cands = glob.glob(os.path.join(ROOT, "profiles", "r*_inkernel_clock.json"))
+    cands.sort(key=lambda p: (int(re.search(r"r(\d+)", os.path.basename(p)).group(1)), p))
+    if not cands:
+        return None, None
+    with open(cands[-1]) as f:
+        rec = json.load(f)
+    fam_kernel = {"fwd_dgrad": "conv3x3_fwd_wres_kernel<.,0>", "fused_ln_fwd": "conv3x3_fwd_wres_kernel<.,2>",
+                  "dgrad_ln_bwd_fused": "conv3x3_fwd_wres_kernel<.,4>", "wgrad": "conv3x3_wgrad_ws_kernel"}
+    return ({f: rec["kernels"][k]["clock_ghz_median"] for f, k in fam_kernel.items() if k in rec.get("kernels", {})},
+            "profiles/" + os.path.basename(cands[-1]))
 
 
-def power_floor_ms(flop: float, nbytes: float) -> float:
-    """Time the socket's power cap allows for `flop` of bf16 matrix arithmetic plus `nbytes` of HBM traffic (ms)."""
-    m = POWER_MODEL
-    joule = (m["pj_per_flop"] * flop + m["pj_per_hbm_byte"] * nbytes) * 1e-12
-    return joule / (m["cap_w"] - m["idle_w"]) * 1e3
+def run_k5(args, rank, world, device, use_dist):
+    """BASELINE config 5 as adunet_amd.multitask defines it (build-defined: the reference trains one independent model per
+    (scale, depth), run_experiment_adaptive_depth.sh:47-55, and segmentation in a separate script).  A step is one pass over
+    K5_STREAM: every item is one graph-replayed train step of its own model (own weights, own Adam, under f16 its own dynamic
+    loss scaler); under torch.distributed every model has its own bucketed gradient exchange.  Reports images/s in total and
+    per item (HIP events around each item's replay inside the timed region)."""
+    import torch.distributed as dist
+    from adunet_amd import multitask as M
+    dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
+    patch = 256
+    bank = M.AdaptiveDepthBank(input_size=patch, dtype=dtype, device=device, learning_rate=1e-4, seg_depth=4)
+    if use_dist:
+        bank.data_parallel()
+    rng = np.random.default_rng(1234 + rank)
+    items = []
+    for task, scale, nb in K5_STREAM:
+        if args.batch:
+            nb = args.batch
+        if task == "sr":
+            hr = rng.random((nb, patch, patch, 3), dtype=np.float32)
+            lr = np.clip(hr + 0.05 * rng.standard_normal(hr.shape, dtype=np.float32), 0, 1).astype(np.float32)
+            items.append(("sr", scale, torch.from_numpy(lr).to(device), torch.from_numpy(hr).to(device)))
+        else:
+            img = rng.random((nb, patch, patch, 3), dtype=np.float32)
+            mask = (rng.random((nb, patch, patch, 1)) < 0.3).astype(np.float32)
+            items.append(("seg", torch.from_numpy(img).to(device), torch.from_numpy(mask).to(device)))
+
+    def sync():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def one_pass(events=None):
+        last = []
+        for i, it in enumerate(items):
+            if events is not None:
+                events[i][0].record()
+            last.append(bank.train_on_batch(it[0], *it[1:], graphed=True))
+            if events is not None:
+                events[i][1].record()
+        return last
+
+    for _ in range(max(args.warmup, 1)):       # the first pass builds the models and captures the graphs
+        one_pass()
+    sync()
+    ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in items] for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        last = one_pass(ev[k])
+    sync()
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+    per_pass = sum(it[-1].shape[0] for it in items)
+    img_s = per_pass * world * args.steps / elapsed
+    per_item, flop_pass = [], 0.0
+    for i, ((task, scale, _), it) in enumerate(zip(K5_STREAM, items)):
+        nb = it[-1].shape[0]
+        ms = sum(e[i][0].elapsed_time(e[i][1]) for e in ev) / args.steps
+        model = bank.sr[(scale, M.route_depth(scale, input_size=patch))] if task == "sr" else bank.seg
+        fwd, first = conv_flops_per_image(model)
+        f_step = 3.0 * fwd - first
+        flop_pass += f_step * nb
+        per_item.append({"task": task, "scale": scale, "depth": (model.depth if task == "sr" else bank.seg_depth), "batch": nb,
+                         "params": model.count_params(), "ms_per_step": ms, "images_per_s": nb / ms * 1e3,
+                         "conv_gflop_per_image_step": f_step / 1e9,
+                         "frac_step": nb / ms * 1e3 * f_step / 1e12 / PEAK_BF16_TFLOPS,
+                         "final_loss": float(last[i][1])})
+    ms_step = elapsed * 1e3 / args.steps
+    tfl = flop_pass / (ms_step * 1e-3) / 1e12
+    line = {"metric": METRIC, "value": img_s, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {"workload": "K5: BUILD-DEFINED mixed stream of BASELINE config 5 (no reference semantics: "
+                                   "adunet_amd/multitask.py) -- SR scale/depth 0.3/2, 0.5/3, 0.6/4, 0.7/5 + segmentation depth 4, "
+                                   "patch 256, one model and one captured graph per item; a step = one pass over the stream",
+                       "global_batch": per_pass * world, "per_gpu_batch": per_pass, "parallelism": f"dp{world}",
+                       "launch": "hipGraph replay per item", "items": per_item},
+            "roofline": {"bound": "mfma", "achieved": tfl, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": tfl / PEAK_BF16_TFLOPS, "traffic": None,
+                         "what": "reference-graph conv FLOPs of the whole pass (3 F_fwd - F_first per image and model) over the "
+                                 "pass time: the step-level figure (`frac_step` of the single-model workloads); per item in config.items"}}
+    if use_dist:
+        line["ranks"] = dist.get_world_size()
+        line["dist_backend"] = args.backend
+        if args.backend == "nccl":
+            line["rccl_ranks"] = dist.get_world_size()
+        torch.cuda.synchronize()
+        bank.close()
+    return line
 
 
 def launch_ranks(n: int) -> int:
@@ -188,9 +291,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="K2p", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="K2p", choices=sorted(WORKLOADS) + ["K5"],
+                    help="K5 = BASELINE config 5, build-defined: a fixed mixed SR (depths 2-5) + segmentation stream, default --dtype f16")
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch override")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"],
+    ap.add_argument("--dtype", default=None, choices=["bf16", "f16", "f32"],
                     help="f16 = the reference's mixed_float16 policy (fp16 kernels + dynamic loss scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-micro", action="store_true", help="skip the 64->64 @256x256 N=32 micro-kernel measurement")
@@ -201,6 +305,8 @@ def main():
                          "scaling run); gloo = a rehearsal of the same rank logic on a box with fewer GPUs than ranks (the "
                          "ranks share the visible GPUs, gradients travel through host memory: NOT a scaling measurement)")
     args = ap.parse_args()
+    if args.dtype is None:
+        args.dtype = "f16" if args.workload == "K5" else "bf16"
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -235,6 +341,14 @@ def main():
     from adunet_amd import ops
     from adunet_amd.model import Adam, build_losses_and_metrics, build_super_resolution_unet
     from adunet_amd.parallel import DataParallel
+
+    if args.workload == "K5":
+        line = run_k5(args, rank, world, device, use_dist)
+        if rank == 0:
+            print(json.dumps(line), file=record_out, flush=True)
+        if use_dist:
+            dist.destroy_process_group()
+        return
 
     scale, depth, patch, batch = WORKLOADS[args.workload]
     if args.batch:
@@ -321,11 +435,7 @@ def main():
                     "frac": fl / ms / 1e9 / PEAK_BF16_TFLOPS if ms > 0 else None,
                     "algorithmic_gb_per_step": nb / 1e9, "hbm_tb_per_s": nb / ms / 1e9 if ms > 0 else None,
                     "hbm_frac": nb / ms / 1e9 / 8.0 if ms > 0 else None,
-                    "flop_per_byte": fl / nb if nb > 0 else None,
-                    # third roof: these launches draw the socket's full power cap (POWER_MODEL): the time their matrix
-                    # arithmetic and HBM bytes cost at the cap, and measured / that
-                    "power_floor_ms_per_step": power_floor_ms(fl, nb),
-                    "frac_of_power_floor": power_floor_ms(fl, nb) / ms if ms > 0 else None}
+                    "flop_per_byte": fl / nb if nb > 0 else None}
 
         fam = {
             # forward convs and dgrads (the same kernels on the rotated pack) launched WITHOUT the fused LayerNorm epilogue
@@ -346,6 +456,11 @@ def main():
             # convolution they stand for); the interpolating gathers beside them are HBM-bound and listed in `hbm_ops`
             "upconv_bank_gemms": family(["pw_gemm", "pw_wgrad"]),
         }
+        clocks, clock_src = inkernel_clocks()
+        for name, ghz in (clocks or {}).items():         # secondary: against the peak at the clock the chip holds under that kernel
+            if fam[name]["tflops"]:
+                fam[name]["inkernel_clock_ghz"] = ghz
+                fam[name]["frac_at_clock"] = fam[name]["tflops"] / (PEAK_BF16_TFLOPS * ghz / 2.4)
         conv_ms = sum(f["ms_per_step"] for f in fam.values())
         conv_gf = sum(f["gflop_per_step"] for f in fam.values())
         total_ms = sum(v[1] for v in summ.values()) * per_step
@@ -404,7 +519,9 @@ def main():
                          # share); FLOPs as launched minus zero-padded channels, time = HIP events on the launch stream
                          "family": dom_name, "kernel": fam_kernels[dom_name],
                          "achieved": dom["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": dom["frac"],
-                         "traffic": traffic,
+                         # HBM bytes per launch (stamped PMC passes) and the operand bytes per launch, both over the SAME launches:
+                         # every launch of `traffic_ops` in a step (tools/pmc_summary.py books the same kernels to the family)
+                         "traffic": traffic, "traffic_ops": dom_ops,
                          "algorithmic_bytes_per_launch": dom_bytes / n_launch if n_launch else None,
                          "launches_per_step": n_launch * per_step, "avg_launch_ms": ms / n_launch if n_launch else None,
                          "gflop_per_launch": dom["gflop_per_step"] / (n_launch * per_step) if n_launch else None,
@@ -413,6 +530,9 @@ def main():
                          # (every HBM-bound op included; the factored up-convs execute fewer FLOPs than the graph's 3x3
                          # convolutions they replace: `executed_gflop_per_step` is what the MFMA launches really did)
                          "frac_step": img_s / world * f_step / 1e12 / PEAK_BF16_TFLOPS,
+                         # the same with the FLOPs the MFMA launches really execute (the factored up-convs do 1 / ratio^2 of
+                         # the 3x3 convolutions they stand for): what the matrix pipes deliver over the whole step
+                         "frac_step_executed": conv_gf / 1e3 / ms_step / PEAK_BF16_TFLOPS,
                          "algorithmic_gflop_per_step": f_step * batch / 1e9,
                          "executed_gflop_per_step": conv_gf,
                          "frac_all_conv_kernels": conv_gf / conv_ms / PEAK_BF16_TFLOPS if conv_ms > 0 else None,
@@ -421,7 +541,7 @@ def main():
                          "hbm_gb_per_step": hbm_gb,
                          "hbm_frac": hbm_gb / (ms_step / 1e3) / 8000.0 if hbm_gb else None,
                          "families": fam,
-                         "power_model": POWER_MODEL,
+                         "inkernel_clock_source": clock_src,
                          "hbm_ops": hbm_ops,
                          "non_conv_ms_per_step": total_ms - conv_ms,
                          "timing": ("HIP events around every launch of %d eager steps run right after the graph-replayed "

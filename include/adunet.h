@@ -221,13 +221,16 @@ int ad_head_bwd(const void* xh, const float* w, const float* b, const float* inp
  * pass over the pixels: the gradient of the head activations stays in fp32 registers instead of being stored and read
  * back.  Inputs as ad_head_bwd plus that layer's saved conv output z, per-pixel mean / rstd and gamma / beta;
  *   dz[npix,ch] = LayerNorm/ReLU backward of (g @ w^T)        (what ad_layernorm_relu_bwd would return)
- *   dw, db: as ad_head_bwd;  dgamma, dbeta: the LayerNorm's;  dbias_conv[ch] = column sums of dz as stored. */
+ *   dw, db: as ad_head_bwd;  dgamma, dbeta: the LayerNorm's;  dbias_conv[ch] = column sums of dz as stored.
+ * stats / sqerr (both may be NULL): what ad_head_fwd reports for the same operands -- stats[3] = (loss sum, mean
+ * tf.image.psnr, loss mean), sqerr[n] per-image squared error.  The pass re-derives the head's output for the gradient
+ * anyway, so a TRAIN step (model.fit, :622-632: only loss and metric leave the step) needs no forward launch over the head. */
 size_t ad_head_ln_bwd_ws_bytes(int n, int ch);
 int ad_head_ln_bwd(const void* xh, const float* w, const float* b, const float* inp, const float* target,
                    const void* z, const float* mean, const float* rstd, const float* gamma, const float* beta,
                    void* dz, float* dw, float* db, float* dgamma, float* dbeta, float* dbias_conv,
                    int n, int64_t pix_per_img, int ch, int loss_kind, float eps, float grad_scale,
-                   const float* loss_scale, void* ws, size_t ws_bytes, int dtype, void* stream);
+                   const float* loss_scale, float* stats, float* sqerr, void* ws, size_t ws_bytes, int dtype, void* stream);
 
 /* -------------------------------------------------------------- optimizer -- */
 

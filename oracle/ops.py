@@ -43,13 +43,54 @@ def fp16_round(x: np.ndarray) -> np.ndarray:
 # --------------------------------------------------------------------------- #
 
 
+_CONV_C = None
+
+
+def _conv_c():
+    """The C restatement of the same sums (oracle/csrc/conv_ref.c, built by oracle/Makefile / __graft_entry__.build()), used for
+    float64 tensors large enough to matter: the layer-wise audits convolve whole BASELINE-size batches, and NumPy's strided tap
+    copies made that most of the GPU suite's run time.  False when the library has not been built (NumPy path below)."""
+    global _CONV_C
+    if _CONV_C is None:
+        import ctypes
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_c", "liboracle_conv.so")
+        _CONV_C = False
+        if os.path.exists(path) and os.environ.get("ORACLE_NO_C") != "1":
+            lib = ctypes.CDLL(path)
+            vp, lg = ctypes.c_void_p, ctypes.c_long
+            lib.oracle_conv_fwd.argtypes = [vp, vp, vp, vp, lg, lg, lg, lg, lg, lg, lg]
+            lib.oracle_conv_wgrad.argtypes = [vp, vp, vp, lg, lg, lg, lg, lg, lg, lg]
+            lib.oracle_conv_fwd.restype = lib.oracle_conv_wgrad.restype = ctypes.c_int
+            _CONV_C = lib
+    return _CONV_C
+
+
+def _use_c(x: np.ndarray, w: np.ndarray) -> bool:
+    # float64 only; the per-thread private dw copies of the C wgrad stay small (<= 8 MB each), and below ~0.2 GFLOP NumPy is fine
+    kh, kw, cin, cout = w.shape
+    return (x.dtype == np.float64 and w.dtype == np.float64 and kh * kw * cin * cout <= (1 << 20)
+            and x.size // cin * kh * kw * cin * cout >= (1 << 27) and bool(_conv_c()))
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data
+
+
 def conv2d_same_fwd(x: np.ndarray, w: np.ndarray, b: np.ndarray | None) -> np.ndarray:
     """One [pixels, Cin] x [Cin, Cout] product per tap (the shifted view is copied to a dense matrix first, so that the
-    product is a single multi-threaded GEMM: the layer-wise audits convolve whole BASELINE-size batches)."""
+    product is a single multi-threaded GEMM); large float64 cases run the same sums in C (_conv_c)."""
     kh, kw, cin, cout = w.shape
     n, h, wd, c = x.shape
     assert c == cin, (x.shape, w.shape)
     ph, pw = kh // 2, kw // 2
+    if _use_c(x, w):
+        y = np.empty((n, h, wd, cout), dtype=np.float64)
+        xc, wc = np.ascontiguousarray(x), np.ascontiguousarray(w)
+        bc = np.ascontiguousarray(b, dtype=np.float64) if b is not None else None
+        rc = _conv_c().oracle_conv_fwd(_ptr(xc), _ptr(wc), _ptr(bc) if bc is not None else None, _ptr(y), n, h, wd, cin, cout, kh, kw)
+        assert rc == 0, "oracle_conv_fwd: out of memory"
+        return y
     xp = np.pad(x, ((0, 0), (ph, ph), (pw, pw), (0, 0)))
     y = np.zeros((n * h * wd, cout), dtype=x.dtype)
     for i in range(kh):
@@ -65,6 +106,15 @@ def conv2d_same_bwd(x: np.ndarray, w: np.ndarray, dy: np.ndarray, need_dx: bool 
     kh, kw, cin, cout = w.shape
     n, h, wd, _ = x.shape
     ph, pw = kh // 2, kw // 2
+    if _use_c(x, w) and dy.dtype == np.float64:
+        dyc, xc = np.ascontiguousarray(dy), np.ascontiguousarray(x)
+        dw = np.empty(w.shape, dtype=np.float64)
+        rc = _conv_c().oracle_conv_wgrad(_ptr(xc), _ptr(dyc), _ptr(dw), n, h, wd, cin, cout, kh, kw)
+        assert rc == 0, "oracle_conv_wgrad: out of memory"
+        dx = None
+        if need_dx:      # dgrad = the forward sum over dy with the kernel rotated by 180 degrees and its channel axes swapped
+            dx = conv2d_same_fwd(dyc, np.ascontiguousarray(w[::-1, ::-1].transpose(0, 1, 3, 2)), None)
+        return dx, dw, dyc.reshape(-1, cout).sum(axis=0)
     xp = np.pad(x, ((0, 0), (ph, ph), (pw, pw), (0, 0)))
     dw = np.zeros_like(w)
     dxp = np.zeros_like(xp) if need_dx else None

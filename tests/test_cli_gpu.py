@@ -153,11 +153,14 @@ def test_bench_plain_and_under_torchrun_agree(device):
         # both roofs per family: the LayerNorm-forward launches move their operand bytes at 3-6 TB/s (the HBM side of the ridge)
         assert all({"hbm_tb_per_s", "flop_per_byte", "share_of_step"} <= set(f) for f in rf["families"].values())
         assert 2.5 < rf["families"]["fused_ln_fwd"]["hbm_tb_per_s"] < 8.0
-        # third roof (the conv launches run at the socket's power cap): no family beats the time its FLOPs and bytes cost at
-        # the cap, the plain conv / wgrad families come close to it
-        assert rf["power_model"]["cap_w"] == 1400.0
-        for name in ("fused_ln_fwd", "wgrad", "dgrad_ln_bwd_fused", "dgrad_relu_fused"):
-            assert 0.3 < rf["families"][name]["frac_of_power_floor"] < 1.05, (name, rf["families"][name])
+        # r04: traffic and operand bytes of the named family are quoted over the same launches; the executed-FLOP step fraction
+        # sits below the reference-graph one (factored up-convs); the r03 rocm-smi power model is gone from the line
+        assert rf["traffic_ops"] and "power_model" not in rf and rf["frac_step_executed"] < rf["frac_step"]
+        # secondary figure: fractions against the peak at the in-kernel clock (profiles/r*_inkernel_clock.json), when committed
+        if rf["inkernel_clock_source"]:
+            for name in ("fused_ln_fwd", "wgrad", "dgrad_ln_bwd_fused"):
+                f = rf["families"][name]
+                assert 1.2 < f["inkernel_clock_ghz"] <= 2.45 and f["frac"] <= f["frac_at_clock"] < 1.0, (name, f)
 
 
 def test_bench_starts_two_gloo_ranks_on_one_gpu(device):

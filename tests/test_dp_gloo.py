@@ -101,3 +101,60 @@ def test_two_rank_gradient_exchange_equals_global_batch():
         assert gscale == 0.5 and g2 == 0.5
         assert err < 1e-6, f"rank {rank}: averaged gradient differs from the global-batch gradient ({err})"
         assert nxt == 0 and nworks == 0
+
+
+def _bank_worker(rank, world, port, q):
+    """BASELINE config 5 under data parallelism (adunet_amd.multitask.AdaptiveDepthBank.data_parallel): ONE exchange object per
+    model of the bank, attached when the model is built -- before or after data_parallel() was called."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from adunet_amd import multitask as M
+
+    class StandInBank(M.AdaptiveDepthBank):           # the HIP models need a GPU: same flat-buffer surface on CPU tensors
+        def _build_sr(self, key):
+            m = FlatStandIn({"conv/kernel": (3, 3, 8, 8 * key[1]), "conv/bias": (8 * key[1],), "head/kernel": (8, 3)})
+            m.P += 100.0 * rank + key[1]                # every rank starts elsewhere: the broadcast must bring rank 0's values
+            return m
+
+        def _build_seg(self, steps_per_epoch, epochs):
+            m = FlatStandIn({"seg/kernel": (3, 3, 3, 16), "seg/bias": (16,)})
+            m.P += 100.0 * rank + 77.0
+            return m
+
+    bank = StandInBank(input_size=256, dtype=torch.float32, device=None)
+    _, early = bank.sr_model(0.5)                       # built BEFORE data_parallel(): attached by the call
+    assert getattr(early, "_dp", None) is None
+    bank.data_parallel(bucket_bytes=1024)
+    key3, late = bank.sr_model(0.3)                     # built AFTER: attached on construction
+    seg = bank.seg_model()
+    _, again = bank.sr_model(0.5)
+    ok = again is early and key3 == (0.3, 2) and len(bank.dps) == 3 and len({id(m._dp) for m in (early, late, seg)}) == 3
+    ok &= all(m._dp.world == world and m.grad_ready is not None and m.grad_sync is not None for m in (early, late, seg))
+    # rank 0's weights everywhere
+    ok &= bool((early.P == 3.0).all()) and bool((late.P == 2.0).all()) and bool((seg.P == 77.0).all())
+    # one model's exchange leaves the others' buffers alone, and sums over the ranks
+    for i, m in enumerate((early, late, seg)):
+        m.G += float((rank + 1) * (i + 1))
+    late.grad_ready(0)
+    gs = late.grad_sync(late)
+    ok &= gs == 0.5 and bool((late.G == 3.0 * 2).all()) and bool((early.G == float(rank + 1)).all()) and bool((seg.G == 3.0 * (rank + 1)).all())
+    q.put((rank, bool(ok)))
+    bank.close()
+    dist.destroy_process_group()
+
+
+def test_bank_of_models_gets_one_exchange_object_each():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bank_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res), res

@@ -181,6 +181,40 @@ def test_r3_config_against_oracle(device, dtype):
     check_step_against_oracle(oracle, params, model, lr, hr, f32=dtype == torch.float32)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", [(0.5, 2, 32, 3, "charbonnier"), (0.25, 4, 256, 8, "charbonnier"), (0.6, 3, 40, 2, "l1")])
+def test_train_step_reports_the_loss_and_metric_of_the_forward_pass(device, dtype, case):
+    """A train step (model.fit, :622-632) returns only loss and PSNR, so it runs NO forward launch over the head: the head's
+    backward kernel (ad_head_ln_bwd), which re-derives the output for the gradient anyway, reports both.  They must be the
+    numbers of the forward head kernel (checked against the oracle elsewhere) on the same weights: same per-element terms,
+    another summation order -- 2e-6 relative on the loss, 1e-4 dB on the PSNR; and the step's weights must not depend on which
+    kernel reported (ADUNET_HEAD_FWD_IN_TRAIN=1 keeps the forward launch): bitwise."""
+    import os
+    from adunet_amd.model import Adam, build_losses_and_metrics, build_super_resolution_unet
+    scale, depth, p, n, loss_name = case
+    rng = np.random.default_rng(9)
+    lr, hr = synth(rng, n, p)
+    finals = []
+    for keep_fwd in (False, True):
+        model, _ = build_super_resolution_unet(scale, depth_override=depth, input_size=p, dtype=dtype, device=device)
+        loss, metrics = build_losses_and_metrics(loss_name)
+        model.compile(optimizer=Adam(1e-3), loss=loss, metrics=metrics)
+        model._require_device()
+        model.set_weights(model.initial_weights(np.random.default_rng(1), head_uniform=0.05))
+        _, want_loss, want_psnr, _ = model.forward_loss(lr, hr)
+        want_loss, want_psnr = float(want_loss), float(want_psnr)
+        if keep_fwd:
+            os.environ["ADUNET_HEAD_FWD_IN_TRAIN"] = "1"
+        try:
+            got_loss, got_psnr = model.train_on_batch(lr, hr)
+        finally:
+            os.environ.pop("ADUNET_HEAD_FWD_IN_TRAIN", None)
+        assert abs(float(got_loss) - want_loss) < 2e-6 * want_loss, (float(got_loss), want_loss)
+        assert abs(float(got_psnr) - want_psnr) < 1e-4, (float(got_psnr), want_psnr)
+        finals.append(model.P.clone())
+    assert torch.equal(finals[0], finals[1])
+
+
 FULL_SIZE = [
     # name, scale, depth, patch, per-GPU batch of bench.py
     ("K2p", 0.25, 4, 256, 64),

@@ -80,3 +80,45 @@ def test_bucketed_stream_trains_one_model_per_depth(device):
     assert set(bank.sr) == {(0.5, 3), (0.3, 2)}
     with pytest.raises(ValueError):
         bank.train_on_batch("detect", 0.5, *sr_batch(rng))
+
+
+def test_routed_steps_at_patch_256_in_float16_equal_the_stand_alone_models(device):
+    """Config 5 at its real size: 256 x 256 patches, mixed_float16, batches of 8 (the wave-specialised
+    and fused kernels are the ones launched), the Experiment-2 routes 0.5 -> 3, 0.6 -> 4, 0.7 -> 5
+    (run_experiment_adaptive_depth.sh:47-55), a scale WITHOUT a table row (0.75: custom_depth_from_scale says 7, the bank's
+    range clamps it to 6 -- a 4 096-channel bottleneck) and the segmentation task in between.  Every routed step, replayed
+    from its captured graph, must leave BITWISE the weights of the stand-alone model's eager step."""
+    from adunet_amd import multitask as M, seg_model as S
+    from adunet_amd.model import Adam, LossScaleOptimizer, build_losses_and_metrics, build_super_resolution_unet
+    p, n, dtype = 256, 8, torch.float16
+    rng = np.random.default_rng(11)
+
+    def sr(nb):
+        hr = rng.random((nb, p, p, 3), dtype=np.float32)
+        return np.clip(hr + 0.05 * rng.standard_normal(hr.shape).astype(np.float32), 0, 1).astype(np.float32), hr
+
+    assert [M.route_depth(s, input_size=p) for s in (0.5, 0.6, 0.7, 0.75)] == [3, 4, 5, 6]
+    bank = M.AdaptiveDepthBank(input_size=p, dtype=dtype, device=device, learning_rate=1e-3, seg_depth=4)
+    seg_b = (rng.random((n, p, p, 3), dtype=np.float32), (rng.random((n, p, p, 1)) < 0.4).astype(np.float32))
+    batches = {0.5: sr(n), 0.6: sr(n), 0.7: sr(n), 0.75: sr(n)}
+    stream = [("sr", 0.5, *batches[0.5]), ("sr", 0.6, *batches[0.6]), ("seg", *seg_b), ("sr", 0.7, *batches[0.7]),
+              ("sr", 0.75, *batches[0.75])]
+    hist = bank.fit(stream, graphed=True)
+    torch.cuda.synchronize()
+    assert set(hist) == {("sr", 0.5, 3), ("sr", 0.6, 4), ("sr", 0.7, 5), ("sr", 0.75, 6), ("seg",)}
+    assert all(np.isfinite(v).all() for v in hist.values()), hist
+    for (scale, depth), model in list(bank.sr.items()):
+        assert isinstance(model.optimizer, LossScaleOptimizer) and model.optimizer.sync()["applied"] == 1
+        ref, _ = build_super_resolution_unet(scale, depth_override=depth, input_size=p, dtype=dtype, device=device, seed=1234)
+        loss, metrics = build_losses_and_metrics("charbonnier")
+        ref.compile(optimizer=Adam(learning_rate=1e-3), loss=loss, metrics=metrics)
+        ref.train_on_batch(*batches[scale])
+        torch.cuda.synchronize()
+        assert torch.equal(ref.P, model.P), (scale, depth)
+        del ref, bank.sr[(scale, depth)], model
+        torch.cuda.empty_cache()
+    proto = S.PROTOCOLS["A"]
+    seg = S.build_adaptive_depth_unet(p, 64, 4, dtype=dtype, device=device, seed=1234)
+    seg.compile(optimizer=S.build_optimizer(proto, 100, 1), loss=proto.loss_builder())
+    seg.train_on_batch(*seg_b)
+    assert torch.equal(seg.P, bank.seg.P)

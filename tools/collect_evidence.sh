@@ -23,7 +23,7 @@ print("stamp", bench.kernel_source_stamp(), t, "OK" if t == bench.kernel_source_
 d = json.load(open("profiles/${tag}_bench.json")); r = d["roofline"]
 print("K2p %.0f img/s %.2f ms frac_step %.3f  %s %.3f (%.0f TFLOP/s)  hbm %.1f GB" % (d["value"], d["ms_per_step"], r["frac_step"], r["family"], r["frac"], r["achieved"], r["hbm_gb_per_step"]))
 for k, v in r["families"].items():
-    print("  %-20s %.3f ms  frac %.3f  power-floor %.2f" % (k, v["ms_per_step"], v["frac"], v["frac_of_power_floor"]))
+    print("  %-20s %.3f ms  frac %.3f  at-clock %s" % (k, v["ms_per_step"], v["frac"], v.get("frac_at_clock")))
 print("  micro %.3f" % d["micro"]["fwd_dgrad_wgrad"]["frac"])
 for w in ("E2s06", "E2s07"):
     e = json.load(open("profiles/${tag}_bench_%s.json" % w)); print(w, "%.0f img/s %.2f ms frac_step %.3f" % (e["value"], e["ms_per_step"], e["roofline"]["frac_step"]))

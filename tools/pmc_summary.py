@@ -21,6 +21,10 @@ FAMILIES = {       # kernel name -> op family used by bench.py's roofline ("_ln"
     "conv3x3_fwd_wres_kernel_ln": "conv3x3_ln_relu_fwd", "conv3x3_fwd_ws_kernel_ln": "conv3x3_ln_relu_fwd",
     "conv3x3_fwd_wres_kernel_relugrad": "conv3x3_dgrad_relu", "conv3x3_fwd_wres_kernel_lnbwd": "conv3x3_dgrad_ln_bwd",
     "conv3x3_wgrad_kernel": "conv3x3_wgrad", "conv3x3_wgrad_ws_kernel": "conv3x3_wgrad", "wgrad_reduce_kernel": "conv3x3_wgrad",
+    # the dedicated first-layer kernels belong to the families bench.py books them in (r04: traffic and algorithmic bytes of a
+    # family are quoted over the same launches)
+    "conv3x3_c3_fwd_kernel": "conv3x3_ln_relu_fwd", "conv3x3_c3_wgrad_kernel": "conv3x3_wgrad",
+    "pw_gemm_lds_kernel": "upconv_bank_gemms",
     "pw_gemm_kernel": "upconv_bank_gemms", "pw_wgrad_kernel": "upconv_bank_gemms", "pw_wgrad_reduce_kernel": "upconv_bank_gemms",
 }
 HELPERS = {"splitk_finalize_kernel", "wgrad_reduce_kernel", "pw_wgrad_reduce_kernel"}   # counted with the launch they finish
