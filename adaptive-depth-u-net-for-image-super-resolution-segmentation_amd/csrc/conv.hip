@@ -703,18 +703,24 @@ __device__ __forceinline__ void ws_pack_tile(const f32x4 (&acc)[4][4], const flo
         // and this VALU work sits between the MFMA phases of two items (it is not hidden behind anything)
         float mean = 0.f, rstd = 0.f;
         if (EPI == 2) {
+            // Two passes, as LayerNormalization itself (mean, then the mean of squared DEVIATIONS) and ln_fwd_kernel: until r03 this
+            // was E[x^2] - mean^2 in one pass, whose cancellation costs (mean / std)^2 * 2^-24 of the variance -- 10 % at
+            // mean / std = 1 000 (test_fused_layernorm_epilogue_with_a_large_mean_offset; found through ADVICE r03).  Price: eight
+            // packed subtracts and a second, dependent lane-group sum per m-tile.
             f32x2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-                const f32x2 lo = acc[mt][nt].xy, hi = acc[mt][nt].zw;
-                s1 += lo; s1 += hi;
+                s1 += acc[mt][nt].xy; s1 += acc[mt][nt].zw;
+            }
+            mean = sum_lane_groups(s1.x + s1.y) * (1.f / 64.f);
+            const f32x2 nm2 = {-mean, -mean};
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const f32x2 lo = acc[mt][nt].xy + nm2, hi = acc[mt][nt].zw + nm2;
                 s2 = __builtin_elementwise_fma(lo, lo, s2);
                 s2 = __builtin_elementwise_fma(hi, hi, s2);
             }
-            const float t1 = sum_lane_groups(s1.x + s1.y);
-            const float t2 = sum_lane_groups(s2.x + s2.y);
-            mean = t1 * (1.f / 64.f);
-            rstd = rsqrtf(fmaxf(t2 * (1.f / 64.f) - mean * mean, 0.f) + eps);
+            rstd = rsqrtf(sum_lane_groups(s2.x + s2.y) * (1.f / 64.f) + eps);
             const unsigned so = ok && grp == 0 ? (unsigned)((pixbase + (wave * 4 + mt) * img_w + (lane & 15)) * 4) : WR_OOB;
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, mean), rsm, so, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, rstd), rsr, so, 0, 0);

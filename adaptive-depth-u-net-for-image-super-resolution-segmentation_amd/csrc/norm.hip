@@ -313,12 +313,12 @@ int ln_bwd_launch(const void* dy, const void* z, const float* mean, const float*
     size_t need = (size_t)blocks * 3 * c * sizeof(float);
     if (!ws || ws_bytes < need) return ad_set_error(AD_ERR_WS, "layernorm bwd: workspace %zu < %zu", ws_bytes, need);
     size_t lds = (size_t)(256 / cfg.g) * 3 * c * sizeof(float);
-    if (lds > 160 * 1024) return ad_set_error(AD_ERR_ARG, "layernorm bwd: c=%d needs %zu B LDS", c, lds);
+    if (lds > 160 * 1024 - 64) return ad_set_error(AD_ERR_ARG, "layernorm bwd: c=%d needs %zu B LDS", c, lds);
     DISPATCH_NVG_BWD(
         auto kern = ln_bwd_kernel<T, NV_, G_, MODE>;
-        if (lds > 64 * 1024)
+        if (lds > 64 * 1024)       // (dynamic + the kernel's 32 static bytes must stay within the CU's 160 KB)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      160 * 1024);
+                                      (int)lds);
         kern<<<blocks, 256, lds, s>>>((const T*)dy, (const T*)z, mean, rstd, gamma, beta, (T*)dz, (float*)ws, npix, c);)
     AD_LAUNCH_CHECK("layernorm bwd");
     colsum_reduce_kernel<<<(3 * c + 3) / 4, 256, 0, s>>>((const float*)ws, blocks, c, dgamma, dbeta, dbias);
