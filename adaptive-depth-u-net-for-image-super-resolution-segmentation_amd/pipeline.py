@@ -362,8 +362,9 @@ class PrefetchPatchLoader:
             lr, hr = degrade(torch.from_numpy(hr_u8).to(device, non_blocking=True))
     """
 
-    def __init__(self, hr_files: Sequence[str], patch_size: int, batch_size: int, seed: int = 1234, workers: int = 4,
+    def __init__(self, hr_files: Sequence, patch_size: int, batch_size: int, seed: int = 1234, workers: int = 4,
                  slots: int = 8, shard: Tuple[int, int] = (0, 1), patches_per_image: int = 4):
+        """hr_files: image paths, or already decoded [H, W, 3] uint8 arrays (a synthetic in-memory set: bench.py --feed loader)."""
         import multiprocessing as mp
         from multiprocessing import shared_memory
         hr_files = list(hr_files)
@@ -373,9 +374,14 @@ class PrefetchPatchLoader:
             raise ValueError("patch_size, batch_size, workers and patches_per_image must be positive; slots >= 2.")
         self.cache = []
         for path in hr_files:                                      # decode once, keep 8-bit
-            from PIL import Image
-            with Image.open(str(path)) as im:
-                arr = np.asarray(im.convert("RGB"), np.uint8)
+            if isinstance(path, np.ndarray):
+                arr = np.ascontiguousarray(path, np.uint8)
+                if arr.ndim != 3 or arr.shape[2] != 3:
+                    raise ValueError("decoded images must be [H, W, 3] uint8 arrays.")
+            else:
+                from PIL import Image
+                with Image.open(str(path)) as im:
+                    arr = np.asarray(im.convert("RGB"), np.uint8)
             if arr.shape[0] < patch_size or arr.shape[1] < patch_size:
                 raise ValueError("patch_size exceeds image dimensions.")
             self.cache.append(arr)
@@ -437,13 +443,56 @@ class FastFeedDataset:
         self._degrade = None
 
     def __iter__(self):
+        """The uint8 crops of batch i + 1 cross PCIe on a copy stream while the GPU trains on batch i: the ring's shared memory is
+        page-locked (where the runtime allows it), two device staging buffers alternate, events order the copy stream against the
+        compute stream in both directions, and a ring slot goes back to the crop workers only after its copy has completed."""
         import torch
         if self._degrade is None:
             dev = torch.device(self.device) if self.device is not None else torch.device("cuda", torch.cuda.current_device())
             self._degrade = DeviceDegrader(self.patch_size, self.scale, dev)
             self.device = dev
-        for hr_u8 in self.loader:
-            yield self._degrade(torch.from_numpy(hr_u8).to(self.device, non_blocking=False))
+        dev = self.device
+        ring = self.loader._ring
+        self.pinned = False
+        try:            # page-lock the ring once: asynchronous host -> device copies need it (hipHostRegister)
+            rc = torch.cuda.cudart().cudaHostRegister(ring.ctypes.data, ring.nbytes, 0)
+            self.pinned = (int(rc) == 0) if rc is not None else True
+        except Exception:
+            self.pinned = False
+        copy_stream = torch.cuda.Stream(device=dev)
+        shape = (self.loader.batch_size, self.patch_size, self.patch_size, 3)
+        stage = [torch.empty(shape, dtype=torch.uint8, device=dev) for _ in range(2)]
+        consumed = [None, None]                                       # compute-stream events: the staging buffer has been read
+        self.h2d_bytes_per_batch = int(np.prod(shape))
+
+        def issue(k, host_u8):
+            with torch.cuda.stream(copy_stream):
+                if consumed[k] is not None:
+                    copy_stream.wait_event(consumed[k])
+                stage[k].copy_(torch.from_numpy(host_u8), non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(copy_stream)
+            return ev
+
+        k = 0
+        ev = issue(k, next(self.loader))
+        while True:
+            ev.synchronize()                                          # host: the slot behind this copy may be refilled
+            nxt = issue(k ^ 1, next(self.loader))                     # (next() hands the previous slot back to the workers)
+            torch.cuda.current_stream().wait_event(ev)
+            out = self._degrade(stage[k])
+            consumed[k] = torch.cuda.Event()
+            consumed[k].record(torch.cuda.current_stream())
+            yield out
+            k, ev = k ^ 1, nxt
 
     def close(self):
+        if getattr(self, "pinned", False):
+            try:
+                import torch
+                torch.cuda.synchronize()
+                torch.cuda.cudart().cudaHostUnregister(self.loader._ring.ctypes.data)
+            except Exception:
+                pass
+            self.pinned = False
         self.loader.close()

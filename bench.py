@@ -296,6 +296,12 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch override")
     ap.add_argument("--dtype", default=None, choices=["bf16", "f16", "f32"],
                     help="f16 = the reference's mixed_float16 policy (fp16 kernels + dynamic loss scaling)")
+    ap.add_argument("--feed", default="resident", choices=["resident", "loader"],
+                    help="loader: after the resident-batch timed region (which stays `value`), time the same graph-replayed step fed "
+                         "by the host data path -- PrefetchPatchLoader crop workers on a synthetic in-memory uint8 image set, uint8 "
+                         "crops over PCIe, DeviceDegrader LR synthesis in HBM (shared/pipeline.py:214-246's contract) -- and report it "
+                         "as `feed`")
+    ap.add_argument("--feed-workers", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-micro", action="store_true", help="skip the 64->64 @256x256 N=32 micro-kernel measurement")
     ap.add_argument("--breakdown", action="store_true", help="print the per-op-family time table to stderr")
@@ -318,6 +324,15 @@ def main():
         raise SystemExit(launch_ranks(args.gpus))
     if world != args.gpus:
         args.gpus = world
+    feed_ds = None
+    if args.feed == "loader" and args.workload != "K5":
+        # the crop workers are FORKED: start them before this process touches the GPU (they only ever run NumPy)
+        from adunet_amd.pipeline import FastFeedDataset
+        f_scale, _, f_patch, f_batch = WORKLOADS[args.workload]
+        rng_img = np.random.default_rng(99 + rank)
+        images = [rng_img.integers(0, 256, (2 * f_patch, 2 * f_patch, 3), dtype=np.uint8) for _ in range(48)]
+        feed_ds = FastFeedDataset(images, f_patch, args.batch or f_batch, f_scale, patches_per_image=4, seed=1234,
+                                  workers=args.feed_workers, shard=(rank, world))
     # stdout carries exactly ONE line, the JSON record: libraries that write to file descriptor 1 (RCCL prints a version
     # banner there when its first communicator is created) are pointed at stderr for the rest of the run
     sys.stdout.flush()
@@ -398,6 +413,39 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
+
+    feed = None
+    if feed_ds is not None:
+        # the same step, fed by the host data path instead of one resident batch: crop workers -> shared-memory ring -> uint8
+        # over PCIe on a copy stream (one batch ahead) -> LR synthesis in HBM -> copy into the graph's static inputs -> replay
+        feed_ds.device = device
+        it = iter(feed_ds)
+        for _ in range(max(args.warmup, 2)):
+            step_fn(*next(it))
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step_fn(*next(it))
+        sync()
+        feed_elapsed = time.perf_counter() - t0
+        # the loader alone (no GPU work): what the crop workers and the ring sustain
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            next(feed_ds.loader)
+        loader_elapsed = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([feed_elapsed], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            feed_elapsed = float(t[0])
+        feed = {"images_per_s": batch * world * args.steps / feed_elapsed, "ms_per_step": feed_elapsed * 1e3 / args.steps,
+                "fraction_of_resident_rate": (elapsed / feed_elapsed),
+                "h2d_bytes_per_step": feed_ds.h2d_bytes_per_batch, "host_ring_page_locked": bool(feed_ds.pinned),
+                "crop_workers": args.feed_workers, "loader_alone_images_per_s": batch * args.steps / loader_elapsed,
+                "path": "PrefetchPatchLoader (48 synthetic 512x512 uint8 images, forked crop workers, shared-memory ring) -> uint8 "
+                        "crops over PCIe on a copy stream, one batch ahead -> DeviceDegrader (INTER_AREA shrink + INTER_CUBIC "
+                        "enlarge as two ad_resample launches) -> graph replay"}
+        del it
+        feed_ds.close()
 
     exposed_ms = None
     if use_dist:
@@ -557,6 +605,8 @@ def main():
                                 "a scaling measurement" % (world, torch.cuda.device_count()))
             line["exposed_comm_ms_per_step"] = exposed_ms
             line["exchange"] = "ad_allreduce_bucket" if model._dp._native is not None else "torch.distributed.all_reduce"
+        if feed is not None:
+            line["feed"] = feed
         if world == 1 and args.dtype == "bf16" and not args.no_micro:
             line["micro"] = micro_kernel(device)
         if world == 1 and not args.no_cpu_baseline:

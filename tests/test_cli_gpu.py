@@ -191,6 +191,24 @@ def test_bench_starts_two_gloo_ranks_on_one_gpu(device):
     assert bad.returncode != 0 and not [l for l in bad.stdout.splitlines() if l.startswith("{")]
 
 
+def test_bench_feed_loader_reports_the_fed_rate(device):
+    """`bench.py --feed loader`: the resident-batch figure stays `value`; beside it the same graph-replayed
+    step fed by the host data path (crop workers -> shared-memory ring -> uint8 over PCIe -> LR synthesis in HBM), with the H2D
+    bytes per step (uint8 HR crops only: B x P x P x 3)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--feed", "loader", "--feed-workers", "2", "--steps", "6",
+                          "--warmup", "2", "--batch", "8", "--no-cpu-baseline", "--no-micro"],
+                         capture_output=True, text=True, timeout=600, cwd=root)
+    assert run.returncode == 0, run.stderr[-3000:]
+    rec = json.loads(run.stdout.strip().splitlines()[-1])
+    feed = rec["feed"]
+    assert feed["h2d_bytes_per_step"] == 8 * 256 * 256 * 3 and feed["images_per_s"] > 0 and feed["loader_alone_images_per_s"] > 0
+    assert 0.05 < feed["fraction_of_resident_rate"] < 1.2 and rec["value"] > 0 and np.isfinite(rec["config"]["final_loss"])
+
+
 def test_experiment_sweep_launcher(device, tmp_path):
     """Two rows of the Experiment-2 table end to end: per-run metadata files with the reference's keys, checkpoints,
     and the summary table with the offline Y-channel metrics."""

@@ -437,9 +437,17 @@ def test_fused_layernorm_epilogue_with_a_large_mean_offset(device, dtype):
         xs = slice(0 if x0 == 0 else 1, (x1 - x0) if x1 == w else (x1 - x0 - 1))
         ga = act[img, y0:y1, x0:x1].to(torch.float64).cpu().numpy()[ys, xs]
         assert abs(zw.mean() / zw.std(-1).mean()) > 500
-        assert (np.abs(ga - aw[ys, xs]) <= store * np.abs(aw[ys, xs]) + 1e-3).all(), float(np.abs(ga - aw[ys, xs]).max())
         gm = mean.view(n, h, w)[img, y0:y1, x0:x1].to(torch.float64).cpu().numpy()[ys, xs]
-        assert np.abs(gm - zw.mean(-1)[ys, xs]).max() < 1e-6 * 2400 * 4
+        gr = rstd.view(n, h, w)[img, y0:y1, x0:x1].to(torch.float64).cpu().numpy()[ys, xs]
+        rs = 1.0 / np.sqrt(zw.var(-1) + 1e-3)
+        # statistics: the accumulators carry the fp32 rounding of 18 MFMA steps at magnitude 2 400 (ulp 2.4e-4); the one-pass
+        # variance of r03 was off by up to 10 % here
+        assert np.abs(gm - zw.mean(-1)[ys, xs]).max() < 2e-2, float(np.abs(gm - zw.mean(-1)[ys, xs]).max())
+        assert np.abs(gr / rs[ys, xs] - 1).max() < 5e-3, float(np.abs(gr / rs[ys, xs] - 1).max())
+        # activation: one stored value's rounding plus what the accumulators' rounding at this magnitude moves xhat by (a few
+        # 1e-3 x rstd x gamma; it can carry a value across a 16-bit rounding boundary: one ulp = 2^-7 |a|)
+        err = np.abs(ga - aw[ys, xs])
+        assert (err <= 2 * store * np.abs(aw[ys, xs]) + 5e-3).all(), float(err.max())
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])

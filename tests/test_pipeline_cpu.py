@@ -203,6 +203,15 @@ def test_prefetch_loader_streams_crops_from_the_decoded_cache(tmp_path):
         loader.close()
     with pytest.raises(ValueError):
         pipeline.PrefetchPatchLoader(files, patch_size=64, batch_size=2)      # patch larger than the images
+    # already decoded arrays (the synthetic in-memory set of `bench.py --feed loader`) are taken as they are
+    arrays = [np.full((24, 24, 3), 7 * (i + 1), np.uint8) for i in range(2)]
+    loader = pipeline.PrefetchPatchLoader(arrays, patch_size=16, batch_size=3, seed=1, workers=1, slots=2)
+    try:
+        assert {int(v) for _ in range(4) for v in np.unique(next(loader))} == {7, 14}
+    finally:
+        loader.close()
+    with pytest.raises(ValueError):
+        pipeline.PrefetchPatchLoader([np.zeros((24, 24), np.uint8)], patch_size=16, batch_size=2)
 
 
 def test_croppers_follow_the_reference_contract():

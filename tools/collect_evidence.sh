@@ -16,6 +16,9 @@ for w in E2s06 E2s07; do
   cp $o/bench_$w.json profiles/${tag}_bench_$w.json
   cp $o/op_breakdown_$w.txt profiles/${tag}_op_breakdown_$w.txt
 done
+for f in bench_K5.json bench_feed.json layers_K2p.txt inkernel_clock.json inkernel_clock.txt; do
+  [ -f $o/$f ] && cp $o/$f profiles/${tag}_$f
+done
 python3 - <<PY
 import json, bench
 t = json.load(open("profiles/${tag}_pmc_traffic.json"))["kernel_source_stamp"]

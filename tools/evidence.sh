@@ -25,4 +25,12 @@ cp "$(ls $out/prof/*/*_kernel_stats.csv | head -1)" "$out/kernel_stats.csv"
 for w in E2s06 E2s07; do
     python3 bench.py --workload $w --steps 10 --warmup 3 --breakdown --no-cpu-baseline --no-micro > "$out/bench_$w.json" 2> "$out/op_breakdown_$w.txt" || exit 1
 done
+#   5. r04: BASELINE config 5 (build-defined mixed stream), the fed rate beside the resident one, the per-launch table of K2p,
+#      and the in-kernel clock table when the diagnostic build ab/clock.so (tools/build_variant.sh clock -DAD_CLOCK) is present
+python3 bench.py --workload K5 --steps 8 --warmup 2 > "$out/bench_K5.json" 2> "$out/bench_K5.err" || exit 1
+python3 bench.py --feed loader --no-cpu-baseline --no-micro --steps 40 > "$out/bench_feed.json" 2> "$out/bench_feed.err" || exit 1
+python3 tools/layer_table.py --workload K2p > "$out/layers_K2p.txt" 2>&1 || exit 1
+if [ -f ab/clock.so ]; then
+    ADUNET_LIB=ab/clock.so python3 tools/inkernel_clock.py --json "$out/inkernel_clock.json" > "$out/inkernel_clock.txt" 2>&1 || exit 1
+fi
 tail -3 "$out/pmc_summary.txt"; cat "$out/bench.json" | head -c 600; echo
