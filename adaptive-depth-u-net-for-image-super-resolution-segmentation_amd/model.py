@@ -36,10 +36,6 @@ DEFAULT_RESIDUAL_HEAD_CHANNELS = 64   # train_adaptive_unet.py:57
 # --------------------------------------------------------------------------- #
 # Losses / metrics / optimizer descriptors (train_adaptive_unet.py:294-373, :489-494)
 # --------------------------------------------------------------------------- #
-# weight gradients of feature maps with at most this many pixels per launch go to the backward pass's second stream (Model._backward)
-SIDE_STREAM_MAX_PIXELS = 64 * 16 * 16
-
-
 class _Loss:
     def __init__(self, name: str, kind: int, eps: float):
         self.__name__ = name
@@ -202,8 +198,6 @@ class Model:
         self._packs: Dict[str, Tuple[torch.Tensor, Optional[torch.Tensor]]] = {}
         self._banks: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}
         self._ws: Optional[ops.Workspace] = None
-        self._side: Optional[torch.cuda.Stream] = None      # second HIP stream of the backward pass (small-map weight gradients)
-        self._ws_side: Optional[ops.Workspace] = None
         self.optimizer: Optional[Adam] = None
         self.loss = None
         self.metrics_names: List[str] = []
@@ -613,32 +607,10 @@ class Model:
         d = None
         relu_done = False
         dz_ready = None           # dz of the next "cla" record when the head's backward already produced it
-        # Weight gradients of the small maps on a second HIP stream: a wgrad depends only on dz and the layer's input, nothing
-        # in the backward chain depends on it, and on the 16 x 16 ... 1 x 1 levels every launch (wgrad, its slab reduce, the dgrad
-        # and LayerNorm launches of the chain) leaves most of the chip idle -- two such streams fill each other's gaps.  (r02
-        # measured the same for ALL weight gradients and lost: two chip-filling kernels only take turns.)  Not under
-        # DataParallel: gradient finality (`_done`) is signalled on the compute stream.  The side stream has its own scratch
-        # buffer, is forked / joined with events (so the pair is capturable into one hipGraph), and the tensors it reads stay
-        # referenced until the join.
-        side_ok = (self.grad_ready is None and x.is_cuda and os.environ.get("ADUNET_NO_SIDE_STREAM") != "1")
-        side_keep: List[tuple] = []
-
-        def wgrad_launch(fn, dz_t, *tensors):
-            """fn(ws) launches one weight gradient (and its reduce); small maps go to the side stream."""
-            if not (side_ok and dz_t.shape[0] * dz_t.shape[1] * dz_t.shape[2] <= SIDE_STREAM_MAX_PIXELS):
-                fn(ws)
-                return
-            if self._side is None:
-                self._side = torch.cuda.Stream(device=self.device)
-                self._ws_side = ops.Workspace(self.device)
-            main = torch.cuda.current_stream()
-            fork = torch.cuda.Event()
-            fork.record(main)
-            self._side.wait_event(fork)
-            with torch.cuda.stream(self._side):
-                fn(self._ws_side)
-            side_keep.append((dz_t,) + tensors)
-
+        # (r04, measured and withdrawn: the weight gradients of the 16 x 16 ... 1 x 1 levels on a second HIP stream, forked /
+        # joined with events inside the captured graph, own scratch buffer -- 11.24 against 11.08 ms per K2' step, three
+        # alternating rounds on one box.  r02 had measured the same for all weight gradients; even these launches, which leave
+        # most of the chip idle, do not fill each other's gaps through the graph's cross-stream dependencies.)
         while tape:
             rec = tape.pop()
             kind = rec[0]
@@ -681,8 +653,7 @@ class Model:
                 if x1.dtype == torch.float32 and self.dtype != torch.float32:      # raw 3-channel batch: first layer
                     ops.conv3x3_c3_wgrad(x1, dz, self.grad(cs.name + "/kernel"), ws)
                 else:
-                    wgrad_launch(lambda w_, x1=x1, x2=x2, dz=dz, cs=cs: ops.conv3x3_wgrad(x1, x2, dz, self.grad(cs.name + "/kernel"),
-                                                                                        cs.cin, w_), dz, x1, x2)
+                    ops.conv3x3_wgrad(x1, x2, dz, self.grad(cs.name + "/kernel"), cs.cin, ws)
                 self._done(cs.name + "/kernel")
                 dsk = None
                 fused_relu = False
@@ -728,8 +699,7 @@ class Model:
                 # (already the pre-activation gradient, bias gradient included, when the dgrad above fused the ReLU)
                 dz = d if relu_done else ops.relu_bwd(d, u, self.grad(cs.name + "/bias"), ws)
                 relu_done = False
-                wgrad_launch(lambda w_, xin=xin, dz=dz, cs=cs: ops.conv3x3_wgrad(xin, None, dz, self.grad(cs.name + "/kernel"), cs.cin, w_),
-                             dz, xin)
+                ops.conv3x3_wgrad(xin, None, dz, self.grad(cs.name + "/kernel"), cs.cin, ws)
                 self._done(cs.name + "/kernel")
                 d = ops.conv3x3_fwd(dz, None, self._packs[cs.name][1], None, cs.cin)
                 if audit is not None:
@@ -741,8 +711,7 @@ class Model:
                 dz = d if relu_done else ops.relu_bwd(d, u, self.grad(cs.name + "/bias"), ws)
                 relu_done = False
                 dyb = ops.upconv_gather_bwd(dz, tab)
-                wgrad_launch(lambda w_, xin=xin, dyb=dyb, cs=cs: ops.upconv_bank_wgrad(xin, dyb, self.grad(cs.name + "/kernel"), w_),
-                             dyb, xin)
+                ops.upconv_bank_wgrad(xin, dyb, self.grad(cs.name + "/kernel"), ws)
                 self._done(cs.name + "/kernel")
                 d = ops.pw_gemm(dyb, self._banks[cs.name][1], cs.cin)
                 if audit is not None:
@@ -773,11 +742,6 @@ class Model:
                     d = self.enc_down.resize_grad(d, h, w, out=acc)
                     if audit is not None:
                         audit.append(("bwd_resize", "enc_down", d_in, before, d))
-        if side_keep:            # join: everything after the backward pass (the optimizer) follows the side stream's launches
-            join = torch.cuda.Event()
-            join.record(self._side)
-            torch.cuda.current_stream().wait_event(join)
-            side_keep.clear()
 
     def _done(self, name: str):
         if self.grad_ready is not None:

@@ -580,7 +580,7 @@ def main():
                          "frac_step": img_s / world * f_step / 1e12 / PEAK_BF16_TFLOPS,
                          # the same with the FLOPs the MFMA launches really execute (the factored up-convs do 1 / ratio^2 of
                          # the 3x3 convolutions they stand for): what the matrix pipes deliver over the whole step
-                         "frac_step_executed": conv_gf / 1e3 / ms_step / PEAK_BF16_TFLOPS,
+                         "frac_step_executed": conv_gf / ms_step / PEAK_BF16_TFLOPS,      # GFLOP per ms = TFLOP/s
                          "algorithmic_gflop_per_step": f_step * batch / 1e9,
                          "executed_gflop_per_step": conv_gf,
                          "frac_all_conv_kernels": conv_gf / conv_ms / PEAK_BF16_TFLOPS if conv_ms > 0 else None,
