@@ -146,6 +146,8 @@ class IsicDataset:
         self._pass = 0
         self._cache = {} if cache else None
         self.prefetch = int(prefetch)
+        import threading
+        self._cache_lock = threading.Lock()
 
     def __len__(self) -> int:
         return math.ceil(len(self.pairs) / self.batch_size)
@@ -185,23 +187,40 @@ class IsicDataset:
         import threading
         q: "queue.Queue" = queue.Queue(maxsize=self.prefetch)
         done = object()
+        stop = threading.Event()       # set when the consumer leaves (break, exception, garbage-collected generator)
+
+        def put(item) -> bool:
+            while not stop.is_set():
+                try:
+                    q.put(item, timeout=0.1)
+                    return True
+                except queue.Full:
+                    continue
+            return False
 
         def produce():
             try:
-                for item in source:
-                    q.put(item)
-                q.put(done)
+                with self._cache_lock:          # one pass fills / reads the cache at a time (an abandoned pass ends first)
+                    for item in source:
+                        if not put(item):
+                            return
+                put(done)
             except BaseException as exc:        # surfaces in the consumer
-                q.put(exc)
+                put(exc)
 
-        threading.Thread(target=produce, daemon=True).start()
-        while True:
-            item = q.get()
-            if item is done:
-                return
-            if isinstance(item, BaseException):
-                raise item
-            yield item
+        worker = threading.Thread(target=produce, daemon=True)
+        worker.start()
+        try:
+            while True:
+                item = q.get()
+                if item is done:
+                    return
+                if isinstance(item, BaseException):
+                    raise item
+                yield item
+        finally:            # also runs on generator close(): the producer stops instead of blocking in put() for ever
+            stop.set()
+            worker.join(timeout=5.0)
 
 
 def build_isic_dataset(image_dir, mask_dir, batch_size: int, image_size: int, augment: bool, shuffle: bool, seed: int):

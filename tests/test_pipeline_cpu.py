@@ -264,3 +264,19 @@ def test_isic_dataset_cache_and_prefetch_give_the_same_stream(tmp_path):
             assert np.array_equal(ia, ib) and np.array_equal(ma, mb) and ia.dtype == np.float32 and set(np.unique(ma)) <= {0.0, 1.0}
     img = S.load_isic_image(pairs[3][0], 32)             # 70 x 18 -> 32 x 32: shrink one axis, enlarge the other, AREA both
     assert img.shape == (32, 32, 3) and 0.0 <= img.min() and img.max() <= 1.0
+    # a consumer that abandons a pass (evaluate(steps=...) breaks out, an exception in the step) must not leave
+    # the producer thread blocked in put() for ever; the next pass still yields the full, correct stream
+    import threading
+    before = threading.active_count()
+    for _ in range(4):
+        it = iter(S.IsicDataset(pairs, 1, 32, augment=False, shuffle=False, seed=5, prefetch=1))
+        next(it)
+        it.close()                                       # what a `break` out of a for loop does to the generator
+    assert threading.active_count() <= before
+    again = S.IsicDataset(pairs, 2, 32, augment=True, shuffle=True, seed=5)
+    first = next(iter(again))                            # abandoned pass 0 ...
+    full = list(again)                                   # ... pass 1 is complete and equals the unthreaded stream's pass 1
+    ref_ds = S.IsicDataset(pairs, 2, 32, augment=True, shuffle=True, seed=5, cache=False, prefetch=0)
+    list(ref_ds)
+    want = list(ref_ds)
+    assert len(full) == 3 and all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(full, want))
