@@ -138,3 +138,79 @@ int oracle_conv_wgrad(const double* x, const double* dyv, double* dw, long n, lo
     free(xp);
     return 0;
 }
+
+/* ---------------------------------------------------------------------------------------------------------------------------
+ * LayerNormalization(axis=-1, epsilon) forward and backward over the last axis of a [npix, c] float64 matrix: the same sums as
+ * oracle/ops.py::layernorm_fwd / layernorm_bwd (Super_resolution/code/train_adaptive_unet.py:203,208; Keras: mean, then the
+ * mean of squared deviations, biased), one fused pass per pixel instead of a dozen whole-tensor NumPy temporaries (on a
+ * 268 MB batch the NumPy form took 11 s per layer for the forward and the three bracketed backward evaluations of an audit).
+ * ------------------------------------------------------------------------------------------------------------------------- */
+#include <math.h>
+void oracle_ln_fwd(const double* x, const double* gamma, const double* beta, double eps, double* y, double* xhat, double* rstd,
+                   long npix, long c) {
+#pragma omp parallel for schedule(static)
+    for (long p = 0; p < npix; ++p) {
+        const double* xr = x + (size_t)p * c;
+        double s = 0.0;
+        for (long i = 0; i < c; ++i) s += xr[i];
+        const double mu = s / (double)c;
+        double q = 0.0;
+        for (long i = 0; i < c; ++i) { const double d = xr[i] - mu; q += d * d; }
+        const double rs = 1.0 / sqrt(q / (double)c + eps);
+        rstd[p] = rs;
+        double* yr = y + (size_t)p * c;
+        double* hr = xhat + (size_t)p * c;
+        for (long i = 0; i < c; ++i) { const double h = (xr[i] - mu) * rs; hr[i] = h; yr[i] = h * gamma[i] + beta[i]; }
+    }
+}
+
+/* dx = rstd (g - mean(g) - xhat mean(g xhat)), g = dy gamma; dgamma = sum_p dy xhat; dbeta = sum_p dy (per-thread partial sums,
+ * added in thread order) */
+int oracle_ln_bwd(const double* dy, const double* gamma, const double* xhat, const double* rstd, double* dx, double* dgamma,
+                  double* dbeta, long npix, long c) {
+    const int nt = omp_get_max_threads();
+    double* part = (double*)calloc((size_t)nt * 2 * c, sizeof(double));
+    if (!part) return -1;
+#pragma omp parallel
+    {
+        double* pg = part + (size_t)omp_get_thread_num() * 2 * c;
+        double* pb = pg + c;
+#pragma omp for schedule(static)
+        for (long p = 0; p < npix; ++p) {
+            const double* dr = dy + (size_t)p * c;
+            const double* hr = xhat + (size_t)p * c;
+            double m1 = 0.0, m2 = 0.0;
+            for (long i = 0; i < c; ++i) {
+                const double g = dr[i] * gamma[i];
+                m1 += g; m2 += g * hr[i];
+                pg[i] += dr[i] * hr[i]; pb[i] += dr[i];
+            }
+            m1 /= (double)c; m2 /= (double)c;
+            const double rs = rstd[p];
+            double* xr = dx + (size_t)p * c;
+            for (long i = 0; i < c; ++i) xr[i] = rs * (dr[i] * gamma[i] - m1 - hr[i] * m2);
+        }
+    }
+    for (long i = 0; i < c; ++i) { dgamma[i] = 0.0; dbeta[i] = 0.0; }
+    for (int t = 0; t < nt; ++t)
+        for (long i = 0; i < c; ++i) { dgamma[i] += part[(size_t)t * 2 * c + i]; dbeta[i] += part[(size_t)t * 2 * c + c + i]; }
+    free(part);
+    return 0;
+}
+
+/* oracle/ops.py::bf16_round for float64 arrays: nearest bfloat16 (ties to even) of the value's float32 rounding, non-finite
+ * values passed through -- the same integer arithmetic, one parallel pass */
+#include <stdint.h>
+void oracle_bf16_round(const double* x, double* out, long n) {
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < n; ++i) {
+        const float f = (float)x[i];
+        if (!isfinite(f)) { out[i] = (double)f; continue; }
+        uint32_t u;
+        memcpy(&u, &f, 4);
+        const uint32_t r = (uint32_t)(((uint64_t)u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u);
+        float g;
+        memcpy(&g, &r, 4);
+        out[i] = (double)g;
+    }
+}

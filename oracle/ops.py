@@ -22,6 +22,11 @@ import numpy as np
 
 def bf16_round(x: np.ndarray) -> np.ndarray:
     """Round to the nearest bfloat16 (ties to even), returned in x's dtype."""
+    if isinstance(x, np.ndarray) and x.dtype == np.float64 and x.size >= (1 << 20) and _conv_c():
+        xc = np.ascontiguousarray(x)                      # large float64 tensors: the same arithmetic in one parallel C pass
+        out = np.empty_like(xc)
+        _conv_c().oracle_bf16_round(xc.ctypes.data, out.ctypes.data, xc.size)
+        return out
     f = np.ascontiguousarray(x, dtype=np.float32)
     u = f.view(np.uint32)
     r = ((u.astype(np.uint64) + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32)
@@ -62,6 +67,12 @@ def _conv_c():
             lib.oracle_conv_fwd.argtypes = [vp, vp, vp, vp, lg, lg, lg, lg, lg, lg, lg]
             lib.oracle_conv_wgrad.argtypes = [vp, vp, vp, lg, lg, lg, lg, lg, lg, lg]
             lib.oracle_conv_fwd.restype = lib.oracle_conv_wgrad.restype = ctypes.c_int
+            lib.oracle_ln_fwd.argtypes = [vp, vp, vp, ctypes.c_double, vp, vp, vp, lg, lg]
+            lib.oracle_ln_fwd.restype = None
+            lib.oracle_ln_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, lg, lg]
+            lib.oracle_ln_bwd.restype = ctypes.c_int
+            lib.oracle_bf16_round.argtypes = [vp, vp, lg]
+            lib.oracle_bf16_round.restype = None
             _CONV_C = lib
     return _CONV_C
 
@@ -138,7 +149,22 @@ def conv2d_same_bwd(x: np.ndarray, w: np.ndarray, dy: np.ndarray, need_dx: bool 
 LN_EPS = 1e-3
 
 
+def _ln_use_c(x, *vecs) -> bool:
+    # float64 tensors of a million elements or more (the whole-batch tensors of the layer-wise audits): one fused C pass per
+    # pixel (oracle/csrc/conv_ref.c) instead of a dozen whole-tensor temporaries; everything else runs the NumPy lines below
+    return (isinstance(x, np.ndarray) and x.dtype == np.float64 and x.size >= (1 << 20) and x.ndim >= 2
+            and all(np.asarray(v).shape == (x.shape[-1],) for v in vecs) and bool(_conv_c()))
+
+
 def layernorm_fwd(x, gamma, beta, eps: float = LN_EPS):
+    if _ln_use_c(x, gamma, beta):
+        xc = np.ascontiguousarray(x)
+        g, b = np.ascontiguousarray(gamma, dtype=np.float64), np.ascontiguousarray(beta, dtype=np.float64)
+        y, xhat = np.empty_like(xc), np.empty_like(xc)
+        rstd = np.empty(xc.shape[:-1] + (1,), dtype=np.float64)
+        _conv_c().oracle_ln_fwd(_ptr(xc), _ptr(g), _ptr(b), float(eps), _ptr(y), _ptr(xhat), _ptr(rstd), xc.size // xc.shape[-1],
+                                xc.shape[-1])
+        return y, (xhat, rstd)
     mu = x.mean(axis=-1, keepdims=True)
     var = ((x - mu) ** 2).mean(axis=-1, keepdims=True)
     rstd = 1.0 / np.sqrt(var + eps)
@@ -148,6 +174,15 @@ def layernorm_fwd(x, gamma, beta, eps: float = LN_EPS):
 
 def layernorm_bwd(dy, gamma, cache):
     xhat, rstd = cache
+    if (_ln_use_c(dy, gamma) and isinstance(xhat, np.ndarray) and xhat.dtype == np.float64 and xhat.shape == dy.shape
+            and isinstance(rstd, np.ndarray) and rstd.dtype == np.float64 and rstd.size == dy.size // dy.shape[-1]):
+        dyc, hc, rc = np.ascontiguousarray(dy), np.ascontiguousarray(xhat), np.ascontiguousarray(rstd)
+        g = np.ascontiguousarray(gamma, dtype=np.float64)
+        c = dyc.shape[-1]
+        dx, dgamma, dbeta = np.empty_like(dyc), np.empty(c), np.empty(c)
+        rc_ = _conv_c().oracle_ln_bwd(_ptr(dyc), _ptr(g), _ptr(hc), _ptr(rc), _ptr(dx), _ptr(dgamma), _ptr(dbeta), dyc.size // c, c)
+        assert rc_ == 0, "oracle_ln_bwd: out of memory"
+        return dx, dgamma, dbeta
     red = tuple(range(dy.ndim - 1))
     dgamma = (dy * xhat).sum(axis=red)
     dbeta = dy.sum(axis=red)

@@ -32,7 +32,12 @@ KINK = 1e-5
 
 
 def f64(t):
-    return t.detach().float().cpu().numpy().astype(np.float64)
+    # (converted on the device: the host would spend a second per 268 MB tensor in astype)
+    return t.detach().to(torch.float64).cpu().numpy()
+
+
+def _tt(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
 
 
 def stored_tol(want, store):
@@ -44,11 +49,26 @@ def stored_tol(want, store):
     return store * np.abs(want) + 3e-5 * scale + (2.0 ** -25 if store < 2.0 ** -9 else 0.0), scale
 
 
+def _exceeds(got, want, store, ok_pixels=None):
+    """(number of elements beyond stored_tol, largest |got - want| / scale) -- the arithmetic of stored_tol on torch's
+    multi-threaded CPU kernels, a few passes over the tensor instead of NumPy's dozen single-threaded temporaries (a 268 MB
+    tensor took 4.5 s per comparison)."""
+    g, w = _tt(got), _tt(want)
+    scale = float(w.abs().max()) + 1e-30
+    err = (g - w).abs_()
+    floor = 3e-5 * scale + (2.0 ** -25 if (store and store < 2.0 ** -9) else 0.0)
+    tol = w.abs().mul_(store).add_(floor) if store else None
+    bad = err > (tol if store else floor)
+    if ok_pixels is not None:
+        ok = _tt(ok_pixels).unsqueeze(-1)
+        bad &= ok
+        err = err * ok
+    return int(bad.sum()), float(err.max()) / scale
+
+
 def check_stored(got_t, want, what, store):
-    got = f64(got_t)
-    tol, scale = stored_tol(want, store)
-    bad = np.abs(got - want) > tol
-    assert not bad.any(), (what, int(bad.sum()), float(np.abs(got - want).max() / scale))
+    nbad, worst = _exceeds(f64(got_t), want, store)
+    assert nbad == 0, (what, nbad, worst)
 
 
 def check_f32(got, want, what, tol=1e-4, slack=None):
@@ -56,6 +76,23 @@ def check_f32(got, want, what, tol=1e-4, slack=None):
     lim = tol * (np.abs(want).max() + 1e-30) + (0 if slack is None else slack)
     err = np.abs(got - want)
     assert (err <= lim).all(), (what, float((err / (np.abs(want).max() + 1e-30)).max()))
+
+
+def ln_bwd_bracket(z, mean, rstd, gam, bet, d_act):
+    """LayerNorm + ReLU backward of the oracle on the product's own stored z / mean / rstd, for the three ReLU thresholds
+    (0, +KINK, -KINK) that bracket a pre-activation on the kink, and the pixels WITHOUT such an element.  The element-wise
+    preparation (xhat, y, masks) runs on torch's CPU kernels; the backward itself is oracle.ops.layernorm_bwd."""
+    zs = _tt(f64(z))
+    shp = tuple(zs.shape[:-1]) + (1,)
+    mu = mean.detach().to(torch.float64).cpu().reshape(shp)
+    rs = rstd.detach().to(torch.float64).cpu().reshape(shp)
+    xhat = (zs - mu).mul_(rs)
+    y = xhat * _tt(np.asarray(gam, np.float64)) + _tt(np.asarray(bet, np.float64))
+    d = _tt(d_act)
+    xh_np, rs_np = xhat.numpy(), rs.numpy()
+    res = [ref.layernorm_bwd((d * (y > thr)).numpy(), gam, (xh_np, rs_np)) for thr in (0.0, KINK, -KINK)]
+    ok = ~((y.abs() <= KINK).any(dim=-1)).numpy()
+    return res, ok
 
 
 def audit_sr_step(model, lr, hr):
@@ -187,13 +224,8 @@ def audit_sr_step(model, lr, hr):
             check_f32(G["residual_rgb/bias"], db, "residual_rgb/bias grad", slack=slack)
             ln = model.convs[cname].ln
             gam, bet = W[ln + "/gamma"], W[ln + "/beta"]
-            zs = f64(z)
-            mu = mean.cpu().numpy().astype(np.float64).reshape(zs.shape[:-1] + (1,))
-            rs = rstd.cpu().numpy().astype(np.float64).reshape(zs.shape[:-1] + (1,))
-            xhat = (zs - mu) * rs
-            y = xhat * gam + bet
-            res = [ref.layernorm_bwd(dxh * (y > thr), gam, (xhat, rs)) for thr in (0.0, KINK, -KINK)]
-            ok = ~(np.abs(y) <= KINK).any(axis=-1) & ~edge.any(axis=-1)
+            res, ok = ln_bwd_bracket(z, mean, rstd, gam, bet, dxh)
+            ok = ok & ~edge.any(axis=-1)
             check_stored_masked(f64(dz), res[0][0], ok, cname + " dz (fused with the head)", bf16)
             for j, pname in ((1, ln + "/gamma"), (2, ln + "/beta")):
                 check_f32(G[pname], res[0][j], pname + " grad", slack=np.abs(res[1][j] - res[2][j]) + slack)
@@ -202,14 +234,7 @@ def audit_sr_step(model, lr, hr):
             ln = model.convs[name].ln
             if d_in is not None:              # (None: this layer's dz came out of the fused head kernel, checked above)
                 gam, bet = W[ln + "/gamma"], W[ln + "/beta"]
-                zs = f64(z)
-                mu = mean.cpu().numpy().astype(np.float64).reshape(zs.shape[:-1] + (1,))
-                rs = rstd.cpu().numpy().astype(np.float64).reshape(zs.shape[:-1] + (1,))
-                xhat = (zs - mu) * rs
-                y = xhat * gam + bet
-                din = f64(d_in)
-                res = [ref.layernorm_bwd(din * (y > thr), gam, (xhat, rs)) for thr in (0.0, KINK, -KINK)]
-                ok = ~(np.abs(y) <= KINK).any(axis=-1)             # pixels without an element on the ReLU kink
+                res, ok = ln_bwd_bracket(z, mean, rstd, gam, bet, f64(d_in))
                 check_stored_masked(f64(dz), res[0][0], ok, name + " dz", bf16)
                 for j, pname in ((1, ln + "/gamma"), (2, ln + "/beta")):
                     check_f32(G[pname], res[0][j], pname + " grad", slack=np.abs(res[1][j] - res[2][j]))
@@ -236,13 +261,7 @@ def audit_sr_step(model, lr, hr):
             da, _, _ = ref.conv2d_same_bwd(np.zeros(z.shape), q(W[name + "/kernel"]), f64(dz_up))
             ln = model.convs[cname].ln
             gam, bet = W[ln + "/gamma"], W[ln + "/beta"]
-            zs = f64(z)
-            mu = mean.cpu().numpy().astype(np.float64).reshape(zs.shape[:-1] + (1,))
-            rs = rstd.cpu().numpy().astype(np.float64).reshape(zs.shape[:-1] + (1,))
-            xhat = (zs - mu) * rs
-            y = xhat * gam + bet
-            res = [ref.layernorm_bwd(da * (y > thr), gam, (xhat, rs)) for thr in (0.0, KINK, -KINK)]
-            ok = ~(np.abs(y) <= KINK).any(axis=-1)
+            res, ok = ln_bwd_bracket(z, mean, rstd, gam, bet, da)
             check_stored_masked(f64(dz), res[0][0], ok, cname + " dz (fused with the dgrad of " + name + ")", bf16)
             for j, pname in ((1, ln + "/gamma"), (2, ln + "/beta")):
                 check_f32(G[pname], res[0][j], pname + " grad", slack=np.abs(res[1][j] - res[2][j]))
@@ -262,13 +281,7 @@ def audit_sr_step(model, lr, hr):
             da = ref.resize_aa_bwd(f64(d_in), dskip.shape[1], dskip.shape[2]) + f64(dskip)
             ln = model.convs[cname].ln
             gam, bet = W[ln + "/gamma"], W[ln + "/beta"]
-            zs = f64(z)
-            mu = mean.cpu().numpy().astype(np.float64).reshape(zs.shape[:-1] + (1,))
-            rs = rstd.cpu().numpy().astype(np.float64).reshape(zs.shape[:-1] + (1,))
-            xhat = (zs - mu) * rs
-            y = xhat * gam + bet
-            res = [ref.layernorm_bwd(da * (y > thr), gam, (xhat, rs)) for thr in (0.0, KINK, -KINK)]
-            ok = ~(np.abs(y) <= KINK).any(axis=-1)
+            res, ok = ln_bwd_bracket(z, mean, rstd, gam, bet, da)
             check_stored_masked(f64(dz), res[0][0], ok, cname + " dz (fused with the skip junction)", bf16)
             for j, pname in ((1, ln + "/gamma"), (2, ln + "/beta")):
                 check_f32(G[pname], res[0][j], pname + " grad", slack=np.abs(res[1][j] - res[2][j]))
@@ -287,9 +300,8 @@ def audit_sr_step(model, lr, hr):
 
 
 def check_stored_masked(got, want, ok_pixels, what, store):
-    tol, scale = stored_tol(want, store)
-    bad = (np.abs(got - want) > tol) & ok_pixels[..., None]
-    assert not bad.any(), (what, int(bad.sum()), float((np.abs(got - want) * ok_pixels[..., None]).max() / scale))
+    nbad, worst = _exceeds(got, want, store, ok_pixels)
+    assert nbad == 0, (what, nbad, worst)
     # a pixel is left out when ANY of its C pre-activations lies within KINK of zero: the expected share grows with C
     # (observed 1.8 % at 1 024 channels, the 0.7 / depth 5 pyramid), so the allowance does too
     allowed = max(8, 0.01 * ok_pixels.size * max(1.0, want.shape[-1] / 256.0))

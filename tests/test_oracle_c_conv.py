@@ -25,3 +25,33 @@ def test_c_convolution_equals_the_numpy_definition(case, monkeypatch):
     dx0, dw0, db0 = ref.conv2d_same_bwd(x, wt, g)
     for got, want in ((y1, y0), (dx1, dx0), (dw1, dw0), (db1, db0)):
         assert np.abs(got - want).max() <= 1e-12 * np.abs(want).max()
+
+
+def test_c_layernorm_equals_the_numpy_definition(monkeypatch):
+    """oracle_ln_fwd / oracle_ln_bwd (fused per-pixel passes) against the NumPy lines of oracle/ops.py."""
+    if not ref._conv_c():
+        pytest.skip("oracle/_c/liboracle_conv.so is not built (make -C oracle)")
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((3, 17, 19, 96)) * 2 + 0.7
+    gamma, beta = rng.uniform(0.5, 1.5, 96), rng.standard_normal(96)
+    dy = rng.standard_normal(x.shape)
+    monkeypatch.setattr(ref, "_ln_use_c", lambda *a: True)
+    y1, (h1, r1) = ref.layernorm_fwd(x, gamma, beta)
+    dx1, dg1, db1 = ref.layernorm_bwd(dy, gamma, (h1, r1))
+    monkeypatch.setattr(ref, "_ln_use_c", lambda *a: False)
+    y0, (h0, r0) = ref.layernorm_fwd(x, gamma, beta)
+    dx0, dg0, db0 = ref.layernorm_bwd(dy, gamma, (h0, r0))
+    assert r1.shape == r0.shape
+    for got, want in ((y1, y0), (h1, h0), (r1, r0), (dx1, dx0), (dg1, dg0), (db1, db0)):
+        assert np.abs(got - want).max() <= 1e-12 * np.abs(want).max()
+
+
+def test_c_bf16_round_is_bitwise_the_numpy_definition(monkeypatch):
+    if not ref._conv_c():
+        pytest.skip("oracle/_c/liboracle_conv.so is not built (make -C oracle)")
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal(1 << 20) * np.exp(rng.uniform(-40, 40, 1 << 20))
+    x[:9] = [np.inf, -np.inf, np.nan, 0.0, -0.0, 1.00390625, 1.01171875, 3.3895313892515355e38, 1e-45]   # ties, overflow edge
+    got = ref.bf16_round(x)
+    monkeypatch.setattr(ref, "_conv_c", lambda: False)
+    assert np.array_equal(got, ref.bf16_round(x), equal_nan=True)
