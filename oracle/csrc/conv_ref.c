@@ -214,3 +214,10 @@ void oracle_bf16_round(const double* x, double* out, long n) {
         out[i] = (double)g;
     }
 }
+
+/* Threads of the parallel loops above.  The GPU boxes show 256 logical CPUs to a process whose CPU share is 16: one OpenMP thread
+ * per visible CPU then spends the share spinning at barriers (the audits got SLOWER with the C loops until this was capped). */
+void oracle_set_threads(int n) {
+    if (n < 1) n = 1;
+    omp_set_num_threads(n);
+}

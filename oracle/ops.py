@@ -51,6 +51,28 @@ def fp16_round(x: np.ndarray) -> np.ndarray:
 _CONV_C = None
 
 
+def cpu_share(cap: int = 16) -> int:
+    """Threads worth starting in this process: the cgroup's CPU quota where there is one (the GPU boxes show 256 logical CPUs to a
+    process whose share is 16), else the visible CPUs, never more than `cap` (ORACLE_THREADS overrides)."""
+    import os
+    if os.environ.get("ORACLE_THREADS"):
+        return max(1, int(os.environ["ORACLE_THREADS"]))
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except (OSError, ValueError):
+            pass
+    return max(1, min(n, cap))
+
+
 def _conv_c():
     """The C restatement of the same sums (oracle/csrc/conv_ref.c, built by oracle/Makefile / __graft_entry__.build()), used for
     float64 tensors large enough to matter: the layer-wise audits convolve whole BASELINE-size batches, and NumPy's strided tap
@@ -73,6 +95,9 @@ def _conv_c():
             lib.oracle_ln_bwd.restype = ctypes.c_int
             lib.oracle_bf16_round.argtypes = [vp, vp, lg]
             lib.oracle_bf16_round.restype = None
+            lib.oracle_set_threads.argtypes = [ctypes.c_int]
+            lib.oracle_set_threads.restype = None
+            lib.oracle_set_threads(cpu_share())
             _CONV_C = lib
     return _CONV_C
 

@@ -1,6 +1,9 @@
 import os
 import sys
 
+# OpenMP runtimes (torch's and the oracle's C loops) read this when they are loaded: idle threads sleep instead of spinning
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,6 +13,28 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box via gpurun)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _host_threads():
+    """The oracle's float64 work (NumPy / OpenBLAS, torch's CPU kernels in the audits' comparisons, the C loops) is sized to this
+    process's CPU share: the GPU boxes show 256 logical CPUs to a process that may use 16 of them, and one thread per visible
+    CPU costs more in contention than it computes."""
+    from oracle.ops import cpu_share
+    n = cpu_share()
+    limits = None
+    try:
+        import torch
+        torch.set_num_threads(n)
+    except Exception:
+        pass
+    try:
+        from threadpoolctl import threadpool_limits
+        limits = threadpool_limits(limits=n)          # held for the session
+    except Exception:
+        pass
+    yield n
+    del limits
 
 
 @pytest.fixture(scope="session")

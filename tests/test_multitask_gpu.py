@@ -122,3 +122,19 @@ def test_routed_steps_at_patch_256_in_float16_equal_the_stand_alone_models(devic
     seg.compile(optimizer=S.build_optimizer(proto, 100, 1), loss=proto.loss_builder())
     seg.train_on_batch(*seg_b)
     assert torch.equal(seg.P, bank.seg.P)
+
+
+def test_bank_under_two_rank_data_parallelism_equals_a_single_process(device):
+    """`AdaptiveDepthBank.data_parallel()` on real device tensors: two ranks share the GPU over gloo, every model of the bank has
+    its own bucketed exchange, a mixed SR / segmentation stream trained on half batches equals one process on the whole batches
+    (eager and per-model graph replay), ranks bitwise identical (tools/dp2_bank_gloo_gpu_check.py)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import free_port
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(root, "tools", "dp2_bank_gloo_gpu_check.py")]
+    res = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2500:] + res.stderr[-2500:]
+    assert "eager == graph bitwise: True" in res.stdout and res.stdout.count("max |P_dp - P_single|") == 6
