@@ -98,11 +98,18 @@ def cpu_baseline(scale, depth, patch, workload):
     from oracle.torch_standin import time_train_steps
     ips, steps, dt, threads = time_train_steps(scale, depth, patch, 4, 10.0)
     out = {"value": ips, "unit": "images/s", "cores": int(threads), "kind": "port",
+           "cores_note": "threads = this process's CPU share (cgroup quota), not the logical CPUs the box shows",
            "implementation": "PyTorch-CPU float32 stand-in for the TF/Keras CPU path (TF is not installable here)",
            "sample": f"{steps} train step(s) of batch 4 of {workload} after one warm-up step ({dt:.1f} s)"}
     for name, (sc, dp, pp) in (("K1", (0.5, 2, 128)), ("R3", (0.5, 3, 256))):
         v, st, d, _ = time_train_steps(sc, dp, pp, 4, 6.0)
         out[f"{name}_batch4_torch_cpu"] = {"value": v, "unit": "images/s", "sample": f"{st} train step(s), {d:.1f} s"}
+    from oracle.ops import cpu_share
+    try:                                   # OpenBLAS sized to the CPU share as well (it would start one thread per visible CPU)
+        from threadpoolctl import threadpool_limits
+        blas_limit = threadpool_limits(limits=cpu_share(cap=1 << 10))
+    except Exception:
+        blas_limit = None
     rng = np.random.default_rng(1234)
     m = SRUNetOracle(scale, depth, patch)
     params = m.init_params(rng, dtype=np.float32, head_uniform=0.05)
@@ -116,6 +123,7 @@ def cpu_baseline(scale, depth, patch, workload):
         n += 1
     d = time.time() - t0
     out["numpy_oracle"] = {"value": n / d, "unit": "images/s", "sample": f"{n} train step(s) of batch 1 of {workload}, float32, {d:.1f} s"}
+    del blas_limit
     return out
 
 

@@ -92,6 +92,10 @@ class TorchSRUNet:
 def time_train_steps(scale: float, depth: int, patch: int, batch: int, budget_seconds: float, seed: int = 1234):
     """Whole train steps of the stand-in on synthetic data (one untimed warm-up step, then steps until the budget is
     spent).  Returns (images_per_second, steps, seconds, threads)."""
+    from .ops import cpu_share
+    # one thread per CPU this process may actually use (its cgroup share: the GPU boxes show 256 logical CPUs to a process
+    # whose quota is 16; 128 threads on that share ran the baseline at a fraction of what 16 do)
+    torch.set_num_threads(cpu_share(cap=1 << 10))
     rng = np.random.default_rng(seed)
     net = TorchSRUNet(scale, depth, patch)
     net.set_params(net.oracle.init_params(rng, dtype=np.float32, head_uniform=0.05))
