@@ -577,6 +577,12 @@ def main():
                          "achieved": dom["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": dom["frac"],
                          # HBM bytes per launch (stamped PMC passes) and the operand bytes per launch, both over the SAME launches:
                          # every launch of `traffic_ops` in a step (tools/pmc_summary.py books the same kernels to the family)
+                         # which roof binds this family by the roofline model itself: arithmetic intensity (FLOPs per operand byte)
+                         # against the ridge peak_flops / peak_bytes = 312.5 FLOP/B.  `frac` above stays the MFMA fraction the
+                         # verdicts have tracked since r01; for a family below the ridge the binding ceiling is 8 TB/s x AI
+                         "binding_roof": {"flop_per_byte": dom["flop_per_byte"], "ridge_flop_per_byte": PEAK_BF16_TFLOPS * 1e12 / 8e12,
+                                          "bound": "hbm" if (dom["flop_per_byte"] or 1e9) < PEAK_BF16_TFLOPS * 1e12 / 8e12 else "mfma",
+                                          "hbm_tb_per_s": dom["hbm_tb_per_s"], "frac_of_8_tb_per_s": dom["hbm_frac"]},
                          "traffic": traffic, "traffic_ops": dom_ops,
                          "algorithmic_bytes_per_launch": dom_bytes / n_launch if n_launch else None,
                          "launches_per_step": n_launch * per_step, "avg_launch_ms": ms / n_launch if n_launch else None,
