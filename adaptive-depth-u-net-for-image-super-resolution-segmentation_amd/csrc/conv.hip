@@ -595,6 +595,11 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const float* __res
 }
 
 // K slices for a launch with few (tile, output block) items: aim at ~2 workgroups per CU, at least 2 chunks a slice
+// Shape queries may name any integers; the launch paths (and every kernel's 32-bit pixel index) need the whole batch's pixel
+// count below 2^31.  Queries answer "not supported / no workspace" beyond that instead of planning with overflowed ints
+// (found by the host-side sanitizer build, tests/test_host_sanitizers.py).
+static inline bool pixels_ok(int n, int h, int w) { return n > 0 && h > 0 && w > 0 && (long long)n * h * w < (1LL << 31); }
+
 static int pick_ksplit(int nitems, int nch) {
     if (nitems >= NUM_CU || nch < 4) return 1;
     int ks = (2 * NUM_CU + nitems - 1) / nitems;
@@ -2866,7 +2871,7 @@ extern "C" int ad_layernorm_relu_fwd(const void* z, const float* gamma, const fl
                                      float* rstd, int64_t npix, int c, float eps, int relu, int dtype, void* stream);
 
 extern "C" int ad_conv3x3_ln_relu_is_fused(int n, int h, int w, int c1, int c2, int cout, int dtype) {
-    if (!ad_is_half(dtype) || n <= 0 || h <= 0 || w <= 0 || c1 <= 0 || c2 < 0 || cout <= 0 || cout % BN) return 0;
+    if (!ad_is_half(dtype) || !pixels_ok(n, h, w) || c1 <= 0 || c2 < 0 || cout <= 0 || cout % BN) return 0;
     const int chunk = images_per_launch(n, h, w, c1, c2, cout, true, false);
     return fwd_ws_kind(chunk, h, w, c1, c2, cout, true) != 0;
 }
@@ -2904,19 +2909,20 @@ extern "C" int ad_conv3x3_ln_relu_fwd(const void* x1, int c1, const void* x2, in
 }
 
 extern "C" size_t ad_conv3x3_fwd_ws_bytes(int n, int h, int w, int cin, int cout, int dtype) {
-    if (n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0) return 0;
+    if (!pixels_ok(n, h, w) || cin <= 0 || cout <= 0 || !ad_dtype_ok(dtype)) return 0;
     cout = pad64(cout);
     Geo g;
     pick_geo(n, h, w, &g);
-    const int nitems = g.tiles_x * g.tiles_y * g.tiles_i * (cout / BN);
-    const int ks = pick_ksplit(nitems, cin / (ad_is_half(dtype) ? PolBF16::CK : PolF32::CK));
+    const long long nitems = (long long)g.tiles_x * g.tiles_y * g.tiles_i * (cout / BN);      // (64-bit: a query may name any shape)
+    if (nitems >= NUM_CU) return 0;                                                            // split-K only below one item per CU
+    const int ks = pick_ksplit((int)nitems, cin / (ad_is_half(dtype) ? PolBF16::CK : PolF32::CK));
     return ks > 1 ? (size_t)ks * n * h * w * cout * sizeof(float) : 0;
 }
 
 // ---- dgrad with the producer's ReLU-grad fused (decoder: dgrad of conv_block's first conv -> gradient of the up-conv's
 // ReLU output, train_adaptive_unet.py:259-262)
 extern "C" int ad_conv3x3_dgrad_relu_is_fused(int n, int h, int w, int c1, int cout, int cy1, int dtype) {
-    if (!ad_is_half(dtype) || n <= 0 || h <= 0 || w <= 0 || c1 <= 0 || cout <= 0 || cout % BN || cy1 <= 0 || cy1 % BN) return 0;
+    if (!ad_is_half(dtype) || !pixels_ok(n, h, w) || c1 <= 0 || cout <= 0 || cout % BN || cy1 <= 0 || cy1 % BN) return 0;
     if (images_per_launch(n, h, w, c1, 0, cout, false, false) < n) return 0;        // image runs: plain path
     return fwd_ws_kind(n, h, w, c1, 0, cout, false) == 1;      // weights-resident kernel (contraction over 64 channels)
 }
@@ -2955,7 +2961,7 @@ extern "C" int ad_conv3x3_dgrad_relu(const void* dz, int c1, const void* w_dgrad
 // train_adaptive_unet.py:200-210: its input is the first LayerNorm's activation)
 extern "C" int ad_conv3x3_dgrad_ln_bwd_is_fused(int n, int h, int w, int c1, int cout, int dtype) {
     const bool off = ad_option(AD_OPT_NO_DGRAD_LN) != 0;                  // A/B switch (ad_set_option)
-    if (off || !ad_is_half(dtype) || n <= 0 || h <= 0 || w <= 0 || c1 <= 0 || cout != BN) return 0;
+    if (off || !ad_is_half(dtype) || !pixels_ok(n, h, w) || c1 <= 0 || cout != BN) return 0;
     if (images_per_launch(n, h, w, c1, 0, cout, false, false) < n) return 0;        // image runs: plain path
     return fwd_ws_kind(n, h, w, c1, 0, cout, false) == 1;      // weights-resident kernel (contraction over 64 channels)
 }
@@ -3052,7 +3058,10 @@ extern "C" int ad_conv3x3_c3_wgrad(const float* x, const void* dz, float* dw_hwi
 
 extern "C" size_t ad_conv3x3_wgrad_ws_bytes(int n, int h, int w, int cin, int cout, int dtype) {
     WgradPlan p;
-    if (n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0) return 0;
+    // the same argument rules as ad_conv3x3_wgrad (cin a multiple of the channel granule): the plan below divides by the number
+    // of input-channel blocks (r04: a query with cin = 3 was a division by zero -- found by the host-side sanitizer build,
+    // tests/test_host_sanitizers.py)
+    if (!pixels_ok(n, h, w) || cin <= 0 || cout <= 0 || !ad_dtype_ok(dtype) || cin % ad_cin_granule(dtype)) return 0;
     plan_wgrad(n, h, w, cin, 0, cout, dtype, &p);     // the split of cin does not change the slab size
     size_t need = p.ws_bytes;
     const int chunk = ad_is_half(dtype) ? images_per_launch(n, h, w, cin, 0, cout, false, true) : n;

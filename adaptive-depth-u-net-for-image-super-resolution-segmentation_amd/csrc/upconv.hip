@@ -896,7 +896,9 @@ extern "C" int ad_pw_wgrad_supported(int64_t m, int cin, int cout, int dtype) {
 }
 
 extern "C" size_t ad_pw_wgrad_ws_bytes(int64_t m, int cin, int cout) {
-    if (m <= 0 || cin <= 0 || cout <= 0 || cin % PWG_KT || cout % 64) return 0;
+    // (pixel counts beyond what ad_pw_wgrad_supported accepts -- every operand below 2 GiB -- would overflow the 32-bit plan)
+    if (m <= 0 || cin <= 0 || cout <= 0 || cin % PWG_KT || cout % 64 || m * (cin > 9LL * cout ? cin : 9LL * cout) * 2 > PW_MAX_BYTES)
+        return 0;
     int mps, nsplit;
     pw_wgrad_plan(m, cin, 9 * cout, &mps, &nsplit);
     return (size_t)nsplit * cin * 9 * cout * sizeof(float);
