@@ -191,6 +191,31 @@ def test_bench_starts_two_gloo_ranks_on_one_gpu(device):
     assert bad.returncode != 0 and not [l for l in bad.stdout.splitlines() if l.startswith("{")]
 
 
+def test_bench_config5_stream_alone_and_under_two_gloo_ranks(device):
+    """`bench.py --workload K5` (BASELINE config 5, build-defined): one JSON line with the mixed stream's items; and the same under
+    two ranks sharing the GPU over gloo -- every model of the bank with its own DataParallel (`AdaptiveDepthBank.data_parallel`)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for extra, ranks in ((["--batch", "8"], 1), (["--batch", "4", "--gpus", "2", "--backend", "gloo"], 2)):
+        run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "K5", "--steps", "2", "--warmup", "1"] + extra,
+                             capture_output=True, text=True, timeout=900, env=env, cwd=root)
+        assert run.returncode == 0, run.stderr[-3000:]
+        lines = run.stdout.strip().splitlines()
+        assert len(lines) == 1, run.stdout[-2000:]
+        rec = json.loads(lines[0])
+        items = rec["config"]["items"]
+        assert rec["dtype"] == "f16" and rec["n_gpus"] == ranks and "BUILD-DEFINED" in rec["config"]["workload"]
+        assert [(i["task"], i["scale"], i["depth"]) for i in items] == [("sr", 0.3, 2), ("sr", 0.5, 3), ("sr", 0.6, 4), ("sr", 0.7, 5),
+                                                                        ("seg", None, 4)]
+        assert rec["value"] > 0 and all(np.isfinite(i["final_loss"]) and i["images_per_s"] > 0 for i in items)
+        assert rec["config"]["global_batch"] == sum(i["batch"] for i in items) * ranks
+        if ranks == 2:
+            assert rec["ranks"] == 2 and rec["dist_backend"] == "gloo"
+
+
 def test_bench_feed_loader_reports_the_fed_rate(device):
     """`bench.py --feed loader`: the resident-batch figure stays `value`; beside it the same graph-replayed
     step fed by the host data path (crop workers -> shared-memory ring -> uint8 over PCIe -> LR synthesis in HBM), with the H2D
