@@ -63,3 +63,38 @@ for chunk in (64, 32, 16, 8, 4):
     f = timeit(lambda: [fwd_pair(x[s]) for s in sl])
     bt = timeit(lambda: [bwd_trio(dz2[s], z1[s], px(m1, s), px(r1, s), x[s], z0[s], px(m0, s), px(r0, s)) for s in sl])
     print(f"{chunk:>18}{f:>18.3f}{bt:>18.3f}")
+
+# ---- a chain of FOUR conv + LayerNorm + ReLU layers (K2' forward: dec0a -> dec0b -> head_a -> head_b), replayed from a hipGraph so
+# that launch gaps do not blur the comparison
+print()
+print(f"{'images per chunk':>18}{'4-layer forward chain, graph replay, ms':>44}")
+packs = [ops.conv3x3_pack((rnd(3, 3, c, c) * 0.05).to(dev), c, torch.bfloat16)[0] for _ in range(4)]
+
+
+def chain(xs):
+    a = xs
+    keep = []
+    for wf in packs:
+        z, a, m, r = ops.conv3x3_ln_relu_fwd(a, None, wf, b, gam, bet, c)
+        keep.append((z, m, r))
+    return a, keep
+
+
+for chunk in (64, 32, 16):
+    sl = [slice(i, i + chunk) for i in range(0, n, chunk)]
+    run = lambda: [chain(x[s]) for s in sl]
+    run(); torch.cuda.synchronize()
+    gph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gph):
+        outs = run()
+    for _ in range(5):
+        gph.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        gph.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"{chunk:>18}{e0.elapsed_time(e1) / 20:>44.3f}")
+    del gph, outs
