@@ -441,6 +441,7 @@ class FastFeedDataset:
                                           patches_per_image=patches_per_image)
         self.patch_size, self.scale, self.device = patch_size, scale, device
         self._degrade = None
+        self.pinned = False
 
     def __iter__(self):
         """The uint8 crops of batch i + 1 cross PCIe on a copy stream while the GPU trains on batch i: the ring's shared memory is
@@ -453,12 +454,12 @@ class FastFeedDataset:
             self.device = dev
         dev = self.device
         ring = self.loader._ring
-        self.pinned = False
-        try:            # page-lock the ring once: asynchronous host -> device copies need it (hipHostRegister)
-            rc = torch.cuda.cudart().cudaHostRegister(ring.ctypes.data, ring.nbytes, 0)
-            self.pinned = (int(rc) == 0) if rc is not None else True
-        except Exception:
-            self.pinned = False
+        if not getattr(self, "pinned", False):       # page-lock the ring ONCE per object (a second pass over the dataset reuses it):
+            try:                                     # asynchronous host -> device copies need it (hipHostRegister)
+                rc = torch.cuda.cudart().cudaHostRegister(ring.ctypes.data, ring.nbytes, 0)
+                self.pinned = (int(rc) == 0) if rc is not None else True
+            except Exception:
+                self.pinned = False
         copy_stream = torch.cuda.Stream(device=dev)
         shape = (self.loader.batch_size, self.patch_size, self.patch_size, 3)
         stage = [torch.empty(shape, dtype=torch.uint8, device=dev) for _ in range(2)]

@@ -156,6 +156,9 @@ def test_bench_plain_and_under_torchrun_agree(device):
         # r04: traffic and operand bytes of the named family are quoted over the same launches; the executed-FLOP step fraction
         # sits below the reference-graph one (factored up-convs); the r03 rocm-smi power model is gone from the line
         assert rf["traffic_ops"] and "power_model" not in rf and rf["frac_step_executed"] < rf["frac_step"]
+        # the roof that binds the named family by the roofline model itself (arithmetic intensity against the 312.5 FLOP/B ridge)
+        br = rf["binding_roof"]
+        assert br["bound"] == ("hbm" if br["flop_per_byte"] < br["ridge_flop_per_byte"] else "mfma") and 0.2 < br["frac_of_8_tb_per_s"] < 1.0
         # secondary figure: fractions against the peak at the in-kernel clock (profiles/r*_inkernel_clock.json), when committed
         if rf["inkernel_clock_source"]:
             for name in ("fused_ln_fwd", "wgrad", "dgrad_ln_bwd_fused"):

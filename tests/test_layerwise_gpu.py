@@ -343,6 +343,10 @@ CONFIGS = [
     ("E2s06-b2", 0.6, 4, 256, 2, (F32,)),
     ("E2s07-b2", 0.7, 5, 256, 2, (BF16, F16)),   # 256/180/126/89/63/45, 2048-channel bottleneck (138 M parameters)
     ("E2s07-b1", 0.7, 5, 256, 1, (F32,)),        # (fp32 runs the generic kernels at any batch: one image halves the oracle's work)
+    # scale 0.8 / depth 5 (the last row of the Experiment-2 table): 256/205/164/132/106/85.  Its 132 -> 164 up-conv at 256 channels
+    # stages 2 x 32 256 bytes per workgroup in the forward gather: the eight-slot variant BEYOND the 64 KB default dynamic-LDS limit
+    # (until r04 only the 12-slot instantiations had the limit raised, so this row's training would have aborted)
+    ("E2s08-b1", 0.8, 5, 256, 1, (BF16,)),
 ]
 BIG_LAUNCH_CONFIGS = {"K2p-b8", "E2s06-b8", "K2-b2"}              # batch 8: >= 1 work item per CU at full resolution
 CASES = [(c, dt_) for c in CONFIGS for dt_ in c[5]]
