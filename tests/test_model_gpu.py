@@ -226,8 +226,13 @@ FULL_SIZE = [
 ]
 
 
-@pytest.mark.parametrize("case", FULL_SIZE, ids=[c[0] for c in FULL_SIZE])
-def test_full_size_properties(device, case):
+# bf16 (the bench policy) for every workload; float16 + dynamic loss scaling (the reference's policy, train_adaptive_unet.py:471-477)
+# for the headline workload and the Experiment-2 row the reference ran in it
+FULL_SIZE_CASES = [(c, torch.bfloat16) for c in FULL_SIZE] + [(c, torch.float16) for c in FULL_SIZE if c[0] in ("K2p", "E2s06")]
+
+
+@pytest.mark.parametrize("case,dtype", FULL_SIZE_CASES, ids=[f"{c[0]}-{str(d).split('.')[-1]}" for c, d in FULL_SIZE_CASES])
+def test_full_size_properties(device, case, dtype):
     """The benchmarked configurations at their full batch (far beyond what the oracle can convolve): the train step is
     deterministic (two models, same data -> bitwise equal weights), the hipGraph replay equals the eager step bit for
     bit, the loss is finite and falls over five steps on a fixed batch, and the K2'/batch-2 oracle-checked forward is
@@ -239,7 +244,7 @@ def test_full_size_properties(device, case):
     dlr, dhr = torch.from_numpy(lr).to(device), torch.from_numpy(hr).to(device)
     finals = []
     for mode in ("eager", "eager", "graph"):
-        model, _ = build_super_resolution_unet(scale, depth_override=depth, input_size=p, dtype=torch.bfloat16, device=device)
+        model, _ = build_super_resolution_unet(scale, depth_override=depth, input_size=p, dtype=dtype, device=device)
         loss, metrics = build_losses_and_metrics("charbonnier")
         model.compile(optimizer=Adam(1e-3), loss=loss, metrics=metrics)
         model._require_device()
