@@ -1051,6 +1051,14 @@ __device__ __forceinline__ void ws_mma_role_lnb(const ConvArgs& a, const char* x
         tx = o.slot0 - r0 * g.tiles_x; nn = r0 / g.tiles_y; ty = r0 - nn * g.tiles_y;
         sx = o.stride - rs0 * g.tiles_x; sn = rs0 / g.tiles_y; sy = rs0 - sn * g.tiles_y;
     }
+#ifdef AD_STAMP     // diagnostic build (tools/stamps_lnb.py): cycles of MFMA wave 0 by segment; slot 8 = total, 7 = wall (10 ns)
+    unsigned long long lst[7] = {0, 0, 0, 0, 0, 0, 0};
+    unsigned long long lt_last = clock64();
+    const unsigned long long lt_begin = lt_last, lwall_begin = wall_clock64();
+#define LSTAMP(slot) do { unsigned long long now_ = clock64(); lst[slot] += now_ - lt_last; lt_last = now_; } while (0)
+#else
+#define LSTAMP(slot) do {} while (0)
+#endif
     for (int k = 0; k < nloc; ++k) {
         const int x0 = tx << 4, y0 = ty << 4;
         pixbase = (nn * a.h + y0) * a.w + x0;
@@ -1065,10 +1073,24 @@ __device__ __forceinline__ void ws_mma_role_lnb(const ConvArgs& a, const char* x
         f32x4 c0[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) c0[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        LSTAMP(0);                                      // item set-up
         lds_barrier();                                  // even stage (chunk 0) ready
+        LSTAMP(1);                                      // barrier waits
         P::template mma_chunk_rows<true>(acc, xb0, abase0, HWB, wt0, lane, hook0, c0);
+        LSTAMP(2);                                      // MFMA phases
         lds_barrier();                                  // odd stage (chunk 1) ready
-        P::mma_chunk_rows(acc, xb1, abase0, HWB, wt1, lane, [](int) {});
+        LSTAMP(1);
+#ifndef AD_LNB_FETCH_ST
+#define AD_LNB_FETCH_ST 99
+#endif
+        auto hook1 = [&](int st) {
+            if (st != AD_LNB_FETCH_ST) return;
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(2);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        P::mma_chunk_rows(acc, xb1, abase0, HWB, wt1, lane, hook1);
+        LSTAMP(2);
         // ---- LayerNorm + ReLU backward of the 64 values per pixel this wave holds
         // bf16: the second half's operands are fetched here, behind the arithmetic of the first two m-tiles (471 us per
         // full-resolution launch; fetched after the first m-tile: 488 us).  fp16 needs more conversion temporaries and
@@ -1084,7 +1106,10 @@ __device__ __forceinline__ void ws_mma_role_lnb(const ConvArgs& a, const char* x
         }
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
-            if (!FETCH_EARLY && mt == 1) {
+#ifdef AD_LNB_SB
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            if (AD_LNB_FETCH_ST == 99 && !FETCH_EARLY && mt == 1) {
                 __builtin_amdgcn_sched_barrier(0);
                 fetch(2);
                 __builtin_amdgcn_sched_barrier(0);
@@ -1133,8 +1158,18 @@ __device__ __forceinline__ void ws_mma_role_lnb(const ConvArgs& a, const char* x
                 const u32x2 w1 = __builtin_amdgcn_permlane16_swap(pa.u[1], pb.u[1], false, false);
                 __builtin_amdgcn_raw_buffer_store_b128(u32x4{w0[0], w1[0], w0[1], w1[1]}, rsy, pvo_mt, np * 32 * TSZ, 0);
             }
+            LSTAMP(3 + mt);                             // epilogue of m-tile mt (mt == 1 includes issuing the second fetch)
         }
     }
+#ifdef AD_STAMP
+    if (wave == 0 && lane == 0 && a.dbg) {
+        for (int i = 0; i < 7; ++i) a.dbg[blockIdx.x * 10 + i] = lst[i];
+        a.dbg[blockIdx.x * 10 + 7] = wall_clock64() - lwall_begin;
+        a.dbg[blockIdx.x * 10 + 8] = clock64() - lt_begin;
+        a.dbg[blockIdx.x * 10 + 9] = nloc;
+    }
+#endif
+#undef LSTAMP
     // column sums: fold the 16 pixel lanes of each lane group; one row of 3 x 64 per MFMA wave goes to
     // dbias_part[workgroup][wave][dgamma | dbeta | dbias][64], lnb_reduce_kernel adds the rows in a fixed order
     float* row = a.dbias_part + ((size_t)blockIdx.x * 4 + wave) * (3 * BN);
