@@ -23,6 +23,7 @@ SIGNATURES = {
     "ad_last_error": (C.c_char_p, []),
     "ad_device_cus": (_i, []),
     "ad_set_option": (_i, [C.c_char_p, _i]),
+    "ad_conv3x3_mosaic": (_i, [_i, _i, _i, _i, _i, _i, _i, _i]),
     "ad_get_option": (_i, [C.c_char_p]),
     "ad_cin_granule": (_i, [_i]),
     "ad_pad_channels": (_i, [_vp, _vp, _i64, _i, _i, _i, _vp]),
@@ -131,7 +132,8 @@ def load():
         fn.restype = res
         fn.argtypes = args
     # A/B switches: the HOST reads the environment and sets the library's explicit options (ad_set_option)
-    for env, opt in (("ADUNET_NO_MAP1", b"no_map1"), ("ADUNET_NO_MAP4", b"no_map4"), ("ADUNET_NO_DGRAD_LN", b"no_dgrad_ln")):
+    for env, opt in (("ADUNET_NO_MAP1", b"no_map1"), ("ADUNET_NO_MAP4", b"no_map4"), ("ADUNET_NO_DGRAD_LN", b"no_dgrad_ln"),
+                     ("ADUNET_NO_MOSAIC", b"no_mosaic")):
         if os.environ.get(env):
             lib.ad_set_option(opt, 1)
     _lib = lib

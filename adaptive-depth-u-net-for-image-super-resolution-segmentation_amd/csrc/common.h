@@ -19,7 +19,7 @@ int ad_set_error(int code, const char* fmt, ...);
 // Compute units of the current device, queried once (api.hip): the persistent kernels launch one workgroup per CU.
 int ad_num_cu();
 // Explicit library options (ad_set_option, include/adunet.h): the library itself never reads the environment.
-enum { AD_OPT_NO_MAP1 = 0, AD_OPT_NO_MAP4 = 1, AD_OPT_NO_DGRAD_LN = 2, AD_OPT_COUNT = 3 };
+enum { AD_OPT_NO_MAP1 = 0, AD_OPT_NO_MAP4 = 1, AD_OPT_NO_DGRAD_LN = 2, AD_OPT_NO_MOSAIC = 3, AD_OPT_COUNT = 4 };
 int ad_option(int which);
 
 static inline bool ad_is_half(int dtype) { return dtype == AD_BF16 || dtype == AD_F16; }   // 16-bit storage types

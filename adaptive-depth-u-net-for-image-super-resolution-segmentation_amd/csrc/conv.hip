@@ -49,6 +49,16 @@ struct Geo {
     int HH, HW, NPH;    // halo rows, cols, pixels
     int NPHP;           // NPH rounded up to the staging granule of the kernel variant (slots/4)
     int tiles_x, tiles_y, tiles_i;
+    // Image mosaic (wave-specialised 16 x 16 kernels only; plan_mosaic): the tiles walk ONE virtual map in which the n images
+    // stand side by side, `mix` per mosaic row, with a single zero line between neighbours.  A map whose extent is not a
+    // multiple of 16 (the 154 / 93 / 56 / 34-wide levels of the scale-0.6 pyramid, run_experiment_adaptive_depth.sh:47-55)
+    // then wastes one line in 35 instead of 14 pixels in 48.  Only addresses change: a mosaic pixel maps to (image, y, x) or
+    // to "zero" (loads) / "dropped" (stores); every output pixel sees the same operands in the same order as without it.
+    int mos;            // 0: off
+    int mix;            // images per mosaic row
+    int mpw, mph;       // pitch of an image inside the mosaic: w + 1, h + 1
+    unsigned mdw, mdh;  // ceil(2^32 / pitch): v / pitch == umulhi(v, md) for v, pitch < 65 536
+    int mw, mh;         // mosaic extent in pixels
 };
 
 // max_nph: most halo pixels a tile may have (the fp32 wgrad kernel's dz tile leaves room for 576, not for the 1024 of
@@ -80,6 +90,36 @@ static bool pick_geo(int n, int h, int w, Geo* g, int max_nph = 1 << 30) {
     g->NPH = ti * g->HH * g->HW;
     g->NPHP = g->NPH;
     g->tiles_x = (w + tw - 1) / tw; g->tiles_y = (h + th - 1) / th; g->tiles_i = (n + ti - 1) / ti;
+    g->mos = 0; g->mix = 0; g->mpw = g->mph = 0; g->mdw = g->mdh = 0; g->mw = g->mh = 0;
+    return true;
+}
+
+// The mosaic of n images of h x w pixels that takes the fewest ROUNDS of `per_round` 16 x 16 tiles (the persistent kernels deal
+// `per_round` tiles to the chip at a time, so a launch lasts ceil(tiles / per_round) rounds; among equals: the fewest tiles).
+// false (g untouched) unless that is at least one round less than the per-image tiling needs (r04: on the scale-0.7 pyramid at
+// batch 8 every level keeps its 8 or 9 rounds whatever the mosaic saves in tiles), or when the extents leave the range of
+// the reciprocal division.
+static bool plan_mosaic(int n, int h, int w, int per_round, Geo* g) {
+    if (ad_option(AD_OPT_NO_MOSAIC) || n < 2 || h < 2 || w < 2 || h >= 32768 || w >= 32768 || per_round < 1) return false;
+    const long plain = (long)n * ((h + 15) / 16) * ((w + 15) / 16);
+    const long plain_rounds = (plain + per_round - 1) / per_round;
+    long best = plain, best_rounds = plain_rounds;
+    int best_ix = 0;
+    for (int ix = 1; ix <= n; ++ix) {
+        const int iy = (n + ix - 1) / ix;
+        const long mw = (long)ix * (w + 1) - 1, mh = (long)iy * (h + 1) - 1;
+        if (mw >= 65536 || mh >= 65536) continue;
+        const long cnt = ((mw + 15) / 16) * ((mh + 15) / 16);
+        const long rounds = (cnt + per_round - 1) / per_round;
+        if (rounds < best_rounds || (rounds == best_rounds && best_ix && cnt < best)) { best = cnt; best_rounds = rounds; best_ix = ix; }
+    }
+    if (!best_ix) return false;
+    const int iy = (n + best_ix - 1) / best_ix;
+    g->mos = 1; g->mix = best_ix; g->mpw = w + 1; g->mph = h + 1;
+    g->mdw = (unsigned)((0x100000000ULL + (unsigned)g->mpw - 1) / (unsigned)g->mpw);
+    g->mdh = (unsigned)((0x100000000ULL + (unsigned)g->mph - 1) / (unsigned)g->mph);
+    g->mw = best_ix * (w + 1) - 1; g->mh = iy * (h + 1) - 1;
+    g->tiles_x = (g->mw + 15) / 16; g->tiles_y = (g->mh + 15) / 16; g->tiles_i = 1;
     return true;
 }
 
@@ -645,6 +685,15 @@ __device__ __forceinline__ auto wave_uniform_rsrc(const void* p, int bytes) {
                                              __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
 }
 
+// Flat pixel index (image, y, x) of mosaic pixel (Y, X), or -1 on a separating line, outside the mosaic or past the last image
+__device__ __forceinline__ int mosaic_pix(const Geo& g, int n, int h, int w, int Y, int X) {
+    if ((unsigned)Y >= (unsigned)g.mh || (unsigned)X >= (unsigned)g.mw) return -1;
+    const int iy = (int)__umulhi((unsigned)Y, g.mdh), ix = (int)__umulhi((unsigned)X, g.mdw);
+    const int y = Y - iy * g.mph, x = X - ix * g.mpw;
+    const int img = iy * g.mix + ix;
+    return (y < h && x < w && img < n) ? (img * h + y) * w + x : -1;
+}
+
 // Sum of v over the four 16-lane groups of a wave, returned in every lane.  v_permlane16_swap(a, b) leaves rows
 // (a0,b0,a2,b2) / (a1,b1,a3,b3), v_permlane32_swap the lower / upper halves side by side, so with a = b = v two swaps
 // and two adds do the butterfly.  Written as inline asm with two distinct registers: extracting BOTH results of the
@@ -789,10 +838,11 @@ __device__ __forceinline__ void ws_pack_tile(const f32x4 (&acc)[4][4], const flo
 // the vector issue port for half of its cycles; 590 VALU instructions per item need the other half entirely), so the
 // launch costs MFMA + arithmetic + what the two store streams add either way: 304 us with the stores dropped
 // (-DAD_DROP_STORES), 234 us for the plain epilogue.
-template <typename P, int EPI>
+template <typename P, int EPI, bool MOS = false>
 __device__ __forceinline__ void ws_mma_role(const ConvArgs& a, const char* xb0, const char* xb1, const char* wt0,
                                             const char* wt1, const float* gb, int wave, int lane, const WsOrder& o,
                                             int nch) {
+    static_assert(!MOS || EPI <= 1, "the image mosaic exists for the bias / bias + ReLU epilogues");
     const int nb = o.nb, nloc = o.nloc;
     constexpr int TSZ = 2;
     constexpr int HWB = 18 * PIXB;
@@ -926,6 +976,14 @@ __device__ __forceinline__ void ws_mma_role(const ConvArgs& a, const char* xb0, 
         }
         ws_pack_tile<(EPI == 3 ? 0 : EPI), typename P::T>(acc, gb, a.ln_eps, wave, lane, a.h, a.w, nn_k, y0, x0, cy, soff, rsm, rsr,
                                                           pend, pvo);
+        if constexpr (MOS) {    // (y0, x0) are mosaic coordinates: the pieces go to the image pixel under them, or nowhere
+            const int csoff = (coff + (grp & 1) * 16 + (grp >> 1) * 8) * TSZ;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int px = mosaic_pix(g, a.n, a.h, a.w, y0 + wave * 4 + mt, x0 + (lane & 15));
+                pvo[mt] = px >= 0 ? (unsigned)(px * cy * TSZ + csoff) : WR_OOB;
+            }
+        }
         WSTAMP(3);                                      // pack (+ fused LayerNorm arithmetic)
         if (EPI == 3) {        // unconditional loads (zero records when this block is not masked): exact vmcnt bookkeeping
 #pragma unroll
@@ -1315,7 +1373,7 @@ __global__ __launch_bounds__(WR_T, 1) void conv3x3_fwd_wres_kernel(ConvArgs a) {
 // stage = one channel chunk, stages alternate between two [X][W] buffer pairs, one barrier per stage, loads issued
 // two stages ahead of their LDS store.  The pending output stores of an item drain during the first two stages of
 // the next one.  LDS: as above, 135.9 KB.
-template <typename P, int EPI>
+template <typename P, int EPI, bool MOS = false>
 __global__ __launch_bounds__(WR_T, 1) void conv3x3_fwd_ws_kernel(ConvArgs a) {
     typedef typename P::T T;
     static_assert(sizeof(T) == 2, "bf16 throughput path");
@@ -1368,7 +1426,8 @@ __global__ __launch_bounds__(WR_T, 1) void conv3x3_fwd_ws_kernel(ConvArgs a) {
     {                                                                                            \
         const int y_ = (Y0) - 1 + (hyx[I] >> 8), x_ = (X0) - 1 + (hyx[I] & 255);                 \
         const bool ok_ = (unsigned)y_ < (unsigned)a.h && (unsigned)x_ < (unsigned)a.w;           \
-        pix##I = ok_ ? ((NN) * a.h + y_) * a.w + x_ : -1;                                        \
+        if constexpr (MOS) pix##I = mosaic_pix(g, a.n, a.h, a.w, y_, x_);      /* (Y0, X0): mosaic coordinates, NN == 0 */ \
+        else pix##I = ok_ ? ((NN) * a.h + y_) * a.w + x_ : -1;                                   \
     }
         // stage cursor of the next issue: local item k (clamped to the last one), chunk ch
 #define WS_PIXELS(K)                                                                             \
@@ -1445,7 +1504,7 @@ __global__ __launch_bounds__(WR_T, 1) void conv3x3_fwd_ws_kernel(ConvArgs a) {
 #undef WS_STORE_A
 #undef WS_STORE_B
     } else {
-        ws_mma_role<P, EPI>(a, xb0, xb1, wt0, wt1, gb, wave, lane, o, nch);
+        ws_mma_role<P, EPI, MOS>(a, xb0, xb1, wt0, wt1, gb, wave, lane, o, nch);
     }
 }
 
@@ -1987,7 +2046,7 @@ __device__ __forceinline__ void w2_half(f32x4 (&acc)[9][4], const char* xh, cons
 
 // grid: x = K split, y = 64-input-channel block, z = 64-output-channel block
 // ws slab layout: [split][cib][cob][tap][64][64] fp32
-template <typename E>
+template <typename E, bool MOS = false>
 __global__ __launch_bounds__(W2_T, 1) void conv3x3_wgrad_ws_kernel(WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Geo& g = a.g;      // geometry is (1, 16, 16)
@@ -2036,16 +2095,18 @@ __global__ __launch_bounds__(W2_T, 1) void conv3x3_wgrad_ws_kernel(WgradArgs a) 
 #define W2_XLD(I, NN, YB, X0)                                                                              \
     ({                                                                                                     \
         const int y_ = (YB) + (xdesc[I] >> 8), x_ = (X0) - 1 + (xdesc[I] & 255);                           \
-        const bool ok_ = (unsigned)y_ < (unsigned)a.h && (unsigned)x_ < (unsigned)a.w;                     \
-        const int pix_ = ((NN) * a.h + y_) * a.w + x_;                                                     \
+        const int mp_ = MOS ? mosaic_pix(g, a.n, a.h, a.w, y_, x_) : 0;     /* (YB, X0): mosaic coordinates, NN == 0 */ \
+        const bool ok_ = MOS ? mp_ >= 0 : (unsigned)y_ < (unsigned)a.h && (unsigned)x_ < (unsigned)a.w;   \
+        const int pix_ = MOS ? mp_ : ((NN) * a.h + y_) * a.w + x_;                                         \
         (I) < 3 ? __builtin_amdgcn_raw_buffer_load_b128(rs0, ok_ ? (unsigned)(pix_ * rb0 + ob0 + xpart) : WR_OOB, 0, 0) \
                 : __builtin_amdgcn_raw_buffer_load_b128(rs1, ok_ ? (unsigned)(pix_ * rb1 + ob1 + xpart) : WR_OOB, 0, 0); \
     })
 #define W2_ZLD(I, NN, YB, X0)                                                                              \
     ({                                                                                                     \
         const int y_ = (YB) + drow0 + 2 * (I), x_ = (X0) + dcol;                                           \
-        const bool ok_ = y_ < a.h && x_ < a.w;                                                             \
-        const int pix_ = ((NN) * a.h + y_) * a.w + x_;                                                     \
+        const int mp_ = MOS ? mosaic_pix(g, a.n, a.h, a.w, y_, x_) : 0;                                    \
+        const bool ok_ = MOS ? mp_ >= 0 : y_ < a.h && x_ < a.w;                                            \
+        const int pix_ = MOS ? mp_ : ((NN) * a.h + y_) * a.w + x_;                                         \
         __builtin_amdgcn_raw_buffer_load_b128(rsz, ok_ ? (unsigned)(pix_ * rbz + cob * BN * TSZ + dpart) : WR_OOB, 0, 0); \
     })
 #define W2_TILE(TILE)                                                                                      \
@@ -2598,6 +2659,15 @@ static int images_per_launch(int n, int h, int w, int c1, int c2, int cout, bool
 template <typename P>
 int launch_fwd(ConvArgs a, void* ws, size_t ws_bytes, hipStream_t s);
 
+// streamed-weights kernel, bias / bias + ReLU epilogue: the image mosaic when it needs fewer tiles and still gives every
+// workgroup an item
+static bool fwd_mosaic(int n, int h, int w, int nblk, Geo* g) {
+    Geo mg = *g;
+    if (!plan_mosaic(n, h, w, NUM_CU / nblk, &mg) || (long long)mg.tiles_x * mg.tiles_y * nblk < NUM_CU) return false;
+    *g = mg;
+    return true;
+}
+
 // conv3x3_map1_kernel: 1x1 maps, four chunks per step group, the concat boundary on a chunk, the output split on 16-channel tiles
 static bool map1_ok(int n, int h, int w, int c1, int c2, int cout, int cy1) {
     if (ad_option(AD_OPT_NO_MAP1)) return false;                      // A/B switch (ad_set_option)
@@ -2718,6 +2788,24 @@ int launch_fwd(ConvArgs a, void* ws, size_t ws_bytes, hipStream_t s) {
         return AD_OK;                                                                                \
     }
         if (kind == 1) AD_WS_LAUNCH(conv3x3_fwd_wres_kernel, "conv3x3_fwd_wres")
+        if (kind == 2 && a.epilogue <= AD_EPI_RELU) {
+            // maps whose extent is not a multiple of 16: all images as one mosaic when that needs fewer tiles (Geo)
+            Geo mg = a.g;
+            if (fwd_mosaic(a.n, a.h, a.w, nblk, &mg)) {
+                static bool mos_attr = false;
+                if (!mos_attr) {
+                    allow_big_lds(conv3x3_fwd_ws_kernel<P, 0, true>);
+                    allow_big_lds(conv3x3_fwd_ws_kernel<P, 1, true>);
+                    mos_attr = true;
+                }
+                a.g = mg;
+                a.ntiles = mg.tiles_x * mg.tiles_y;
+                if (a.epilogue == AD_EPI_RELU) conv3x3_fwd_ws_kernel<P, 1, true><<<NUM_CU, WR_T, WR_LDS, s>>>(a);
+                else conv3x3_fwd_ws_kernel<P, 0, true><<<NUM_CU, WR_T, WR_LDS, s>>>(a);
+                AD_LAUNCH_CHECK("conv3x3_fwd_ws (mosaic)");
+                return AD_OK;
+            }
+        }
         if (kind == 2) AD_WS_LAUNCH(conv3x3_fwd_ws_kernel, "conv3x3_fwd_ws")
 #undef AD_WS_LAUNCH
     }
@@ -2764,6 +2852,14 @@ static void plan_wgrad(int n, int h, int w, int c1, int c2, int cout, int dtype,
     const long long widest = (long long)n * h * w * (c1 > c2 ? (c1 > cout ? c1 : cout) : (c2 > cout ? c2 : cout)) * 2;
     p->specialised = ad_is_half(dtype) && p->g.lti == 0 && p->g.lth == 4 && p->g.ltw == 4 && cin % 64 == 0 && cout % BN == 0 &&
                      c1 % 32 == 0 && widest <= WR_MAX_BYTES && p->ntiles >= 4 * NUM_CU / ((cin / 64) * p->ncob);
+    if (p->specialised) {      // the image mosaic where it needs fewer tiles and still fills the chip (Geo)
+        Geo mg = p->g;
+        const int wgs = NUM_CU / ((cin / 64) * p->ncob);          // workgroups that share the tiles of one channel-block pair
+        if (plan_mosaic(n, h, w, wgs < 1 ? 1 : wgs, &mg) && mg.tiles_x * mg.tiles_y >= 2 * wgs) {
+            p->g = mg;
+            p->ntiles = mg.tiles_x * mg.tiles_y;
+        }
+    }
     p->ck = p->specialised ? 64 : ad_is_half(dtype) ? PolBF16::CK : PolF32::CK;
     p->ncib = cin / p->ck;
     int want = ((p->specialised ? 1 : 2) * NUM_CU) / (p->ncib * p->ncob);   // workgroups per CU in total
@@ -2796,8 +2892,13 @@ int launch_wgrad(WgradArgs a, const WgradPlan& p, hipStream_t s) {
     if constexpr (sizeof(typename P::T) == 2) {
         if (p.specialised) {
             static bool attr2 = false;
-            if (!attr2) { allow_big_lds(conv3x3_wgrad_ws_kernel<typename P::T>); attr2 = true; }
-            conv3x3_wgrad_ws_kernel<typename P::T><<<grid, W2_T, W2_LDS, s>>>(a);
+            if (!attr2) {
+                allow_big_lds(conv3x3_wgrad_ws_kernel<typename P::T>);
+                allow_big_lds(conv3x3_wgrad_ws_kernel<typename P::T, true>);
+                attr2 = true;
+            }
+            if (g.mos) conv3x3_wgrad_ws_kernel<typename P::T, true><<<grid, W2_T, W2_LDS, s>>>(a);
+            else conv3x3_wgrad_ws_kernel<typename P::T><<<grid, W2_T, W2_LDS, s>>>(a);
             AD_LAUNCH_CHECK("conv3x3_wgrad_ws");
             return AD_OK;
         }
@@ -2941,6 +3042,20 @@ extern "C" int ad_conv3x3_ln_relu_fwd(const void* x1, int c1, const void* x2, in
     rc = launch_fwd_dtype(dtype, a, ws, ws_bytes, s);
     if (rc) return rc;
     return ad_layernorm_relu_fwd(z, gamma, beta, act, mean, rstd, (int64_t)n * h * w, cout, eps, 1, dtype, stream);
+}
+
+extern "C" int ad_conv3x3_mosaic(int n, int h, int w, int c1, int c2, int cout, int dtype, int wgrad) {
+    if (!ad_is_half(dtype) || !pixels_ok(n, h, w) || c1 <= 0 || c2 < 0 || cout <= 0) return 0;
+    if (wgrad) {
+        WgradPlan p;
+        plan_wgrad(n, h, w, c1, c2, cout, dtype, &p);
+        return p.specialised && p.g.mos ? p.g.mix : 0;
+    }
+    if (map4_ok(n, h, w, c1, c2, cout, cout) || map1_ok(n, h, w, c1, c2, cout, cout)) return 0;
+    if (images_per_launch(n, h, w, c1, c2, cout, false, false) < n || fwd_ws_kind(n, h, w, c1, c2, cout, false) != 2) return 0;
+    Geo g;
+    pick_geo(n, h, w, &g);
+    return fwd_mosaic(n, h, w, cout / BN, &g) ? g.mix : 0;
 }
 
 extern "C" size_t ad_conv3x3_fwd_ws_bytes(int n, int h, int w, int cin, int cout, int dtype) {

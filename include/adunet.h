@@ -57,6 +57,8 @@ int ad_device_cus(void);
  *   "no_map1"      1x1 feature maps take the generic kernel instead of conv3x3_map1_kernel
  *   "no_map4"      4x4 feature maps take the generic kernel instead of conv3x3_map4_kernel
  *   "no_dgrad_ln"  ad_conv3x3_dgrad_ln_bwd_is_fused() answers 0 (dgrad and LayerNorm backward as two launches)
+ *   "no_mosaic"    the wave-specialised conv kernels tile every image by itself even where the image mosaic
+ *                  (one virtual map of all images, a single zero line between neighbours) needs fewer 16 x 16 tiles
  * ad_get_option returns the value, -1 for an unknown name. */
 int ad_set_option(const char* name, int value);
 int ad_get_option(const char* name);
@@ -92,6 +94,12 @@ int ad_conv3x3_pack_job_blocks(int cin_pad, int cout);
 int ad_conv3x3_pack_batch(const void* jobs_dev, int njobs, int nblocks, int dtype, void* stream);
 
 /* ------------------------------------------------------------ convolution -- */
+
+/* Images per mosaic row when a bias / bias + ReLU forward or dgrad launch (wgrad = 0; outputs split on a 64-channel block)
+ * or a weight-gradient launch (wgrad = 1) of this shape walks the image mosaic -- all n images as one virtual map with a
+ * single zero line between neighbours, for maps whose extent is not a multiple of the 16 x 16 tile -- and 0 when it tiles
+ * image by image.  Only addresses differ: forward results are bitwise those of the per-image tiling (option "no_mosaic"). */
+int ad_conv3x3_mosaic(int n, int h, int w, int c1, int c2, int cout, int dtype, int wgrad);
 
 /* Conv2D 3x3, stride 1, padding "same" (+bias, +optional ReLU):
  *   L.Conv2D(nf, 3, padding="same")            train_adaptive_unet.py:202,207
