@@ -3045,7 +3045,7 @@ extern "C" int ad_conv3x3_ln_relu_fwd(const void* x1, int c1, const void* x2, in
 }
 
 extern "C" int ad_conv3x3_mosaic(int n, int h, int w, int c1, int c2, int cout, int dtype, int wgrad) {
-    if (!ad_is_half(dtype) || !pixels_ok(n, h, w) || c1 <= 0 || c2 < 0 || cout <= 0) return 0;
+    if (!ad_is_half(dtype) || !pixels_ok(n, h, w) || c1 <= 0 || c2 < 0 || cout <= 0 || (c1 + c2) % ad_cin_granule(dtype)) return 0;
     if (wgrad) {
         WgradPlan p;
         plan_wgrad(n, h, w, c1, c2, cout, dtype, &p);

@@ -34,6 +34,31 @@ def test_library_exports_every_declared_symbol():
     assert lib.ad_upconv_slab_cols(sx.ctypes.data, 32, 256, 64, _lib.AD_BF16) == -1
 
 
+def test_mosaic_planner_takes_the_mosaic_where_it_saves_a_round():
+    """Host arithmetic of the image mosaic (conv.hip plan_mosaic; without a device the library plans for 256 CUs, as MI355X):
+    the levels of Experiment 2's pyramids (run_experiment_adaptive_depth.sh:47-55: scale 0.6 at batch 32, 0.7 at batch 8)."""
+    from adunet_amd import _lib
+    lib = _lib.load()
+    bf = _lib.AD_BF16
+    # scale 0.6, batch 32: 34-wide (18 -> 11 rounds) and 56-wide (16 -> 14) levels; 93 keeps its 18 rounds
+    assert lib.ad_conv3x3_mosaic(32, 34, 34, 1024, 0, 1024, bf, 0) > 0 and lib.ad_conv3x3_mosaic(32, 34, 34, 1024, 0, 1024, bf, 1) > 0
+    assert lib.ad_conv3x3_mosaic(32, 56, 56, 512, 0, 512, bf, 0) > 0
+    assert lib.ad_conv3x3_mosaic(32, 93, 93, 256, 0, 256, bf, 0) == 0
+    # scale 0.7, batch 8: every level keeps its 8 or 9 rounds
+    for hw, c in ((179, 128), (125, 256), (88, 512), (61, 1024), (43, 2048)):
+        assert lib.ad_conv3x3_mosaic(8, hw, hw, c, 0, c, bf, 0) == 0, hw
+    # whole tiles, one image, float32 (generic kernels), the option
+    assert lib.ad_conv3x3_mosaic(64, 64, 64, 128, 0, 128, bf, 0) == 0 and lib.ad_conv3x3_mosaic(1, 34, 34, 1024, 0, 1024, bf, 0) == 0
+    assert lib.ad_conv3x3_mosaic(32, 34, 34, 1024, 0, 1024, _lib.AD_F32, 0) == 0
+    lib.ad_set_option(b"no_mosaic", 1)
+    try:
+        assert lib.ad_conv3x3_mosaic(32, 34, 34, 1024, 0, 1024, bf, 0) == 0
+    finally:
+        lib.ad_set_option(b"no_mosaic", 0)
+    # the row length the planner picks tiles the mosaic in the fewest rounds: 32 images of 34 x 34 -> 4 x 8 (9 x 18 tiles)
+    assert lib.ad_conv3x3_mosaic(32, 34, 34, 1024, 0, 1024, bf, 0) in (4, 8)
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     from adunet_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)

@@ -20,6 +20,7 @@ for _ in range(3000):
     lib.ad_conv3x3_fwd_ws_bytes(nn,h,w,cin,cout,dt); lib.ad_conv3x3_wgrad_ws_bytes(nn,h,w,cin,cout,dt)
     lib.ad_conv3x3_ln_relu_is_fused(nn,h,w,cin,0,cout,dt); lib.ad_conv3x3_dgrad_relu_is_fused(nn,h,w,cin,cout,cout//2,dt)
     lib.ad_conv3x3_dgrad_ln_bwd_is_fused(nn,h,w,cin,cout,dt); lib.ad_conv3x3_c3_supported(nn,h,w,cout,dt)
+    lib.ad_conv3x3_mosaic(nn,h,w,cin,0,cout,dt,0); lib.ad_conv3x3_mosaic(nn,h,w,cin//2,cin//2,cout,dt,1)
     lib.ad_pw_supported(nn*h*w,cin,9*cout,dt); lib.ad_pw_gemm_variant(nn*h*w,cin,9*cout,dt); lib.ad_pw_wgrad_supported(nn*h*w,cin,cout,dt); lib.ad_pw_wgrad_ws_bytes(nn*h*w,cin,cout)
     lib.ad_resample_ln_bwd_ws_bytes(nn,h,w,cout,dt) if hasattr(lib,'ad_resample_ln_bwd_ws_bytes') else None
     lib.ad_layernorm_bwd_ws_bytes(nn*h*w,cout); lib.ad_head_ws_bytes(nn,cout); lib.ad_head_ln_bwd_ws_bytes(nn,cout); lib.ad_conv3x3_pack_elems(cin,cout,max(cin,16)); lib.ad_metrics_ws_bytes(nn,h,w)
@@ -31,6 +32,7 @@ for _ in range(4000):
     lib.ad_conv3x3_ln_relu_is_fused(nn,h,w,cin,0,cout,dt); lib.ad_conv3x3_dgrad_relu_is_fused(nn,h,w,cin,cout,max(cout//2,16),dt)
     lib.ad_conv3x3_dgrad_ln_bwd_is_fused(nn,h,w,cin,cout,dt); lib.ad_conv3x3_c3_supported(nn,h,w,cout,dt)
     m = nn*h*w
+    lib.ad_conv3x3_mosaic(nn,h,w,cin,0,cout,dt,0); lib.ad_conv3x3_mosaic(nn,h,w,cin,0,cout,dt,1)
     lib.ad_pw_supported(m,cin,9*cout,dt); lib.ad_pw_gemm_variant(m,cin,9*cout,dt); lib.ad_pw_wgrad_supported(m,cin,cout,dt); lib.ad_pw_wgrad_ws_bytes(m,cin,cout)
     lib.ad_resample_ln_bwd_ws_bytes(nn,h,w,cout,dt); lib.ad_resample_ln_bwd_supported(nn,h,w,cout,rnd.choice([1,2,8,40]),dt)
     lib.ad_layernorm_bwd_ws_bytes(m,cout); lib.ad_head_ws_bytes(nn,cout); lib.ad_head_ln_bwd_ws_bytes(nn,cout); lib.ad_metrics_ws_bytes(nn,h,w)
