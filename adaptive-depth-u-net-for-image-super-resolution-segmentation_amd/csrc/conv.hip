@@ -334,6 +334,7 @@ __device__ __forceinline__ uint4 load_w_slot(const char* wp, int kc_total, int c
 #define AD_EPI_LN_RELU 2        // internal: ad_conv3x3_ln_relu_fwd
 #define AD_EPI_MASK 3           // internal: ad_conv3x3_dgrad_relu (ReLU-grad of the producer fused into this dgrad)
 #define AD_EPI_LNBWD 4          // internal: ad_conv3x3_dgrad_ln_bwd (LayerNorm + ReLU backward of the producer fused into this dgrad)
+#define AD_EPI_LN_STATS 5        // internal: ad_conv3x3_ln_relu_fwd without an activation tensor: z and the LayerNorm statistics only
 #define AD_ERR_UNFUSED 1000     // internal: no fused kernel for this shape, run the two launches
 
 struct ConvArgs {
@@ -756,7 +757,7 @@ __device__ __forceinline__ void ws_pack_tile(const f32x4 (&acc)[4][4], const flo
         // EPI 2 arithmetic is written on float pairs: v_pk_add / v_pk_mul / v_pk_fma_f32 do two channels per instruction,
         // and this VALU work sits between the MFMA phases of two items (it is not hidden behind anything)
         float mean = 0.f, rstd = 0.f;
-        if (EPI == 2) {
+        if (EPI == 2 || EPI == 5) {
             // Two passes, as LayerNormalization itself (mean, then the mean of squared DEVIATIONS) and ln_fwd_kernel: until r03 this
             // was E[x^2] - mean^2 in one pass, whose cancellation costs (mean / std)^2 * 2^-24 of the variance -- 10 % at
             // mean / std = 1 000 (test_fused_layernorm_epilogue_with_a_large_mean_offset; found through ADVICE r03).  Price: eight
@@ -850,8 +851,9 @@ __device__ __forceinline__ void ws_mma_role(const ConvArgs& a, const char* xb0, 
     const int nblk = a.cout / BN;
     const int npix = a.n * a.h * a.w;
     const int grp = lane >> 4;
+    constexpr bool LN = EPI == 2 || EPI == 5;      // 5: z and the LayerNorm statistics, no activation (ad_conv3x3_ln_relu_fwd, act == NULL)
     float4 bv[4];
-    if (EPI != 2) {
+    if (!LN) {
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             bv[nt] = a.bias ? *reinterpret_cast<const float4*>(a.bias + nb * BN + nt * 16 + grp * 4)
@@ -865,8 +867,8 @@ __device__ __forceinline__ void ws_mma_role(const ConvArgs& a, const char* xb0, 
     else { yp = a.y2; cy = a.cout_real - a.cy1; coff = nb * BN - a.cy1; }
     const auto rsy = wave_uniform_rsrc(yp, npix * cy * TSZ);
     const auto rsa = wave_uniform_rsrc(EPI == 2 ? a.a_out : yp, npix * cy * TSZ);
-    const auto rsm = wave_uniform_rsrc(EPI == 2 ? (const void*)a.ln_mean : (const void*)yp, npix * 4);
-    const auto rsr = wave_uniform_rsrc(EPI == 2 ? (const void*)a.ln_rstd : (const void*)yp, npix * 4);
+    const auto rsm = wave_uniform_rsrc(LN ? (const void*)a.ln_mean : (const void*)yp, npix * 4);
+    const auto rsr = wave_uniform_rsrc(LN ? (const void*)a.ln_rstd : (const void*)yp, npix * 4);
     const int abase0 = ((wave * 4 + 1) * 18 + (lane & 15) + 1) * PIXB + P::a_lane_off(lane);
     int soff[4];
 #pragma unroll
@@ -952,7 +954,7 @@ __device__ __forceinline__ void ws_mma_role(const ConvArgs& a, const char* xb0, 
         f32x4 c0[4];                                    // bias: the accumulators start from it in the first tap step
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float4 b4 = EPI == 2 ? *reinterpret_cast<const float4*>(gb + 128 + j * 16 + grp * 4) : bv[j];
+            const float4 b4 = LN ? *reinterpret_cast<const float4*>(gb + 128 + j * 16 + grp * 4) : bv[j];
             c0[j] = f32x4{b4.x, b4.y, b4.z, b4.w};
         }
         WSTAMP(0);                                      // item set-up
@@ -1276,7 +1278,7 @@ __global__ __launch_bounds__(WR_T, 1) void conv3x3_fwd_wres_kernel(ConvArgs a) {
     }
 
     float* gb = reinterpret_cast<float*>(wt + 2 * WT_BYTES);
-    if (EPI == 2 || EPI == 4) {       // [gamma][beta][bias] of the 64 output channels; visible to the MFMA waves after this barrier
+    if (EPI == 2 || EPI == 4 || EPI == 5) {       // [gamma][beta][bias] of the 64 output channels; visible to the MFMA waves after this barrier
         if (tid < 64) {
             gb[tid] = a.ln_gamma[tid]; gb[64 + tid] = a.ln_beta[tid]; gb[128 + tid] = a.bias ? a.bias[tid] : 0.f;
         }
@@ -2691,7 +2693,7 @@ template <typename P>
 int launch_fwd_runs(ConvArgs a, void* ws, size_t ws_bytes, hipStream_t s) {
     int chunk = a.n;
     if constexpr (sizeof(typename P::T) == 2)
-        chunk = images_per_launch(a.n, a.h, a.w, a.c1, a.c2, a.cout_real, a.epilogue == AD_EPI_LN_RELU, false);
+        chunk = images_per_launch(a.n, a.h, a.w, a.c1, a.c2, a.cout_real, a.epilogue == AD_EPI_LN_RELU || a.epilogue == AD_EPI_LN_STATS, false);
     if (chunk >= a.n) return launch_fwd<P>(a, ws, ws_bytes, s);
     constexpr size_t TSZ = sizeof(typename P::T);
     for (int i0 = 0; i0 < a.n; i0 += chunk) {
@@ -2702,7 +2704,8 @@ int launch_fwd_runs(ConvArgs a, void* ws, size_t ws_bytes, hipStream_t s) {
         if (a.x2) b.x2 = a.x2 + pix0 * a.c2 * TSZ;
         b.y1 = a.y1 + pix0 * a.cy1 * TSZ;
         if (a.y2) b.y2 = a.y2 + pix0 * (a.cout_real - a.cy1) * TSZ;
-        if (a.a_out) { b.a_out = a.a_out + pix0 * a.cout_real * TSZ; b.ln_mean = a.ln_mean + pix0; b.ln_rstd = a.ln_rstd + pix0; }
+        if (a.a_out) b.a_out = a.a_out + pix0 * a.cout_real * TSZ;
+        if (a.ln_mean) { b.ln_mean = a.ln_mean + pix0; b.ln_rstd = a.ln_rstd + pix0; }
         pick_geo(b.n, b.h, b.w, &b.g);
         b.ntiles = b.g.tiles_x * b.g.tiles_y * b.g.tiles_i;
         const int rc = launch_fwd<P>(b, ws, ws_bytes, s);
@@ -2736,6 +2739,7 @@ int launch_fwd(ConvArgs a, void* ws, size_t ws_bytes, hipStream_t s) {
             allow_big_lds(conv3x3_fwd_ws_kernel<P, 2>);
             allow_big_lds(conv3x3_fwd_wres_kernel<P, 3>);
             allow_big_lds(conv3x3_fwd_wres_kernel<P, 4>);
+            allow_big_lds(conv3x3_fwd_wres_kernel<P, 5>);
         }
         attr_set = true;
     }
@@ -2763,7 +2767,7 @@ int launch_fwd(ConvArgs a, void* ws, size_t ws_bytes, hipStream_t s) {
             AD_LAUNCH_CHECK("conv3x3_map1");
             return AD_OK;
         }
-        int kind = fwd_ws_kind(a.n, a.h, a.w, a.c1, a.c2, a.cout_real, a.epilogue == AD_EPI_LN_RELU);
+        int kind = fwd_ws_kind(a.n, a.h, a.w, a.c1, a.c2, a.cout_real, a.epilogue == AD_EPI_LN_RELU || a.epilogue == AD_EPI_LN_STATS);
         if (a.cy1 % BN && a.cy1 != a.cout_real) kind = 0;          // a split inside a 64-channel block: generic kernel
         // the ReLU-grad mask epilogue exists for the weights-resident kernel only (the streamed-weights variant would
         // spill: 256 registers + scratch); ad_conv3x3_dgrad_relu_is_fused says so to the caller
@@ -2777,6 +2781,12 @@ int launch_fwd(ConvArgs a, void* ws, size_t ws_bytes, hipStream_t s) {
             if (kind != 1 || a.cout_real != BN) return AD_ERR_UNFUSED;
             conv3x3_fwd_wres_kernel<P, 4><<<NUM_CU, WR_T, WR_LDS, s>>>(a);
             AD_LAUNCH_CHECK("conv3x3_fwd_wres (layernorm-bwd)");
+            return AD_OK;
+        }
+        if (a.epilogue == AD_EPI_LN_STATS) {
+            if (kind != 1 || a.cout_real != BN) return AD_ERR_UNFUSED;
+            conv3x3_fwd_wres_kernel<P, 5><<<NUM_CU, WR_T, WR_LDS, s>>>(a);
+            AD_LAUNCH_CHECK("conv3x3_fwd_wres (layernorm statistics)");
             return AD_OK;
         }
 #define AD_WS_LAUNCH(KERN, NAME)                                                                     \
@@ -2809,7 +2819,8 @@ int launch_fwd(ConvArgs a, void* ws, size_t ws_bytes, hipStream_t s) {
         if (kind == 2) AD_WS_LAUNCH(conv3x3_fwd_ws_kernel, "conv3x3_fwd_ws")
 #undef AD_WS_LAUNCH
     }
-    if (a.epilogue == AD_EPI_LN_RELU || a.epilogue == AD_EPI_MASK || a.epilogue == AD_EPI_LNBWD) return AD_ERR_UNFUSED;     // the caller runs two launches
+    if (a.epilogue == AD_EPI_LN_RELU || a.epilogue == AD_EPI_MASK || a.epilogue == AD_EPI_LNBWD || a.epilogue == AD_EPI_LN_STATS)
+        return AD_ERR_UNFUSED;     // the caller runs two launches
     size_t lds = 2 * (size_t)g.NPHP * 4 + 2 * BN * 4 + (((size_t)g.NPH * PIXB + 15) & ~15) + (size_t)FWS * FT * 16;
     if (lds > 160 * 1024) return ad_set_error(AD_ERR_ARG, "conv3x3_fwd: LDS %zu too large", lds);
     const int per_cu = lds <= 80 * 1024 ? 2 : 1;
@@ -3012,12 +3023,23 @@ extern "C" int ad_conv3x3_ln_relu_is_fused(int n, int h, int w, int c1, int c2, 
     return fwd_ws_kind(chunk, h, w, c1, c2, cout, true) != 0;
 }
 
+// act == NULL in ad_conv3x3_ln_relu_fwd: the weights-resident kernel (Cin = 64 -> Cout = 64) on every image run
+extern "C" int ad_conv3x3_ln_stats_is_fused(int n, int h, int w, int c1, int c2, int cout, int dtype) {
+    if (!ad_is_half(dtype) || !pixels_ok(n, h, w) || c1 <= 0 || c2 < 0 || cout != BN) return 0;
+    const int chunk = images_per_launch(n, h, w, c1, c2, cout, true, false);
+    const int last = n - (n - 1) / chunk * chunk;
+    return fwd_ws_kind(chunk, h, w, c1, c2, cout, true) == 1 && fwd_ws_kind(last, h, w, c1, c2, cout, true) == 1;
+}
+
 extern "C" int ad_conv3x3_ln_relu_fwd(const void* x1, int c1, const void* x2, int c2, const void* w_packed,
                                       const float* bias, const float* gamma, const float* beta, float eps, void* z,
                                       void* act, float* mean, float* rstd, int n, int h, int w, int cout, void* ws,
                                       size_t ws_bytes, int dtype, void* stream) {
     AD_REQUIRE(ad_dtype_ok(dtype), "ad_conv3x3_ln_relu_fwd: bad dtype %d", dtype);
-    AD_REQUIRE(gamma && beta && z && act && mean && rstd, "ad_conv3x3_ln_relu_fwd: NULL LayerNorm operand");
+    AD_REQUIRE(gamma && beta && z && mean && rstd, "ad_conv3x3_ln_relu_fwd: NULL LayerNorm operand");
+    AD_REQUIRE(act || ad_conv3x3_ln_stats_is_fused(n, h, w, c1, c2, cout, dtype),
+               "ad_conv3x3_ln_relu_fwd: act == NULL (statistics only) has no kernel for n=%d %dx%d c1=%d c2=%d cout=%d dtype=%d "
+               "(ask ad_conv3x3_ln_stats_is_fused first)", n, h, w, c1, c2, cout, dtype);
     const int gran = ad_cin_granule(dtype);
     AD_REQUIRE(n > 0 && h > 0 && w > 0 && (long)n * h * w < (1L << 31), "ad_conv3x3_ln_relu_fwd: bad shape n=%d h=%d w=%d", n, h, w);
     AD_REQUIRE(x1 && c1 > 0 && c1 % gran == 0 && (x2 == nullptr) == (c2 == 0) && c2 % gran == 0,
@@ -3027,7 +3049,7 @@ extern "C" int ad_conv3x3_ln_relu_fwd(const void* x1, int c1, const void* x2, in
     a.x1 = (const char*)x1; a.x2 = (const char*)x2; a.c1 = c1; a.c2 = c2;
     a.wp = (const char*)w_packed; a.bias = bias;
     a.y1 = (char*)z; a.y2 = nullptr; a.cy1 = cout;
-    a.n = n; a.h = h; a.w = w; a.cout = pad64(cout); a.cout_real = cout; a.epilogue = AD_EPI_LN_RELU;
+    a.n = n; a.h = h; a.w = w; a.cout = pad64(cout); a.cout_real = cout; a.epilogue = act ? AD_EPI_LN_RELU : AD_EPI_LN_STATS;
     a.dbg = g_dbg;
     a.ksplit = 1; a.slab = nullptr;
     a.ln_gamma = gamma; a.ln_beta = beta; a.ln_eps = eps;
@@ -3038,6 +3060,7 @@ extern "C" int ad_conv3x3_ln_relu_fwd(const void* x1, int c1, const void* x2, in
     hipStream_t s = (hipStream_t)stream;
     int rc = launch_fwd_dtype(dtype, a, ws, ws_bytes, s);
     if (rc != AD_ERR_UNFUSED) return rc;
+    AD_REQUIRE(act, "ad_conv3x3_ln_relu_fwd: act == NULL needs the fused kernel");
     a.epilogue = AD_EPI_NONE;
     rc = launch_fwd_dtype(dtype, a, ws, ws_bytes, s);
     if (rc) return rc;

@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ xh,
 #ifndef AD_HEAD_LN_U
 #define AD_HEAD_LN_U 1
 #endif
-template <typename T, int G>
+template <typename T, int G, bool REDERIVE>        // REDERIVE: xh == NULL, the head's input is re-derived from z
 __global__ __launch_bounds__(256) void head_ln_bwd_kernel(const T* __restrict__ xh, const float* __restrict__ w,
                                                           const float* __restrict__ b, const float* __restrict__ inp,
                                                           const float* __restrict__ target, const T* __restrict__ z,
@@ -280,7 +280,10 @@ __global__ __launch_bounds__(256) void head_ln_bwd_kernel(const T* __restrict__ 
     const float inv_c = 1.0f / (float)ch;
     // U pixels per thread and pass with every load issued before the first use: at one pixel the kernel's 166 registers
     // allow three waves per SIMD = 6 MB in flight on the chip, which bounds it at ~3.9 TB/s (latency x bandwidth)
-    constexpr int U = AD_HEAD_LN_U;
+#ifndef AD_HEAD_LN_UR
+#define AD_HEAD_LN_UR AD_HEAD_LN_U
+#endif
+    constexpr int U = REDERIVE ? AD_HEAD_LN_UR : AD_HEAD_LN_U;
     const int64_t qstep = (int64_t)gridDim.x * PPB;
     for (int64_t q0 = (int64_t)blockIdx.x * PPB + gp; q0 < ppi; q0 += U * qstep) {
         Vec16<T> lxs[U], lzs[U];
@@ -289,7 +292,7 @@ __global__ __launch_bounds__(256) void head_ln_bwd_kernel(const T* __restrict__ 
         for (int u = 0; u < U; ++u) {
             const int64_t qq = q0 + u * qstep < ppi ? q0 + u * qstep : q0;        // past the end: re-read, never stored
             const int64_t pix = (int64_t)img * ppi + qq;
-            lxs[u].load(xh + pix * ch + gl * EPT);
+            if constexpr (!REDERIVE) lxs[u].load(xh + pix * ch + gl * EPT);
             lzs[u].load(z + pix * ch + gl * EPT);
             mus[u] = mean[pix]; rss[u] = rstd[pix];
 #pragma unroll
@@ -301,9 +304,23 @@ __global__ __launch_bounds__(256) void head_ln_bwd_kernel(const T* __restrict__ 
         if (q >= ppi) break;
         const int64_t pix = (int64_t)img * ppi + q;
         const float mu = mus[u], rs = rss[u];
-        float x[EPT], zz[EPT];
-        lxs[u].to_f32(x);
+        float x[EPT], zz[EPT], h[EPT];
+        unsigned pos = 0;                    // REDERIVE: bit e = the LayerNorm output of channel e is positive (the ReLU mask)
         lzs[u].to_f32(zz);
+        if constexpr (REDERIVE) {            // the head's input as a stored activation tensor would hold it
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) {
+                h[e] = (zz[e] - mu) * rs;
+                const float yv = h[e] * gam[e] + bet[e];
+                pos |= yv > 0.f ? 1u << e : 0u;
+                x[e] = yv > 0.f ? yv : 0.f;
+            }
+            Vec16<T> ra;
+            ra.from_f32(x);
+            ra.to_f32(x);
+        } else {
+            lxs[u].to_f32(x);
+        }
         float r[3] = {0.f, 0.f, 0.f};
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
@@ -325,16 +342,21 @@ __global__ __launch_bounds__(256) void head_ln_bwd_kernel(const T* __restrict__ 
                 a_q += d * d;
             }
         }
-        float h[EPT], gg[EPT];
+        float gg[EPT];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
             const float da = g[0] * wl[e][0] + g[1] * wl[e][1] + g[2] * wl[e][2];       // gradient of the head activation
 #pragma unroll
             for (int o = 0; o < 3; ++o) aw[e][o] += x[e] * g[o];
-            h[e] = (zz[e] - mu) * rs;
-            const float yv = h[e] * gam[e] + bet[e];
-            const float dl = yv > 0.f ? da : 0.f;                                        // ReLU
+            bool on;
+            if constexpr (REDERIVE) {
+                on = (pos >> e) & 1u;
+            } else {
+                h[e] = (zz[e] - mu) * rs;
+                on = h[e] * gam[e] + bet[e] > 0.f;
+            }
+            const float dl = on ? da : 0.f;                                              // ReLU
             a_g[e] += dl * h[e];
             a_b[e] += dl;
             gg[e] = dl * gam[e];
@@ -534,10 +556,17 @@ extern "C" int ad_head_ln_bwd(const void* xh, const float* w, const float* b, co
     if (lds > 64 * 1024) return ad_set_error(AD_ERR_ARG, "ad_head_ln_bwd: ch=%d needs %zu B of LDS", ch, lds);
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(bpi, n);
-    AD_DISPATCH_DTYPE(dtype, T_,
-        HEAD_DISPATCH(head_ln_bwd_kernel<T_, G_><<<grid, 256, lds, s>>>((const T_*)xh, w, b, inp, target, (const T_*)z, mean, rstd,
-                                                                        gamma, beta, (T_*)dz, (float*)ws, pix_per_img, ch,
-                                                                        loss_kind, eps, grad_scale, loss_scale, stats ? 1 : 0);))
+    if (xh) {
+        AD_DISPATCH_DTYPE(dtype, T_,
+            HEAD_DISPATCH(head_ln_bwd_kernel<T_, G_, false><<<grid, 256, lds, s>>>((const T_*)xh, w, b, inp, target, (const T_*)z, mean,
+                                                                                   rstd, gamma, beta, (T_*)dz, (float*)ws, pix_per_img, ch,
+                                                                                   loss_kind, eps, grad_scale, loss_scale, stats ? 1 : 0);))
+    } else {
+        AD_DISPATCH_DTYPE(dtype, T_,
+            HEAD_DISPATCH(head_ln_bwd_kernel<T_, G_, true><<<grid, 256, lds, s>>>((const T_*)nullptr, w, b, inp, target, (const T_*)z, mean,
+                                                                                  rstd, gamma, beta, (T_*)dz, (float*)ws, pix_per_img, ch,
+                                                                                  loss_kind, eps, grad_scale, loss_scale, stats ? 1 : 0);))
+    }
     AD_LAUNCH_CHECK("ad_head_ln_bwd");
     HeadLnOuts o;
     o.ptr[0] = dw; o.end[0] = ch * 3;

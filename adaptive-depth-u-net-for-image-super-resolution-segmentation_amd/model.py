@@ -511,8 +511,18 @@ class Model:
         """The layer feeding the head is Conv2D -> LayerNorm -> ReLU (:265) recorded on the tape: its LayerNorm / ReLU
         backward runs inside the head's backward pass (ad_head_ln_bwd), which also reports the loss and the metric."""
         nxt = tape[-1] if tape else None
+        if xh is None:        # the forward pass did not store the head's input: only the fused backward can re-derive it
+            assert nxt is not None and nxt[0] == "cla"
+            return True
         return (nxt is not None and nxt[0] == "cla" and nxt[4].shape == xh.shape
                 and os.environ.get("ADUNET_NO_HEAD_LN_FUSION") != "1")
+
+    def _head_input_stays_in_registers(self, need_out: bool, keep: bool, target) -> bool:
+        """Train steps whose head runs as ad_head_ln_bwd alone (no forward launch over the head, _forward): that kernel can
+        re-derive the head's input from the last layer's z, so the layer need not write its activation (0.5 GB at K2')."""
+        return (not need_out and keep and target is not None and self.audit is None
+                and os.environ.get("ADUNET_NO_HEAD_LN_FUSION") != "1" and os.environ.get("ADUNET_HEAD_FWD_IN_TRAIN") != "1"
+                and os.environ.get("ADUNET_KEEP_HEAD_ACT") != "1")
 
     def _forward(self, x: torch.Tensor, target: Optional[torch.Tensor], keep: bool, need_out: bool = True):
         """need_out=False (train steps: only loss and metric leave the step, :622-632): where the head's backward kernel can
@@ -526,10 +536,14 @@ class Model:
         c3 = first.cin == 3 and first.ln is not None and ops.conv3x3_c3_supported(x, first.cout, self.dtype)
         cur1, cur2 = (x if c3 else ops.pad_channels(x, ops.cin_granule(self.dtype), self.dtype)), None
         skips: List[torch.Tensor] = []
-        for step in self._plan:
+        no_head_act = self._head_input_stays_in_registers(need_out, keep, target)
+        for si, step in enumerate(self._plan):
             kind = step[0]
             if kind == "block":
                 for cs in step[1]:
+                    feeds_head = (no_head_act and cs is step[1][-1] and si + 1 < len(self._plan) and self._plan[si + 1][0] == "head"
+                                  and not (c3 and cs is first) and cs.cout == self.head
+                                  and ops.conv3x3_ln_stats_is_fused(cur1, cur2, cs.cout))
                     if c3 and cs is first:
                         z, a, mean, rstd = ops.conv3x3_c3_ln_relu_fwd(cur1, self.param(cs.name + "/kernel"),
                                                                       self.param(cs.name + "/bias"),
@@ -538,7 +552,7 @@ class Model:
                     else:
                         z, a, mean, rstd = ops.conv3x3_ln_relu_fwd(cur1, cur2, self._packs[cs.name][0],
                                                                    self.param(cs.name + "/bias"), self.param(cs.ln + "/gamma"),
-                                                                   self.param(cs.ln + "/beta"), cs.cout)
+                                                                   self.param(cs.ln + "/beta"), cs.cout, want_act=not feeds_head)
                     if keep:
                         tape.append(("cla", cs, cur1, cur2, z, mean, rstd, step[2]))
                     if self.audit is not None:
@@ -585,8 +599,8 @@ class Model:
             elif kind == "head":
                 w = self.param("residual_rgb/kernel").view(self.head, 3)
                 b = self.param("residual_rgb/bias")
-                if (not need_out and keep and target is not None and self.audit is None and self._head_fuses_with_ln(tape, cur1)
-                        and os.environ.get("ADUNET_HEAD_FWD_IN_TRAIN") != "1"):
+                if cur1 is None or (not need_out and keep and target is not None and self.audit is None
+                                    and self._head_fuses_with_ln(tape, cur1) and os.environ.get("ADUNET_HEAD_FWD_IN_TRAIN") != "1"):
                     stats = torch.empty(3, dtype=torch.float32, device=x.device)
                     sqerr = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
                     tape.append(("head", cur1, stats, sqerr))

@@ -259,13 +259,33 @@ def conv3x3_dgrad_relu(dz: torch.Tensor, w_dgrad: torch.Tensor, relu_out: torch.
     return y1, y2
 
 
-def conv3x3_ln_relu_fwd(x1: torch.Tensor, x2: Optional[torch.Tensor], w_packed: torch.Tensor, bias: Optional[torch.Tensor],
-                        gamma: torch.Tensor, beta: torch.Tensor, cout: int, eps: float = LN_EPS):
-    """conv_block's Conv2D -> LayerNormalization -> ReLU.  Returns (z, act, mean, rstd): z is the conv output kept for
-    the backward pass.  One launch where the library has the fused epilogue (cout == 64, large bf16 launches), else
-    the library runs the convolution and the LayerNorm kernel back to back."""
+def conv3x3_ln_stats_is_fused(x1: torch.Tensor, x2: Optional[torch.Tensor], cout: int) -> bool:
+    """True when conv3x3_ln_relu_fwd(..., want_act=False) has a kernel for these operands."""
     n, h, w, c1 = x1.shape
     c2 = x2.shape[-1] if x2 is not None else 0
+    return bool(_lib.load().ad_conv3x3_ln_stats_is_fused(n, h, w, c1, c2, cout, dt(x1.dtype)))
+
+
+def conv3x3_ln_relu_fwd(x1: torch.Tensor, x2: Optional[torch.Tensor], w_packed: torch.Tensor, bias: Optional[torch.Tensor],
+                        gamma: torch.Tensor, beta: torch.Tensor, cout: int, eps: float = LN_EPS, want_act: bool = True):
+    """conv_block's Conv2D -> LayerNormalization -> ReLU.  Returns (z, act, mean, rstd): z is the conv output kept for
+    the backward pass.  One launch where the library has the fused epilogue (cout == 64, large bf16 launches), else
+    the library runs the convolution and the LayerNorm kernel back to back.
+    want_act=False (conv3x3_ln_stats_is_fused must hold): the activation is not written, act is None -- for the layer in
+    front of the head in a train step, whose only consumer (head_ln_bwd) re-derives it from z."""
+    n, h, w, c1 = x1.shape
+    c2 = x2.shape[-1] if x2 is not None else 0
+    if not want_act:
+        z = torch.empty((n, h, w, cout), dtype=x1.dtype, device=x1.device)
+        mean = torch.empty(n * h * w, dtype=torch.float32, device=x1.device)
+        rstd = torch.empty(n * h * w, dtype=torch.float32, device=x1.device)
+        lib = _lib.load()
+        with _timed("conv3x3_ln_relu_fwd", 2.0 * n * h * w * 9 * (c1 + c2) * cout,        # same family, one output stream less
+                    float(n * h * w * ((c1 + c2 + cout) * x1.element_size() + 8))):
+            check(lib.ad_conv3x3_ln_relu_fwd(_p(x1), c1, _p(x2), c2, _p(w_packed), _p(bias), _p(gamma), _p(beta), eps,
+                                             _p(z), None, _p(mean), _p(rstd), n, h, w, cout, None, 0, dt(x1.dtype), _stream()),
+                  "ad_conv3x3_ln_relu_fwd (statistics only)")
+        return z, None, mean, rstd
     # Shapes without the fused epilogue are issued as the two launches here rather than inside the library, so that
     # the per-op timers book the LayerNorm kernel under its own name (ADUNET_LN_TWO_LAUNCHES=1: A/B switch).
     if os.environ.get("ADUNET_LN_TWO_LAUNCHES") or not _lib.load().ad_conv3x3_ln_relu_is_fused(n, h, w, c1, c2, cout,
@@ -565,15 +585,16 @@ def head_ln_bwd(xh, w, b, inp, target, z, mean, rstd, gamma, beta, dw, db, dgamm
                 ws: Workspace, loss_kind: int = 0, eps: float = CHARBONNIER_EPS, loss_scale: Optional[torch.Tensor] = None,
                 stats: Optional[torch.Tensor] = None, sqerr: Optional[torch.Tensor] = None):
     """head_bwd + the LayerNorm/ReLU backward of the layer feeding the head, one pass; returns that layer's dz.
-    stats[3] / sqerr[n]: filled with what head_fwd reports (loss sum, mean PSNR, loss mean / per-image squared error)."""
-    n, h, wd, ch = xh.shape
+    stats[3] / sqerr[n]: filled with what head_fwd reports (loss sum, mean PSNR, loss mean / per-image squared error).
+    xh=None: the head's input is re-derived from z (the forward pass did not store it: conv3x3_ln_relu_fwd, want_act=False)."""
+    n, h, wd, ch = z.shape
     dz = torch.empty_like(z)
     lib = _lib.load()
     ws.ensure(lib.ad_head_ln_bwd_ws_bytes(n, ch))
-    with _timed("head_ln_bwd", 0.0, float(3 * xh.numel() * xh.element_size() + 2 * inp.numel() * 4)):
+    with _timed("head_ln_bwd", 0.0, float((3 if xh is not None else 2) * z.numel() * z.element_size() + 2 * inp.numel() * 4)):
         check(lib.ad_head_ln_bwd(_p(xh), _p(w), _p(b), _p(inp), _p(target), _p(z), _p(mean), _p(rstd), _p(gamma), _p(beta),
                                  _p(dz), _p(dw), _p(db), _p(dgamma), _p(dbeta), _p(dbias_conv), n, h * wd, ch, loss_kind, eps,
-                                 grad_scale, _p(loss_scale), _p(stats), _p(sqerr), ws.ptr, ws.nbytes, dt(xh.dtype), _stream()),
+                                 grad_scale, _p(loss_scale), _p(stats), _p(sqerr), ws.ptr, ws.nbytes, dt(z.dtype), _stream()),
               "ad_head_ln_bwd")
     return dz
 

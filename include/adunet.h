@@ -136,6 +136,9 @@ int ad_conv3x3_wgrad(const void* x1, int c1, const void* x2, int c2, const void*
  * kernels the LayerNorm runs in the convolution's epilogue, on the fp32 accumulators (one launch, z is never
  * re-read); every other shape runs ad_conv3x3_fwd followed by ad_layernorm_relu_fwd.  Workspace as ad_conv3x3_fwd. */
 int ad_conv3x3_ln_relu_is_fused(int n, int h, int w, int c1, int c2, int cout, int dtype);   /* 1: one launch */
+/* act == NULL: z, mean and rstd only (the caller re-derives the activation where it is consumed: ad_head_ln_bwd with
+ * xh == NULL).  Exists for the weights-resident kernel (c1 + c2 = 64 -> cout = 64); ad_conv3x3_ln_stats_is_fused tells. */
+int ad_conv3x3_ln_stats_is_fused(int n, int h, int w, int c1, int c2, int cout, int dtype);
 int ad_conv3x3_ln_relu_fwd(const void* x1, int c1, const void* x2, int c2,
                            const void* w_packed, const float* bias,
                            const float* gamma, const float* beta, float eps,
@@ -232,7 +235,10 @@ int ad_head_bwd(const void* xh, const float* w, const float* b, const float* inp
  *   dw, db: as ad_head_bwd;  dgamma, dbeta: the LayerNorm's;  dbias_conv[ch] = column sums of dz as stored.
  * stats / sqerr (both may be NULL): what ad_head_fwd reports for the same operands -- stats[3] = (loss sum, mean
  * tf.image.psnr, loss mean), sqerr[n] per-image squared error.  The pass re-derives the head's output for the gradient
- * anyway, so a TRAIN step (model.fit, :622-632: only loss and metric leave the step) needs no forward launch over the head. */
+ * anyway, so a TRAIN step (model.fit, :622-632: only loss and metric leave the step) needs no forward launch over the head.
+ * xh == NULL: the head's input relu(gamma * (z - mean) * rstd + beta) is re-derived from z (rounded to the storage type, as
+ * a stored activation would be) -- the layer's forward pass then need not write its activation at all
+ * (ad_conv3x3_ln_relu_fwd with act == NULL). */
 size_t ad_head_ln_bwd_ws_bytes(int n, int ch);
 int ad_head_ln_bwd(const void* xh, const float* w, const float* b, const float* inp, const float* target,
                    const void* z, const float* mean, const float* rstd, const float* gamma, const float* beta,

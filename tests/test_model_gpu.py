@@ -188,13 +188,16 @@ def test_train_step_reports_the_loss_and_metric_of_the_forward_pass(device, dtyp
     backward kernel (ad_head_ln_bwd), which re-derives the output for the gradient anyway, reports both.  They must be the
     numbers of the forward head kernel (checked against the oracle elsewhere) on the same weights: same per-element terms,
     another summation order -- 2e-6 relative on the loss, 1e-4 dB on the PSNR; and the step's weights must not depend on which
-    kernel reported (ADUNET_HEAD_FWD_IN_TRAIN=1 keeps the forward launch): bitwise."""
+    kernel reported (ADUNET_HEAD_FWD_IN_TRAIN=1 keeps the forward launch): bitwise.  (ADUNET_KEEP_HEAD_ACT=1 throughout: the
+    layer in front of the head stores its activation, as the forward pass compared with does; the step that re-derives it
+    instead is test_train_step_that_rederives_the_head_input.)"""
     import os
     from adunet_amd.model import Adam, build_losses_and_metrics, build_super_resolution_unet
     scale, depth, p, n, loss_name = case
     rng = np.random.default_rng(9)
     lr, hr = synth(rng, n, p)
     finals = []
+    os.environ["ADUNET_KEEP_HEAD_ACT"] = "1"
     for keep_fwd in (False, True):
         model, _ = build_super_resolution_unet(scale, depth_override=depth, input_size=p, dtype=dtype, device=device)
         loss, metrics = build_losses_and_metrics(loss_name)
@@ -212,7 +215,49 @@ def test_train_step_reports_the_loss_and_metric_of_the_forward_pass(device, dtyp
         assert abs(float(got_loss) - want_loss) < 2e-6 * want_loss, (float(got_loss), want_loss)
         assert abs(float(got_psnr) - want_psnr) < 1e-4, (float(got_psnr), want_psnr)
         finals.append(model.P.clone())
+    os.environ.pop("ADUNET_KEEP_HEAD_ACT", None)
     assert torch.equal(finals[0], finals[1])
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_train_step_that_rederives_the_head_input(device, dtype):
+    """Where the weights-resident kernel takes the layer in front of the head (K2' at batch 8 here), a train step does not
+    store that layer's activation: ad_head_ln_bwd re-derives it from z, rounded to the storage type.  The stored tensor held
+    round(f(fp32 accumulator)), the re-derived one is round(f(round(accumulator))): both are the exact activation to one
+    rounding, so loss, metric and every gradient must agree with the storing step to that rounding -- 1e-4 relative on the
+    loss, 1e-2 dB, and per parameter tensor 1 % of the tensor's largest gradient (observed: see DESIGN 6) -- and the step is
+    deterministic and replays bitwise from its captured graph."""
+    import os
+    from adunet_amd.model import Adam, build_losses_and_metrics, build_super_resolution_unet
+    rng = np.random.default_rng(9)
+    lr, hr = synth(rng, 8, 256)
+    res = {}
+    for mode in ("stored", "rederived", "rederived-again", "graph"):
+        model, _ = build_super_resolution_unet(0.25, depth_override=4, input_size=256, dtype=dtype, device=device)
+        loss, metrics = build_losses_and_metrics("charbonnier")
+        model.compile(optimizer=Adam(1e-3), loss=loss, metrics=metrics)
+        model._require_device()
+        model.set_weights(model.initial_weights(np.random.default_rng(1), head_uniform=0.05))
+        if mode == "stored":
+            os.environ["ADUNET_KEEP_HEAD_ACT"] = "1"
+        try:
+            if mode == "graph":
+                step = model.make_graphed_train_step(lr, hr, capture_only=True)
+                l, p = step(lr, hr)
+            else:
+                l, p = model.train_on_batch(lr, hr)
+        finally:
+            os.environ.pop("ADUNET_KEEP_HEAD_ACT", None)
+        torch.cuda.synchronize()
+        res[mode] = (float(l), float(p), model.G.clone(), model.P.clone(), dict(model.index))
+    assert torch.equal(res["rederived"][3], res["rederived-again"][3]) and torch.equal(res["rederived"][3], res["graph"][3])
+    a, b = res["stored"], res["rederived"]
+    assert abs(a[0] - b[0]) < 1e-4 * abs(a[0]) and abs(a[1] - b[1]) < 1e-2, (a[:2], b[:2])
+    assert not torch.equal(a[2], b[2]), "the two steps ran the same kernels: the re-deriving path was not taken"
+    for name, (off, shape) in a[4].items():
+        k = int(np.prod(shape))
+        ga, gb = a[2][off:off + k], b[2][off:off + k]
+        assert float((ga - gb).abs().max()) <= 1e-2 * float(ga.abs().max()) + 1e-12, name
 
 
 FULL_SIZE = [

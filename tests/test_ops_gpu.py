@@ -945,3 +945,91 @@ def test_dgrad_with_fused_layernorm_bwd_against_the_oracle(device, ws, dtype):
         err = np.abs(gq.to(torch.float64).cpu().numpy() - wq)
         lim = (3e-3 if name == "dbias" else 1e-3) * np.abs(wq).max() + sl       # dbias sums dz AS STORED (16 bits)
         assert (err <= lim).all(), (name, float((err / np.abs(wq).max()).max()))
+
+
+@pytest.mark.parametrize("dtype", [BF16, F16])
+def test_conv_layernorm_forward_without_the_activation_tensor(device, dtype):
+    """ad_conv3x3_ln_relu_fwd with act == NULL (the layer in front of the head in a train step: its only consumer re-derives
+    the activation from z): z, mean and rstd must be BITWISE what the full epilogue writes."""
+    from adunet_amd import ops
+    n, h, w, c = 20, 128, 128, 64
+    rng = np.random.default_rng(31)
+    x = to_dev(rng.standard_normal((n, h, w, c)), dtype, device)
+    wk = torch.tensor(rng.standard_normal((3, 3, c, c)) * 0.05, dtype=F32, device=device)
+    wf, _ = ops.conv3x3_pack(wk, c, dtype, want_dgrad=False)
+    bias, gamma, beta = (torch.tensor(rng.standard_normal(c), dtype=F32, device=device) for _ in range(3))
+    assert ops.conv3x3_ln_stats_is_fused(x, None, c)
+    z, a, mean, rstd = ops.conv3x3_ln_relu_fwd(x, None, wf, bias, gamma, beta, c)
+    z2, a2, mean2, rstd2 = ops.conv3x3_ln_relu_fwd(x, None, wf, bias, gamma, beta, c, want_act=False)
+    assert a2 is None and torch.equal(z, z2) and torch.equal(mean, mean2) and torch.equal(rstd, rstd2)
+    # no kernel for small launches (generic path) or other channel counts: the query says so and the call refuses
+    small = x[:1, :16, :16].contiguous()
+    assert not ops.conv3x3_ln_stats_is_fused(small, None, c)
+    with pytest.raises(Exception):
+        ops.conv3x3_ln_relu_fwd(small, None, wf, bias, gamma, beta, c, want_act=False)
+
+
+@pytest.mark.parametrize("dtype", [BF16, F16])
+@pytest.mark.parametrize("loss_kind", [0, 1])
+def test_head_backward_that_rederives_its_input_from_z(device, ws, dtype, loss_kind):
+    """ad_head_ln_bwd with xh == NULL: the head's input relu(LayerNorm(z)), rounded to the storage type, is re-derived from
+    the saved conv output -- against the float64 oracle (train_adaptive_unet.py:265-276 backward) and against the same kernel
+    fed that activation as a stored tensor."""
+    from adunet_amd import ops
+    rng = np.random.default_rng(17 + loss_kind)
+    n, h, w, ch = 3, 37, 29, 64
+    z = rnd(rng.standard_normal((n, h, w, ch)) * 1.5 + 0.3, dtype)
+    gam = (rng.random(ch) + 0.5).astype(np.float32).astype(np.float64)
+    bet = (rng.random(ch) - 0.4).astype(np.float32).astype(np.float64)
+    mean = z.mean(-1, keepdims=True).astype(np.float32).astype(np.float64)
+    rstd = (1.0 / np.sqrt(z.var(-1, keepdims=True) + 1e-3)).astype(np.float32).astype(np.float64)
+    xhat = (z - mean) * rstd
+    y = xhat * gam + bet
+    act = rnd(np.maximum(y, 0), dtype)                         # what a stored activation tensor holds
+    wk = rng.uniform(-0.05, 0.05, (1, 1, ch, 3)).astype(np.float32).astype(np.float64)
+    b = rng.uniform(-0.05, 0.05, 3).astype(np.float32).astype(np.float64)
+    hr = rng.random((n, h, w, 3)).astype(np.float32).astype(np.float64)
+    lr = np.clip(hr + 0.3 * rng.standard_normal(hr.shape), -0.2, 1.2).astype(np.float32).astype(np.float64)
+    up = 4096.0                                               # a loss scale: keeps half-precision dz out of its subnormals
+    gscale = up / hr.size
+    out, pre = ref.clip_add_fwd(lr, ref.conv2d_same_fwd(act, wk, b))
+    dout = (ref.charbonnier_bwd(hr, out) if loss_kind == 0 else ref.l1_bwd(hr, out)) * up
+    dr = ref.clip_add_bwd(dout, pre)
+    da, dw, db = ref.conv2d_same_bwd(act, wk, dr)
+    dl = da * (y > 0)
+    dgamma, dbeta = (dl * xhat).sum((0, 1, 2)), dl.sum((0, 1, 2))
+    g = dl * gam
+    dz = rstd * (g - g.mean(-1, keepdims=True) - xhat * (g * xhat).mean(-1, keepdims=True))
+    loss = ref.charbonnier_fwd(hr, out) if loss_kind == 0 else ref.l1_fwd(hr, out)
+
+    f = lambda a: torch.tensor(a, dtype=F32, device=device)
+    zd = to_dev(z, dtype, device)
+    args = (f(wk.reshape(ch, 3)), f(b), f(lr), f(hr), zd, f(mean.reshape(-1)), f(rstd.reshape(-1)), f(gam), f(bet))
+
+    def run(xh):
+        o = [torch.empty((ch, 3), dtype=F32, device=device), torch.empty(3, dtype=F32, device=device)] + \
+            [torch.empty(ch, dtype=F32, device=device) for _ in range(3)]
+        stats = torch.empty(3, dtype=F32, device=device)
+        sq = torch.empty(n, dtype=F32, device=device)
+        d = ops.head_ln_bwd(xh, *args, *o, gscale, ws, loss_kind=loss_kind, stats=stats, sqerr=sq)
+        return [d] + o + [stats, sq]
+
+    got = run(None)
+    # pixels whose clip or ReLU decision sits on a kink may legitimately differ between fp32 and float64
+    kink = (np.abs(pre) < 1e-5) | (np.abs(pre - 1.0) < 1e-5)
+    okpix = ~kink.any(-1) & (np.abs(y) > 1e-4).all(-1)
+    gd = got[0].to(torch.float64).cpu().numpy()
+    assert okpix.mean() > 0.9
+    assert np.abs(gd - dz)[okpix].max() <= TOL[dtype] * np.abs(dz).max()
+    slack = np.abs(dout * kink).sum() * np.abs(act).max() + 1e-3 * np.abs(dw).max()
+    assert np.abs(got[1].cpu().numpy().astype(np.float64) - dw.reshape(ch, 3)).max() <= slack
+    assert relerr(got[2], db) < 1e-3 + float(np.abs(dout * kink).sum() / np.abs(db).max())
+    assert relerr(got[3], dgamma) < 5e-3 and relerr(got[4], dbeta) < 5e-3
+    assert abs(float(got[6][0]) / hr.size - loss) < 1e-5 * max(1.0, abs(loss))
+    assert relerr(got[7], ((hr - out) ** 2).reshape(n, -1).sum(1)) < 1e-4
+    # the same kernel fed the activation as a stored tensor: fp32-vs-float64 rounding ties of the activation aside, the same numbers
+    want = run(to_dev(act, dtype, device))
+    assert float((got[0].float() - want[0].float()).abs().max()) <= TOL[dtype] * float(want[0].float().abs().max())
+    for i in (1, 2, 3, 4, 5):
+        assert float((got[i] - want[i]).abs().max()) <= 2e-3 * float(want[i].abs().max()), i
+    assert abs(float(got[6][0]) - float(want[6][0])) <= 1e-5 * abs(float(want[6][0]))
