@@ -119,6 +119,28 @@ template <> struct Vec16<f16_t> {
     }
 };
 
+#ifdef __HIPCC__
+// Sum over the G lanes (a power of two up to 64, aligned) that own one pixel / row, returned in each of them.  Inside a row of
+// 16 lanes the partners arrive as DPP operands of the adds (quad_perm for the lanes 1 and 2 away; once the four lanes of a quad
+// agree, row_half_mirror / row_mirror deliver the other quad's / the other half row's sum) instead of ds_bpermute round trips
+// through LDS (what __shfl_xor compiles to): head_ln_bwd_kernel, bound by its instruction count, had 15 of them per pixel.
+template <int CTRL>
+__device__ __forceinline__ float ad_dpp_f32(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+template <int G>
+__device__ __forceinline__ float ad_group_sum(float v) {
+    static_assert(G >= 1 && G <= 64 && (G & (G - 1)) == 0, "lane groups are powers of two");
+    if (G >= 2) v += ad_dpp_f32<0xB1>(v);            // quad_perm [1, 0, 3, 2]
+    if (G >= 4) v += ad_dpp_f32<0x4E>(v);            // quad_perm [2, 3, 0, 1]
+    if (G >= 8) v += ad_dpp_f32<0x141>(v);           // row_half_mirror
+    if (G >= 16) v += ad_dpp_f32<0x140>(v);          // row_mirror
+#pragma unroll
+    for (int o = 16; o < G; o <<= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+#endif
+
 template <typename A, typename B> struct ad_same_type { static constexpr bool value = false; };
 template <typename A> struct ad_same_type<A, A> { static constexpr bool value = true; };
 

@@ -9,11 +9,7 @@ namespace {
 constexpr int BPI_MAX = 32;  // blocks per image
 
 template <int G>
-__device__ __forceinline__ float gsum(float v) {
-#pragma unroll
-    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
+__device__ __forceinline__ float gsum(float v) { return ad_group_sum<G>(v); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

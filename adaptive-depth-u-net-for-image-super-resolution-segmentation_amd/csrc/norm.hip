@@ -9,11 +9,7 @@ namespace {
 constexpr int NB_MAX = 1024;  // blocks used by the backward kernels (partials per block in ws)
 
 template <int G>
-__device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
+__device__ __forceinline__ float group_sum(float v) { return ad_group_sum<G>(v); }
 
 // ----------------------------------------------------------------------------- forward
 template <typename T, int NV, int G>
