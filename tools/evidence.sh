@@ -20,7 +20,7 @@ python3 tools/pmc_summary.py "$out/pmc_fetch_size" "$out/pmc_write_size" "$out/p
 cp "$out/pmc_traffic.json" profiles/${tag}_pmc_traffic.json          # bench.py quotes it (stamped) from here on
 python3 bench.py --breakdown > "$out/bench.json" 2> "$out/op_breakdown.txt" || exit 1
 rm -rf "$out/prof"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof" -- python3 bench.py --no-cpu-baseline > "$out/bench_under_rocprof.json" 2> "$out/bench_under_rocprof.err" || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof" -- python3 bench.py --no-cpu-baseline --no-micro > "$out/bench_under_rocprof.json" 2> "$out/bench_under_rocprof.err" || exit 1
 cp "$(ls $out/prof/*/*_kernel_stats.csv | head -1)" "$out/kernel_stats.csv"
 for w in E2s06 E2s07; do
     python3 bench.py --workload $w --steps 10 --warmup 3 --breakdown --no-cpu-baseline --no-micro > "$out/bench_$w.json" 2> "$out/op_breakdown_$w.txt" || exit 1
