@@ -155,3 +155,26 @@ def test_the_mosaic_is_taken_where_it_saves_a_round(device):
     # scale 0.6, batch 32 (run_experiment_adaptive_depth.sh:47-55): the 56- and 34-wide levels
     assert mosaic_row((32, 56, 56, 512, 0, 512), BF16) > 0 and mosaic_row((32, 34, 34, 1024, 0, 1024), BF16) > 0
     assert mosaic_row((32, 56, 56, 512, 0, 512), BF16, wgrad=1) > 0 and mosaic_row((32, 34, 34, 1024, 0, 1024), BF16, wgrad=1) > 0
+
+
+def test_batches_of_2gib_and_more_take_the_mosaic_run_by_run(device, ws):
+    """Tensors that reach 2 GiB are cut into runs of images inside the library (32-bit buffer offsets); every run plans its own
+    mosaic.  1 100 images of 34 x 34 x 1 024 (2.6 GB): forward bitwise the per-image tiling, wgrad equal to summation order."""
+    from adunet_amd import ops
+    n, h, w, c = 1100, 34, 34, 1024
+    g = torch.Generator(device=device).manual_seed(7)
+    x = (torch.rand((n, h, w, c), device=device, generator=g) - 0.5).bfloat16()
+    wk = (torch.rand((3, 3, c, 128), device=device, generator=g) - 0.5) * 0.05
+    wf, _ = ops.conv3x3_pack(wk, c, BF16, want_dgrad=False)
+    b = torch.rand(128, device=device, generator=g)
+    y = ops.conv3x3_fwd(x, None, wf, b, 128)
+    dz = y
+    dw = torch.empty((3, 3, c, 128), dtype=F32, device=device)
+    ops.conv3x3_wgrad(x, None, dz, dw, c, ws)
+    with per_image_tiling():
+        y0 = ops.conv3x3_fwd(x, None, wf, b, 128)
+        dw0 = torch.empty_like(dw)
+        ops.conv3x3_wgrad(x, None, dz, dw0, c, ws)
+    assert torch.equal(y, y0)
+    assert float((dw - dw0).abs().max() / dw0.abs().max()) < 1e-5
+    assert mosaic_row((n // 2, h, w, c, 0, 128), BF16) > 0 and mosaic_row((n // 2, h, w, c, 0, 128), BF16, wgrad=1) > 0

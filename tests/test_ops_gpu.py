@@ -493,7 +493,11 @@ def test_conv3x3_batches_of_2gib_and_more_run_in_image_chunks(device, ws):
         z2, a2, m2, r2 = ops.conv3x3_ln_relu_fwd(x[lo:lo + half], None, wf, b, gam, bet, c)
         assert torch.equal(z[lo:lo + half], z2) and torch.equal(act[lo:lo + half], a2)
         assert torch.equal(mean[lo * h * w:lo * h * w + npx], m2) and torch.equal(rstd[lo * h * w:lo * h * w + npx], r2)
-    del act, mean, rstd, y
+    # ... and the variant that writes no activation (the layer in front of the head in a train step)
+    assert ops.conv3x3_ln_stats_is_fused(x, None, c)
+    z3, a3, m3, r3 = ops.conv3x3_ln_relu_fwd(x, None, wf, b, gam, bet, c, want_act=False)
+    assert a3 is None and torch.equal(z, z3) and torch.equal(mean, m3) and torch.equal(rstd, r3)
+    del act, mean, rstd, y, z3, m3, r3
     dz = z                                   # any bf16 tensor of the right shape
     dw = torch.empty((3, 3, c, c), dtype=F32, device=device)
     ops.conv3x3_wgrad(x, None, dz, dw, c, ws)
