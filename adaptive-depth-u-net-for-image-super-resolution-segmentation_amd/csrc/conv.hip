@@ -1067,9 +1067,11 @@ __device__ __forceinline__ void ws_mma_role_lnb(const ConvArgs& a, const char* x
     const int scst = ((grp & 1) * 16 + (grp >> 1) * 8) * TSZ;
     const int px0s = ((wave * 4) * a.w + (lane & 15)) * CY * TSZ + scst;
     const int zdiff = grp * 4 * TSZ - scst;
-    float cg[16], cb[16], cz[16];
+    // per-channel sums as float PAIRS (channels q, q + 1 of an n-tile): the epilogue below is written on pairs so that its
+    // multiply-adds and adds are v_pk_* instructions (r04: 144 scalar v_add_f32 per item were the cb / cz updates)
+    f32x2 cg2[8], cb2[8], cz2[8];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) cg[j] = cb[j] = cz[j] = 0.f;
+    for (int j = 0; j < 8; ++j) cg2[j] = cb2[j] = cz2[j] = f32x2{0.f, 0.f};
     u32x2 zq[16];
     float mu[4], rs[4];
     int pixbase = 0, ylim = 0;                  // of the current item (wave uniform)
@@ -1177,42 +1179,59 @@ __device__ __forceinline__ void ws_mma_role_lnb(const ConvArgs& a, const char* x
             const unsigned pvo_mt = pvo_of(mt);
             const bool valid = pvo_mt != WR_OOB;
             const float rstd = rs[mt], nmr = -mu[mt] * rstd;     // xhat = z * rstd + (-mean * rstd): one fma per element (r03)
-            float xh[16], gg[16];
-            float s1 = 0.f, s2 = 0.f;
+            const f32x2 rstd2 = {rstd, rstd}, nmr2 = {nmr, nmr};
+            f32x2 xh2[8], gg2[8];
+            f32x2 s1p = {0.f, 0.f}, s2p = {0.f, 0.f};
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-                const float4 ga = *reinterpret_cast<const float4*>(gb + nt * 16 + grp * 4);
-                const float4 be = *reinterpret_cast<const float4*>(gb + 64 + nt * 16 + grp * 4);
-                const float gaa[4] = {ga.x, ga.y, ga.z, ga.w}, bea[4] = {be.x, be.y, be.z, be.w};
+                const f32x4 ga = *reinterpret_cast<const f32x4*>(gb + nt * 16 + grp * 4);
+                const f32x4 be = *reinterpret_cast<const f32x4*>(gb + 64 + nt * 16 + grp * 4);
                 union { h4 h; u32x2 u; } zz;
                 zz.u = zq[mt * 4 + nt];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float h = fmaf((float)zz.h[q], rstd, nmr);
-                    const float yv = h * gaa[q] + bea[q];
-                    const float dl = (valid && yv > 0.f) ? acc[mt][nt][q] : 0.f;
-                    cg[nt * 4 + q] += dl * h;
-                    cb[nt * 4 + q] += dl;
-                    const float gv = dl * gaa[q];
-                    s1 += gv;
-                    s2 += gv * h;
-                    xh[nt * 4 + q] = h;
-                    gg[nt * 4 + q] = gv;
+                for (int hp = 0; hp < 2; ++hp) {          // channel pair (2 hp, 2 hp + 1) of this lane's four
+                    const f32x2 ga2 = hp ? ga.zw : ga.xy, be2 = hp ? be.zw : be.xy;
+                    const f32x2 zf = {(float)zz.h[2 * hp], (float)zz.h[2 * hp + 1]};
+                    const f32x2 h = __builtin_elementwise_fma(zf, rstd2, nmr2);
+                    const f32x2 yv = __builtin_elementwise_fma(h, ga2, be2);
+                    const f32x2 av = hp ? acc[mt][nt].zw : acc[mt][nt].xy;
+                    const f32x2 dl = {(valid && yv.x > 0.f) ? av.x : 0.f, (valid && yv.y > 0.f) ? av.y : 0.f};
+                    const int j = nt * 2 + hp;
+                    cg2[j] = __builtin_elementwise_fma(dl, h, cg2[j]);
+                    cb2[j] += dl;
+                    const f32x2 gv = dl * ga2;
+                    s1p += gv;
+                    s2p = __builtin_elementwise_fma(gv, h, s2p);
+                    xh2[j] = h;
+                    gg2[j] = gv;
                 }
             }
             // dz = rstd (g - mean(g) - xhat mean(g xhat)) as two fused multiply-adds per element on per-pixel products (r03)
-            s1 = sum_lane_groups(s1) * (-rstd / 64.f);
-            s2 = sum_lane_groups(s2) * (-rstd / 64.f);
+            const float s1 = sum_lane_groups(s1p.x + s1p.y) * (-rstd / 64.f);
+            const float s2 = sum_lane_groups(s2p.x + s2p.y) * (-rstd / 64.f);
+            const f32x2 s1v = {s1, s1}, s2v = {s2, s2};
+            typedef E e16x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
             for (int np = 0; np < 2; ++np) {
-                union { h4 h; u32x2 u; } pa, pb;
+                union { u32x2 u; } pa, pb;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int ja = (2 * np) * 4 + q, jb = (2 * np + 1) * 4 + q;
-                    pa.h[q] = (E)fmaf(xh[ja], s2, fmaf(gg[ja], rstd, s1));
-                    pb.h[q] = (E)fmaf(xh[jb], s2, fmaf(gg[jb], rstd, s1));
-                    cz[ja] += (float)pa.h[q];           // the conv bias gradient sums dz as stored (what wgrad sees)
-                    cz[jb] += (float)pb.h[q];
+                for (int hp = 0; hp < 2; ++hp) {
+                    const int ja = (2 * np) * 2 + hp, jb = (2 * np + 1) * 2 + hp;
+                    const f32x2 da = __builtin_elementwise_fma(xh2[ja], s2v, __builtin_elementwise_fma(gg2[ja], rstd2, s1v));
+                    const f32x2 db = __builtin_elementwise_fma(xh2[jb], s2v, __builtin_elementwise_fma(gg2[jb], rstd2, s1v));
+                    const e16x2 ta = {(E)da.x, (E)da.y}, tb = {(E)db.x, (E)db.y};
+                    pa.u[hp] = __builtin_bit_cast(unsigned, ta);
+                    pb.u[hp] = __builtin_bit_cast(unsigned, tb);
+                    // the conv bias gradient sums dz as stored (what wgrad sees); bf16: the two stored values back as floats are a
+                    // shift and a mask of the packed word (hipcc converts each element a second time when asked for (float)ta.x)
+                    if constexpr (sizeof(E) == 2 && !ad_same_type<E, f16_t>::value) {
+                        asm volatile("" : "+v"(pa.u[hp]), "+v"(pb.u[hp]));      // opaque: else the low half is converted once more
+                        cz2[ja] += f32x2{__builtin_bit_cast(float, pa.u[hp] << 16), __builtin_bit_cast(float, pa.u[hp] & 0xffff0000u)};
+                        cz2[jb] += f32x2{__builtin_bit_cast(float, pb.u[hp] << 16), __builtin_bit_cast(float, pb.u[hp] & 0xffff0000u)};
+                    } else {
+                        cz2[ja] += f32x2{(float)ta.x, (float)ta.y};
+                        cz2[jb] += f32x2{(float)tb.x, (float)tb.y};
+                    }
                 }
                 const u32x2 w0 = __builtin_amdgcn_permlane16_swap(pa.u[0], pb.u[0], false, false);
                 const u32x2 w1 = __builtin_amdgcn_permlane16_swap(pa.u[1], pb.u[1], false, false);
@@ -1235,7 +1254,7 @@ __device__ __forceinline__ void ws_mma_role_lnb(const ConvArgs& a, const char* x
     float* row = a.dbias_part + ((size_t)blockIdx.x * 4 + wave) * (3 * BN);
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        float v0 = cg[j], v1 = cb[j], v2 = cz[j];
+        float v0 = cg2[j >> 1][j & 1], v1 = cb2[j >> 1][j & 1], v2 = cz2[j >> 1][j & 1];
 #pragma unroll
         for (int of = 1; of < 16; of <<= 1) {
             v0 += __shfl_xor(v0, of, 64);
