@@ -802,14 +802,18 @@ __device__ __forceinline__ void ws_pack_tile(const f32x4 (&acc)[4][4], const flo
                 f32x2 va = h ? acc[mt][2 * np].zw : acc[mt][2 * np].xy;
                 f32x2 vb = h ? acc[mt][2 * np + 1].zw : acc[mt][2 * np + 1].xy;
                 if (EPI == 1) { va = relu2(va); vb = relu2(vb); }
-                pa.h[2 * h] = (E)va.x; pa.h[2 * h + 1] = (E)va.y;
-                pb.h[2 * h] = (E)vb.x; pb.h[2 * h + 1] = (E)vb.y;
+                const e16x2 za = __builtin_convertvector(va, e16x2), zb = __builtin_convertvector(vb, e16x2);
+                pa.u[h] = __builtin_bit_cast(unsigned, za);
+                pb.u[h] = __builtin_bit_cast(unsigned, zb);
                 if (EPI == 2) {
-                    const f32x2 ya = __builtin_elementwise_fma(__builtin_elementwise_fma(va, rstd2, nmr2), h ? ga.zw : ga.xy, h ? ba.zw : ba.xy);
-                    const f32x2 yb = __builtin_elementwise_fma(__builtin_elementwise_fma(vb, rstd2, nmr2), h ? gb4.zw : gb4.xy, h ? bb.zw : bb.xy);
+                    f32x2 ya = __builtin_elementwise_fma(__builtin_elementwise_fma(va, rstd2, nmr2), h ? ga.zw : ga.xy, h ? ba.zw : ba.xy);
+                    f32x2 yb = __builtin_elementwise_fma(__builtin_elementwise_fma(vb, rstd2, nmr2), h ? gb4.zw : gb4.xy, h ? bb.zw : bb.xy);
                     // (built as values, not through the union: writing .h elements and reading .u back in the same iteration
                     // was folded to the h = 0 pair by hipcc)
-                    const e16x2 ta = {(E)ya.x, (E)ya.y}, tb = {(E)yb.x, (E)yb.y};
+                    // one v_cvt_pk per pair (r04: as element-wise casts the pairs were converted singly and joined by v_perm_b32,
+                    // 96 instructions per item where 32 do)
+                    asm volatile("" : "+v"(ya), "+v"(yb));
+                    const e16x2 ta = __builtin_convertvector(ya, e16x2), tb = __builtin_convertvector(yb, e16x2);
                     qa.u[h] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, ta), s16x2{0, 0}));
                     qb.u[h] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, tb), s16x2{0, 0}));
                 }
