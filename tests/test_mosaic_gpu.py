@@ -59,6 +59,7 @@ CASES = [
     (11, 34, 34, 128, 0, 512, 3),        # 11 images, 3 per row: the last mosaic row holds TWO (99 tiles -> 63)
     (9, 56, 56, 64, 64, 256, None),      # virtual concat of two inputs; 144 tiles -> 121
     (15, 43, 88, 128, 0, 128, 3),        # h != w, 3 x 5 images; 270 tiles -> 238 (3 rounds of 128 tiles -> 2)
+    (1000, 17, 17, 128, 0, 64, None),    # many small maps one pixel past a tile: 4 000 tiles -> ~1 300, a 18-pixel pitch
 ]
 
 
