@@ -1,6 +1,6 @@
 """Per-launch table of the conv kernels inside one eager train step of a workload: shape, time, TFLOP/s, fraction of peak.
 
-    python tools/layer_table.py --workload E2s06 [--batch B]
+    python tools/layer_table.py --workload E2s06 [--batch B]        (or --workload scale,depth,patch,batch)
 
 The ops wrappers are patched to bracket each call with HIP events (launch stream); two eager steps are timed, the second
 is printed.  Shows which launches of a pyramid sit far below the roof (odd map widths, small maps, wide channels)."""
@@ -44,7 +44,11 @@ def main():
     ap.add_argument("--batch", type=int, default=None)
     args = ap.parse_args()
     from adunet_amd.model import Adam, build_losses_and_metrics, build_super_resolution_unet
-    scale, depth, patch, batch = WORKLOADS[args.workload]
+    if args.workload in WORKLOADS:
+        scale, depth, patch, batch = WORKLOADS[args.workload]
+    else:                                            # "scale,depth,patch,batch", e.g. 0.4,3,256,64
+        f = args.workload.split(",")
+        scale, depth, patch, batch = float(f[0]), int(f[1]), int(f[2]), int(f[3])
     batch = args.batch or batch
     dev = torch.device("cuda:0")
     model, _ = build_super_resolution_unet(scale, depth_override=depth, input_size=patch, dtype=torch.bfloat16, device=dev)
