@@ -72,7 +72,12 @@ struct PwArgs {
     const char* x; const char* bp; char* y;
     int m, k, n;               // pixels, contraction, output channels (n % 64 == 0, k % 64 == 0)
     int nb_per_wg;             // 64-channel output blocks per workgroup
+    unsigned long long* dbg;   // diagnostic builds only (-DAD_STAMP, tools/stamps_pw.py): cycle sums by phase of wave 0
 };
+#ifdef AD_STAMP
+static unsigned long long* g_pw_dbg = nullptr;
+extern "C" void ad_dbg_set_pw_stamp_buffer(void* p) { g_pw_dbg = (unsigned long long*)p; }
+#endif
 
 constexpr int PW_T = 256;      // 4 waves, 64 pixels each
 
@@ -232,23 +237,36 @@ __global__ __launch_bounds__(PL_T, 1) void pw_gemm_lds_kernel(PwArgs a) {
     {                                                                                                            \
         const int tq_ = min(it, ntiles - 1);          /* past the end: re-read the last stage, never stored */   \
         const int tm_ = tq_ / tiles_n, tn_ = tq_ - tm_ * tiles_n;                                                \
+        const int kk_ = iks;                                                                                     \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                          \
             const int mrow_ = tm_ * 256 + xrow[i];                                                               \
             xr[SLOT][i] = __builtin_amdgcn_raw_buffer_load_b128(rsx, mrow_ < a.m ? (unsigned)(mrow_ * a.k * 2 + xpart) : PW_OOB, \
-                                                                (unsigned)(iks * 128), 0);                       \
+                                                                (unsigned)(kk_ * 128), 0);                       \
         }                                                                                                        \
-        const unsigned wb_ = (unsigned)((iks * 8 * a.n + tn_ * G::NT) * 16);                                     \
+        const unsigned wb_ = (unsigned)((kk_ * 8 * a.n + tn_ * G::NT) * 16);                                     \
         _Pragma("unroll") for (int i = 0; i < G::WSL; ++i)                                                       \
             wr[SLOT][i] = __builtin_amdgcn_raw_buffer_load_b128(rsb, (unsigned)wsrc[i], wb_, 0);                 \
         if (++iks == ks_per_tile) { iks = 0; it += gridDim.x; }                                                  \
     }
+#ifdef AD_STAMP
+    unsigned long long pst[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long pt_last = clock64();
+    const unsigned long long pt_begin = pt_last;
+#define PSTAMP(slot) do { unsigned long long now_ = clock64(); pst[slot] += now_ - pt_last; pt_last = now_; } while (0)
+#else
+#define PSTAMP(slot) do {} while (0)
+#endif
 #define PL_STAGE(SLOT)                                                                                           \
     {                                                                                                            \
         char* sb = smem + buf * G::STAGE;                                                                        \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(sb + xlds[i]) = xr[SLOT][i];     \
         _Pragma("unroll") for (int i = 0; i < G::WSL; ++i) *reinterpret_cast<u32x4*>(sb + wlds[i]) = wr[SLOT][i]; \
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                          \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                       \
+        PSTAMP(0);                          /* wait for the staged loads + LDS stores */                         \
+        asm volatile("s_barrier" ::: "memory");                                                                  \
+        PSTAMP(1);                          /* barrier */                                                        \
         PL_ISSUE(SLOT)                                                                                           \
+        PSTAMP(2);                          /* issue of the next loads */                                        \
         _Pragma("unroll") for (int c = 0; c < 2; ++c) {                                                          \
             frag xf[4], wf[NW];                                                                                  \
             _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                     \
@@ -258,6 +276,7 @@ __global__ __launch_bounds__(PL_T, 1) void pw_gemm_lds_kernel(PwArgs a) {
             _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                     \
                 _Pragma("unroll") for (int nt = 0; nt < NW; ++nt) acc[mt][nt] = P::mma(wf[nt], xf[mt], acc[mt][nt]); \
         }                                                                                                        \
+        PSTAMP(3);                          /* fragment reads + MFMAs of both chunks */                          \
         buf ^= 1;                                                                                                \
     }
     const int xfo = (wm * 64 + l15) * 96 + grp * 16;                           // + mt * 16 * 96 (+ chunk * PL_XB)
@@ -288,7 +307,15 @@ __global__ __launch_bounds__(PL_T, 1) void pw_gemm_lds_kernel(PwArgs a) {
                 __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, rsy, yo + np * 64, 0, 0);
             }
         }
+        PSTAMP(4);                          // tile epilogue (pack + stores)
     }
+#ifdef AD_STAMP
+    if (wave == 0 && lane == 0 && a.dbg) {
+        for (int i = 0; i < 5; ++i) a.dbg[blockIdx.x * 8 + i] = pst[i];
+        a.dbg[blockIdx.x * 8 + 7] = clock64() - pt_begin;
+    }
+#endif
+#undef PSTAMP
 #undef PL_ISSUE
 #undef PL_STAGE
 }
@@ -830,6 +857,10 @@ extern "C" int ad_pw_gemm(const void* x, const void* bank, void* y, int64_t m, i
     a.x = (const char*)x; a.bp = (const char*)bank; a.y = (char*)y;
     a.m = (int)m; a.k = k; a.n = n;
     a.nb_per_wg = 0;
+    a.dbg = nullptr;
+#ifdef AD_STAMP
+    a.dbg = g_pw_dbg;
+#endif
     const int variant = pw_gemm_variant(m, k, n, dtype);
     if (variant > 0) {                                                              // LDS-tiled persistent kernel
         hipStream_t s = (hipStream_t)stream;
