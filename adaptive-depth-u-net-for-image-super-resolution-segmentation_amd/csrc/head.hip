@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ xh,
     }
 }
 
-// stats[0] = sum of all loss partials, stats[2] = their mean over all elements; stats[1] = mean over the images of tf.image.psnr(max_val = 1) = -10 log10(MSE)
+// stats[0] = sum of all loss partials, stats[2] = their mean over all elements; stats[1] = mean over the images of tf.image.psnr(max_val = 1) = -float32(10 / ln 10) ln(MSE)
 // (+inf at MSE 0, as TensorFlow returns); sqerr[img] = sum of that image's squared-error partials
 __global__ __launch_bounds__(256) void head_stats_kernel(const float* __restrict__ part, int n, int bpi,
                                                          float* __restrict__ stats, float* __restrict__ sqerr,
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void head_stats_kernel(const float* __restrict
         float q = 0.f;
         for (int k = 0; k < bpi; ++k) q += part[((size_t)img * bpi + k) * 2 + 1];
         if (sqerr) sqerr[img] = q;
-        ps += -10.f * log10f(q / elems_per_img);
+        ps += -4.3429448190325175f * logf(q / elems_per_img);       // tf.image.psnr: -float32(10 / ln 10) * ln(mse)
     }
     sm[tid] = s;
     sp[tid] = ps;
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void head_stats_strided_kernel(const float* __
         float q = 0.f;
         for (int k = 0; k < bpi; ++k) q += part[((size_t)img * bpi + k) * ncol + col0 + 1];
         if (sqerr) sqerr[img] = q;
-        ps += -10.f * log10f(q / elems_per_img);
+        ps += -4.3429448190325175f * logf(q / elems_per_img);       // tf.image.psnr: -float32(10 / ln 10) * ln(mse)
     }
     sm[tid] = s;
     sp[tid] = ps;

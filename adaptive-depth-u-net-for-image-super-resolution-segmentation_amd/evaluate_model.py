@@ -82,8 +82,7 @@ def evaluate(model, dataset, eval_shave: int, with_ssim: bool = True) -> Tuple[E
         side = min(pred_y.shape[1:3]) - 2 * eval_shave
         mse, ssim, _ = dm.mse_ssim(hr_y, pred_y, shave=eval_shave, with_ssim=with_ssim)
         b_mse = mse.cpu().numpy()
-        with np.errstate(divide="ignore"):
-            b_psnr = (-10.0 * np.log10(b_mse)).astype(np.float32)                 # tf.image.psnr(max_val=1): inf at MSE 0
+        b_psnr = metrics.psnr_from_mse(b_mse)                                    # tf.image.psnr(max_val=1): inf at MSE 0
         b_ssim = ssim.cpu().numpy() if ssim is not None else np.full_like(b_psnr, np.nan)
         # MS-SSIM needs 5 halvings of an 11-pixel window
         b_ms = dm.msssim(hr_y, pred_y, shave=eval_shave) if with_ssim and side >= 11 * 16 else np.full_like(b_psnr, np.nan)
@@ -96,12 +95,15 @@ def evaluate(model, dataset, eval_shave: int, with_ssim: bool = True) -> Tuple[E
     if not per_image:
         raise RuntimeError("Evaluation dataset yielded no samples.")
 
-    def stats(key):
-        arr = np.concatenate(vals[key], axis=0).astype(np.float64)
-        return float(np.mean(arr)), float(np.std(arr))
+    return summarise({k: np.concatenate(v, axis=0) for k, v in vals.items()}), per_image
 
-    (mse_m, mse_s), (p_m, p_s), (s_m, s_s), (ms_m, ms_s) = stats("mse"), stats("psnr"), stats("ssim"), stats("msssim")
-    return EvalResults(mse_m, mse_s, p_m, p_s, s_m, s_s, ms_m, ms_s, len(per_image)), per_image
+
+def summarise(columns: Dict[str, np.ndarray]) -> EvalResults:
+    """evaluate_model.py:141-163: float64 mean / population std of the per-patch float32 columns `mse`, `psnr`, `ssim`,
+    `msssim` (reproduces every metrics.json of the reference from its per_image_metrics.csv:
+    tests/test_reference_metric_reports.py)."""
+    (mse_m, mse_s), (p_m, p_s), (s_m, s_s), (ms_m, ms_s) = (metrics.aggregate(columns[k]) for k in ("mse", "psnr", "ssim", "msssim"))
+    return EvalResults(mse_m, mse_s, p_m, p_s, s_m, s_s, ms_m, ms_s, int(len(columns["mse"])))
 
 
 def attach_filenames(per_image: List[Dict[str, float]], filenames: Sequence[str]) -> None:

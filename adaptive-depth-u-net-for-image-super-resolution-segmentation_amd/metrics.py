@@ -1,5 +1,7 @@
 """Evaluation metrics of the reference's eval loops: device kernels (csrc/metrics.hip) for tensors that live in HBM
-(`*_device`, used by evaluate_model.evaluate) and a NumPy restatement with the same definitions for host arrays.
+(`DeviceMetrics`, used by evaluate_model.evaluate) and the host-side definitions the evaluator needs (luma for host arrays,
+shave rule, PSNR from a per-image MSE, aggregation).  The NumPy restatement of SSIM / MS-SSIM the kernels are tested against
+lives in oracle/metrics.py (test infrastructure).
 
 rgb_to_luma_bt601: Super_resolution/code/train_adaptive_unet.py:144-157; shave: evaluate_model.py:49-54;
 PSNR / MSE / SSIM / MS-SSIM on Y: evaluate_model.py:106-126 (tf.image.psnr / ssim / ssim_multiscale).
@@ -28,63 +30,22 @@ def infer_eval_shave(scale: float, explicit: int | None = None) -> int:
     return 2 * scale_factor if scale_factor > 0 else 0
 
 
-def mse_per_image(a: np.ndarray, b: np.ndarray) -> np.ndarray:
-    d = np.asarray(a, np.float32) - np.asarray(b, np.float32)
-    return (d * d).reshape(d.shape[0], -1).mean(axis=1)
-
-
-def psnr_per_image(a: np.ndarray, b: np.ndarray, max_val: float = 1.0) -> np.ndarray:
+def psnr_from_mse(mse: np.ndarray, max_val: float = 1.0) -> np.ndarray:
+    """tf.image.psnr's float32 arithmetic on a per-image MSE: 20 log(max_val)/log(10) - float32(10/ln 10) * ln(mse), `inf` at
+    MSE 0.  This form (not -10 * log10) is what reproduces the `psnr_y` column of the reference's committed
+    per_image_metrics.csv files from their `mse_y` column (tests/test_reference_metric_reports.py)."""
+    mse = np.asarray(mse, np.float32)
     with np.errstate(divide="ignore"):
-        return (20.0 * np.log10(max_val) - 10.0 * np.log10(mse_per_image(a, b))).astype(np.float32)
+        head = np.float32(20.0) * np.log(np.float32(max_val)) / np.log(np.float32(10.0))
+        return (head - np.float32(10.0 / np.log(10.0)) * np.log(mse)).astype(np.float32)
 
 
-def _gauss_kernel(size: int = 11, sigma: float = 1.5) -> np.ndarray:
-    x = np.arange(size, dtype=np.float64) - (size - 1) / 2.0
-    g = np.exp(-(x * x) / (2.0 * sigma * sigma))
-    return g / g.sum()
-
-
-def _filter_valid(x: np.ndarray, g: np.ndarray) -> np.ndarray:
-    """Separable VALID correlation over H and W of [N,H,W,C]."""
-    k = g.size
-    h = sum(g[i] * x[:, i:x.shape[1] - k + 1 + i] for i in range(k))
-    return sum(g[i] * h[:, :, i:h.shape[2] - k + 1 + i] for i in range(k))
-
-
-def _ssim_cs(a, b, max_val=1.0, k1=0.01, k2=0.03, size=11, sigma=1.5):
-    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
-    g = _gauss_kernel(size, sigma)
-    c1, c2 = (k1 * max_val) ** 2, (k2 * max_val) ** 2
-    mu_a, mu_b = _filter_valid(a, g), _filter_valid(b, g)
-    aa, bb, ab = _filter_valid(a * a, g), _filter_valid(b * b, g), _filter_valid(a * b, g)
-    va, vb, cov = aa - mu_a * mu_a, bb - mu_b * mu_b, ab - mu_a * mu_b
-    lum = (2 * mu_a * mu_b + c1) / (mu_a * mu_a + mu_b * mu_b + c1)
-    cs = (2 * cov + c2) / (va + vb + c2)
-    return (lum * cs).mean(axis=(1, 2)), cs.mean(axis=(1, 2))      # per image, per channel
-
-
-def ssim_per_image(a, b, max_val: float = 1.0) -> np.ndarray:
-    s, _ = _ssim_cs(a, b, max_val)
-    return s.mean(axis=-1).astype(np.float32)
-
-
-def msssim_per_image(a, b, max_val: float = 1.0, weights=MSSSIM_WEIGHTS) -> np.ndarray:
-    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
-    mcs = []
-    for i, _ in enumerate(weights):
-        s, cs = _ssim_cs(a, b, max_val)
-        mcs.append(np.maximum(s if i == len(weights) - 1 else cs, 0.0))
-        if i < len(weights) - 1:
-            n, h, w, c = a.shape
-            pad_h, pad_w = h % 2, w % 2
-            if pad_h or pad_w:                                  # tf pads by symmetric replication before pooling
-                a = np.pad(a, ((0, 0), (0, pad_h), (0, pad_w), (0, 0)), mode="symmetric")
-                b = np.pad(b, ((0, 0), (0, pad_h), (0, pad_w), (0, 0)), mode="symmetric")
-                h, w = h + pad_h, w + pad_w
-            a = a.reshape(n, h // 2, 2, w // 2, 2, c).mean(axis=(2, 4))
-            b = b.reshape(n, h // 2, 2, w // 2, 2, c).mean(axis=(2, 4))
-    mcs = np.stack(mcs, axis=-1)                                 # [N, C, scales]
-    return np.prod(mcs ** np.asarray(weights), axis=-1).mean(axis=-1).astype(np.float32)
+def aggregate(values) -> tuple[float, float]:
+    """evaluate_model.py:141-143 `stats`: float64 mean and population std of the per-patch float32 values (one `inf`
+    gives mean inf / std nan, as in the reference's scale-0.20 reports)."""
+    arr = np.asarray(values).astype(np.float64)
+    with np.errstate(invalid="ignore"):
+        return float(np.mean(arr)), float(np.std(arr))
 
 
 # ----------------------------------------------------------------------------- device path (csrc/metrics.hip)

@@ -417,7 +417,8 @@ def l1_bwd(y_true, y_pred):
 
 
 def psnr_per_image(y_true, y_pred, max_val: float = 1.0):
-    """tf.image.psnr on clip(y_pred): per-image, inf when MSE == 0 (:308-311)."""
+    """tf.image.psnr on clip(y_pred): per-image, inf when MSE == 0 (:308-311).  Float64 truth; the float32 arithmetic
+    TensorFlow itself runs (pinned by the reference's evaluation CSVs) is oracle.metrics.psnr_from_mse."""
     yp = np.clip(y_pred, 0.0, 1.0)
     mse = ((y_true - yp) ** 2).reshape(y_true.shape[0], -1).mean(axis=1)
     with np.errstate(divide="ignore"):

@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 from adunet_amd import metrics, pipeline
+from oracle import metrics as ref_metrics
 from oracle import ops as ref
 
 
@@ -83,21 +84,23 @@ def test_metrics_definitions():
     assert [metrics.infer_eval_shave(s) for s in (0.5, 0.25, 0.6, 0.2, 0.8)] == [4, 8, 4, 10, 2]
     assert metrics.infer_eval_shave(0.5, 3) == 3 and ref.infer_eval_shave(0.3) == metrics.infer_eval_shave(0.3)
     y, b = a[..., :1], np.clip(a[..., :1] + 0.05 * rng.standard_normal((2, 48, 48, 1)).astype(np.float32), 0, 1)
-    assert np.allclose(metrics.psnr_per_image(y, b), ref.psnr_per_image(y.astype(np.float64), b.astype(np.float64)), atol=1e-4)
-    assert np.isinf(metrics.psnr_per_image(y, y)).all()
-    s = metrics.ssim_per_image(y, b)
-    assert np.allclose(metrics.ssim_per_image(y, y), 1.0) and (s < 1).all() and (s > 0.3).all()
+    assert np.array_equal(metrics.rgb_to_luma_bt601(a), ref_metrics.rgb_to_luma_bt601(a))
+    assert np.allclose(ref_metrics.psnr_per_image(y, b), ref.psnr_per_image(y.astype(np.float64), b.astype(np.float64)), atol=1e-4)
+    assert np.isinf(ref_metrics.psnr_per_image(y, y)).all()
+    mse = ref_metrics.mse_per_image(y, b)
+    assert np.array_equal(metrics.psnr_from_mse(mse), ref_metrics.psnr_from_mse(mse))        # product's host form == oracle's
+    s = ref_metrics.ssim_per_image(y, b)
+    assert np.allclose(ref_metrics.ssim_per_image(y, y), 1.0) and (s < 1).all() and (s > 0.3).all()
     big = rng.random((1, 192, 192, 1)).astype(np.float32)
-    assert np.allclose(metrics.msssim_per_image(big, big), 1.0, atol=1e-6)
+    assert np.allclose(ref_metrics.msssim_per_image(big, big), 1.0, atol=1e-6)
     noisy = np.clip(big + 0.1 * rng.standard_normal(big.shape).astype(np.float32), 0, 1)
-    assert 0 < float(metrics.msssim_per_image(big, noisy)[0]) < 1
+    assert 0 < float(ref_metrics.msssim_per_image(big, noisy)[0]) < 1
 
 
 def test_ssim_against_a_direct_2d_gaussian_filter():
-    """tf.image.ssim restated twice: metrics.py filters separably; here the 11x11 sigma-1.5 window is applied as one 2-D
+    """tf.image.ssim restated twice: oracle/metrics.py filters separably; here the 11x11 sigma-1.5 window is applied as one 2-D
     VALID correlation (scipy.signal) and the SSIM map is formed from scratch."""
     from scipy.signal import correlate2d
-    from adunet_amd import metrics
     rng = np.random.default_rng(4)
     a = rng.random((2, 40, 37, 1))
     b = np.clip(a + 0.1 * rng.standard_normal(a.shape), 0, 1)
@@ -113,7 +116,7 @@ def test_ssim_against_a_direct_2d_gaussian_filter():
         vp, vq, cov = f(p * p) - mp * mp, f(q * q) - mq * mq, f(p * q) - mp * mq
         c1, c2 = 0.01 ** 2, 0.03 ** 2
         want.append((((2 * mp * mq + c1) * (2 * cov + c2)) / ((mp * mp + mq * mq + c1) * (vp + vq + c2))).mean())
-    assert np.allclose(metrics.ssim_per_image(a, b), np.asarray(want), atol=1e-6)
+    assert np.allclose(ref_metrics.ssim_per_image(a, b), np.asarray(want), atol=1e-6)
 
 
 # ----------------------------------------------------------------------------- ISIC data path of the segmentation trainer
