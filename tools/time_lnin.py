@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""LayerNorm on load (include/adunet.h): the pair `conv -> LN -> ReLU` (statistics only, no activation) followed by a conv whose
+loader waves re-derive the activation, against the pair that stores and re-reads it.  64 x 256^2, 64 -> 64, bf16 (VERDICT r04
+item 1's gate: pair <= 0.57 ms against 0.381 + 0.272).  Also checks the LN-in result against the stored-activation route."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from adunet_amd import ops
+
+dev = torch.device("cuda:0")
+dtype = {"bf16": torch.bfloat16, "f16": torch.float16}[sys.argv[1] if len(sys.argv) > 1 else "bf16"]
+n, hw, c = (int(sys.argv[2]) if len(sys.argv) > 2 else 64), 256, 64
+torch.manual_seed(0)
+x = torch.randn((n, hw, hw, c), device=dev).to(dtype)
+w1 = torch.randn((3, 3, c, c), device=dev) * 0.05
+w2 = torch.randn((3, 3, c, c), device=dev) * 0.05
+wf1, _ = ops.conv3x3_pack(w1, c, dtype)
+wf2, _ = ops.conv3x3_pack(w2, c, dtype)
+b = torch.randn(c, device=dev) * 0.1
+g1, b1 = 1 + 0.2 * torch.randn(c, device=dev), 0.2 * torch.randn(c, device=dev)
+g2, b2 = 1 + 0.2 * torch.randn(c, device=dev), 0.2 * torch.randn(c, device=dev)
+
+
+def timeit(fn, iters=100):
+    for _ in range(150):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
+# correctness: producer with / without activation, consumer on the stored activation / on LN-in
+z1, a1, m1, r1 = ops.conv3x3_ln_relu_fwd(x, None, wf1, b, g1, b1, c)
+z1s, none, m1s, r1s = ops.conv3x3_ln_relu_fwd(x, None, wf1, b, g1, b1, c, want_act=False)
+assert none is None and torch.equal(z1, z1s) and torch.equal(m1, m1s) and torch.equal(r1, r1s)
+ln = ops.LnIn(z1s, m1s, r1s, g1, b1)
+a_ref = ln.materialise()                      # ln_fwd_kernel on the STORED z with the same statistics? (it recomputes its own)
+za, aa, ma, ra = ops.conv3x3_ln_relu_fwd(a_ref, None, wf2, b, g2, b2, c)
+zl, al, ml, rl = ops.conv3x3_ln_relu_fwd(ln, None, wf2, b, g2, b2, c)
+d = (zl.float() - za.float()).abs().max().item()
+print(f"consumer z: max |LN-in - stored(ln_fwd_kernel on z)| = {d:.3e} (max |z| {za.float().abs().max().item():.2f}); "
+      f"bitwise equal: {torch.equal(zl, za)}")
+zf, _, _, _ = ops.conv3x3_ln_relu_fwd(a1, None, wf2, b, g2, b2, c)
+print(f"            max |LN-in - stored(fused epilogue's activation)| = {(zl.float() - zf.float()).abs().max().item():.3e}")
+zl2, none2, _, _ = ops.conv3x3_ln_relu_fwd(ln, None, wf2, b, g2, b2, c, want_act=False)
+assert none2 is None and torch.equal(zl2, zl)
+
+t_p2 = timeit(lambda: ops.conv3x3_ln_relu_fwd(x, None, wf1, b, g1, b1, c))
+t_p5 = timeit(lambda: ops.conv3x3_ln_relu_fwd(x, None, wf1, b, g1, b1, c, want_act=False))
+t_c0 = timeit(lambda: ops.conv3x3_fwd(a1, None, wf2, b, c))
+t_c2 = timeit(lambda: ops.conv3x3_ln_relu_fwd(a1, None, wf2, b, g2, b2, c))
+t_c5 = timeit(lambda: ops.conv3x3_ln_relu_fwd(a1, None, wf2, b, g2, b2, c, want_act=False))
+t_l2 = timeit(lambda: ops.conv3x3_ln_relu_fwd(ln, None, wf2, b, g2, b2, c))
+t_l5 = timeit(lambda: ops.conv3x3_ln_relu_fwd(ln, None, wf2, b, g2, b2, c, want_act=False))
+print(f"{dtype} n={n}")
+print(f"  producer  conv+LN+ReLU (z, a)        {t_p2:8.1f} us")
+print(f"  producer  conv+LN stats (z only)     {t_p5:8.1f} us")
+print(f"  consumer  plain conv on a            {t_c0:8.1f} us")
+print(f"  consumer  conv+LN+ReLU on a          {t_c2:8.1f} us      LN-in: {t_l2:8.1f} us")
+print(f"  consumer  conv+LN stats on a         {t_c5:8.1f} us      LN-in: {t_l5:8.1f} us")
+print(f"  chain link today  (z, a) -> conv+LN+ReLU (z, a): {t_p2:.1f} per layer;  new: stats producer + LN-in = {t_l5:.1f} per layer")
