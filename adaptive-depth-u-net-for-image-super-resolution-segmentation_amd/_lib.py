@@ -38,9 +38,6 @@ SIGNATURES = {
     "ad_conv3x3_ln_stats_is_fused": (_i, [_i, _i, _i, _i, _i, _i, _i]),
     "ad_conv3x3_ln_relu_fwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz,
                                     _i, _vp]),
-    "ad_conv3x3_lnin_supported": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i]),
-    "ad_conv3x3_ln_relu_fwd_lnin": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp,
-                                         _sz, _i, _vp]),
     "ad_conv3x3_dgrad_relu_is_fused": (_i, [_i, _i, _i, _i, _i, _i, _i]),
     "ad_conv3x3_dgrad_relu_ws_bytes": (_sz, []),
     "ad_conv3x3_dgrad_relu": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _i, _vp]),

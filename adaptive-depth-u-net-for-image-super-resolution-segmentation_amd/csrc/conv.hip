@@ -357,13 +357,6 @@ struct ConvArgs {
     // stored conv output (laid out like y1), ln_mean / ln_rstd / ln_gamma / ln_beta its statistics and parameters (inputs
     // here); y1 receives dz of that layer, dbias_part[workgroup][wave][3][64] the column sums for dgamma / dbeta / dbias
     const char* lnb_z;
-    // LayerNorm on load ("LN-in", ad_conv3x3_*_lnin): source k (0: x1, 1: x2; exactly 64 channels) is the stored conv output z of a
-    // Conv2D -> LayerNormalization -> ReLU layer whose activation was never written; the loader waves apply
-    // relu(gamma * (z - mean) * rstd + beta) to the 16-byte slots they move, with that layer's per-pixel statistics and parameters
-    const float* li_mean[2] = {nullptr, nullptr};
-    const float* li_rstd[2] = {nullptr, nullptr};
-    const float* li_gamma[2] = {nullptr, nullptr};
-    const float* li_beta[2] = {nullptr, nullptr};
     Geo g;
 };
 
@@ -712,34 +705,6 @@ __device__ __forceinline__ float sum_lane_groups(float v) {
     float s = a + b, c = s;
     asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(s), "+v"(c));
     return s + c;
-}
-
-// LayerNorm on load: one 16-byte slot (8 consecutive channels of a pixel) of a stored conv output z becomes the activation
-// relu(gamma * (z - mean) * rstd + beta) in the storage type, as ln_fwd_kernel computes it from the stored z: two packed fused
-// multiply-adds per channel pair, one v_cvt_pk, ReLU on the packed 16-bit pair (v_pk_max_i16 against 0).  A slot outside the image
-// arrives as zeros WITH rstd == 0 (out-of-range buffer loads; a real rstd is positive) and must stay zero -- the convolution's
-// padding pads the ACTIVATION, and relu(beta) is not zero.  ~28 VALU instructions per slot, in the loader waves.
-template <typename E>
-__device__ __forceinline__ u32x4 ln_in_apply(u32x4 z, float mean, float rstd, const f32x2 (&gm)[4], const f32x2 (&bt)[4]) {
-    typedef short s16x2 __attribute__((ext_vector_type(2)));
-    typedef E e16x2 __attribute__((ext_vector_type(2)));
-    const f32x2 r2 = {rstd, rstd}, nmr2 = {-mean * rstd, -mean * rstd};
-    u32x4 out;
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-        f32x2 v;
-        if constexpr (ad_same_type<E, bf16_t>::value) {
-            v = f32x2{__builtin_bit_cast(float, z[d] << 16), __builtin_bit_cast(float, z[d] & 0xffff0000u)};
-        } else {
-            v = __builtin_convertvector(__builtin_bit_cast(e16x2, z[d]), f32x2);
-        }
-        f32x2 y = __builtin_elementwise_fma(__builtin_elementwise_fma(v, r2, nmr2), gm[d], bt[d]);
-        asm volatile("" : "+v"(y));          // one v_cvt_pk per pair (see ws_pack_tile)
-        const e16x2 t = __builtin_convertvector(y, e16x2);
-        out[d] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, t), s16x2{0, 0}));
-    }
-    const bool in = rstd != 0.f;
-    return u32x4{in ? out[0] : 0u, in ? out[1] : 0u, in ? out[2] : 0u, in ? out[3] : 0u};
 }
 
 // XCD-aware work order of the wave-specialised forward kernels.  Workgroup b runs on XCD b % 8 (round-robin dispatch
@@ -1307,7 +1272,7 @@ __device__ __forceinline__ void ws_mma_role_lnb(const ConvArgs& a, const char* x
     }
 }
 
-template <typename P, int EPI, bool LNIN = false>
+template <typename P, int EPI>
 __global__ __launch_bounds__(WR_T, 1) void conv3x3_fwd_wres_kernel(ConvArgs a) {
     typedef typename P::T T;
     static_assert(sizeof(T) == 2, "the weights-resident kernel is the bf16 throughput path");
@@ -1362,24 +1327,6 @@ __global__ __launch_bounds__(WR_T, 1) void conv3x3_fwd_wres_kernel(ConvArgs a) {
         }
         const int lds_slot = (lt >> 2) * PIXB + part16;                  // + 64 i * PIXB
         int pix0, pix1, pix2, pix3, pix4, pix5;     // flat pixel index of each slot for the tile being fetched, or -1
-        // LNIN: x1 (64 channels: both chunks) is a stored conv output z; its statistics travel with the slots and the slots become
-        // activations on their way into LDS (ln_in_apply).  This thread's channels: (lt & 3) * 8 .. + 7 of each chunk.
-        f32x2 lgA[4], lbA[4], lgB[4], lbB[4];
-        float ma0 = 0.f, ma1 = 0.f, ma2 = 0.f, ma3 = 0.f, ma4 = 0.f, ma5 = 0.f, ra0 = 0.f, ra1 = 0.f, ra2 = 0.f, ra3 = 0.f, ra4 = 0.f, ra5 = 0.f;
-        float mb0 = 0.f, mb1 = 0.f, mb2 = 0.f, mb3 = 0.f, mb4 = 0.f, mb5 = 0.f, rb_0 = 0.f, rb_1 = 0.f, rb_2 = 0.f, rb_3 = 0.f, rb_4 = 0.f, rb_5 = 0.f;
-        const auto rsm = wave_uniform_rsrc(LNIN ? (const void*)a.li_mean[0] : (const void*)a.x1, LNIN ? npix * 4 : 0);
-        const auto rsr = wave_uniform_rsrc(LNIN ? (const void*)a.li_rstd[0] : (const void*)a.x1, LNIN ? npix * 4 : 0);
-        if constexpr (LNIN) {
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                lgA[d] = *reinterpret_cast<const f32x2*>(a.li_gamma[0] + (lt & 3) * 8 + 2 * d);
-                lbA[d] = *reinterpret_cast<const f32x2*>(a.li_beta[0] + (lt & 3) * 8 + 2 * d);
-                lgB[d] = *reinterpret_cast<const f32x2*>(a.li_gamma[0] + 32 + (lt & 3) * 8 + 2 * d);
-                lbB[d] = *reinterpret_cast<const f32x2*>(a.li_beta[0] + 32 + (lt & 3) * 8 + 2 * d);
-                // consumed here, so that the wait for them is placed before the loop and not (as vmcnt(0)) inside it
-                asm volatile("" : "+v"(lgA[d]), "+v"(lbA[d]), "+v"(lgB[d]), "+v"(lbB[d]));
-            }
-        }
 #define WR_PIX(I, NN, Y0, X0)                                                                    \
     {                                                                                            \
         const int y_ = (Y0) - 1 + (hyx[I] >> 8), x_ = (X0) - 1 + (hyx[I] & 255);                 \
@@ -1399,30 +1346,14 @@ __global__ __launch_bounds__(WR_T, 1) void conv3x3_fwd_wres_kernel(ConvArgs a) {
 #define WR_LD(RS, RB, OB, PIXV) \
     __builtin_amdgcn_raw_buffer_load_b128((RS), (PIXV) >= 0 ? (unsigned)((PIXV) * (RB) + (OB) + part16) : WR_OOB, 0, 0)
         u32x4 xa0, xa1, xa2, xa3, xa4, xa5, xb_0, xb_1, xb_2, xb_3, xb_4, xb_5;
-#define WR_SLD(RS, PIXV) \
-    __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32((RS), (PIXV) >= 0 ? (unsigned)((PIXV) * 4) : WR_OOB, 0, 0))
 #define WR_ISSUE_A                                                                               \
     xa0 = WR_LD(rs0, rb0, 0, pix0); xa1 = WR_LD(rs0, rb0, 0, pix1); xa2 = WR_LD(rs0, rb0, 0, pix2); \
     xa3 = WR_LD(rs0, rb0, 0, pix3); xa4 = WR_LD(rs0, rb0, 0, pix4); xa5 = WR_LD(rs0, rb0, 0, pix5); \
-    if constexpr (LNIN) {                                                                        \
-        ma0 = WR_SLD(rsm, pix0); ma1 = WR_SLD(rsm, pix1); ma2 = WR_SLD(rsm, pix2);               \
-        ma3 = WR_SLD(rsm, pix3); ma4 = WR_SLD(rsm, pix4); ma5 = WR_SLD(rsm, pix5);               \
-        ra0 = WR_SLD(rsr, pix0); ra1 = WR_SLD(rsr, pix1); ra2 = WR_SLD(rsr, pix2);               \
-        ra3 = WR_SLD(rsr, pix3); ra4 = WR_SLD(rsr, pix4); ra5 = WR_SLD(rsr, pix5);               \
-    }                                                                                            \
     asm volatile("" ::: "memory");
 #define WR_ISSUE_B                                                                               \
     xb_0 = WR_LD(rs1, rb1, ob1, pix0); xb_1 = WR_LD(rs1, rb1, ob1, pix1); xb_2 = WR_LD(rs1, rb1, ob1, pix2); \
     xb_3 = WR_LD(rs1, rb1, ob1, pix3); xb_4 = WR_LD(rs1, rb1, ob1, pix4); xb_5 = WR_LD(rs1, rb1, ob1, pix5); \
-    if constexpr (LNIN) {                                                                        \
-        mb0 = WR_SLD(rsm, pix0); mb1 = WR_SLD(rsm, pix1); mb2 = WR_SLD(rsm, pix2);               \
-        mb3 = WR_SLD(rsm, pix3); mb4 = WR_SLD(rsm, pix4); mb5 = WR_SLD(rsm, pix5);               \
-        rb_0 = WR_SLD(rsr, pix0); rb_1 = WR_SLD(rsr, pix1); rb_2 = WR_SLD(rsr, pix2);            \
-        rb_3 = WR_SLD(rsr, pix3); rb_4 = WR_SLD(rsr, pix4); rb_5 = WR_SLD(rsr, pix5);            \
-    }                                                                                            \
     asm volatile("" ::: "memory");
-#define WR_LNA(I) (LNIN ? ln_in_apply<T>(xa##I, ma##I, ra##I, lgA, lbA) : xa##I)
-#define WR_LNB(I) (LNIN ? ln_in_apply<T>(xb_##I, mb##I, rb_##I, lgB, lbB) : xb_##I)
 #define WR_STORE(XT, V0, V1, V2, V3, V4, V5)                                                     \
     *reinterpret_cast<u32x4*>((XT) + lds_slot) = V0;                                             \
     *reinterpret_cast<u32x4*>((XT) + lds_slot + 64 * PIXB) = V1;                                 \
@@ -1436,15 +1367,15 @@ __global__ __launch_bounds__(WR_T, 1) void conv3x3_fwd_wres_kernel(ConvArgs a) {
         WR_PIXELS(k)
         WR_ISSUE_A
         WR_ISSUE_B
-        WR_STORE(xb0, WR_LNA(0), WR_LNA(1), WR_LNA(2), WR_LNA(3), WR_LNA(4), WR_LNA(5))
+        WR_STORE(xb0, xa0, xa1, xa2, xa3, xa4, xa5)
         WR_PIXELS(k + 1)                             // pix* now describe item k + 1 until B(k + 1) has been issued
         WR_ISSUE_A
         for (; k < o.nloc; ++k) {
             lds_barrier();                           // B0: X0 = chunk 0 of this item is complete; X1 is free
-            WR_STORE(xb1, WR_LNB(0), WR_LNB(1), WR_LNB(2), WR_LNB(3), WR_LNB(4), WR_LNB(5))
+            WR_STORE(xb1, xb_0, xb_1, xb_2, xb_3, xb_4, xb_5)
             WR_ISSUE_B                               // chunk 1 of the next item
             lds_barrier();                           // B1: X1 complete; X0 is free
-            WR_STORE(xb0, WR_LNA(0), WR_LNA(1), WR_LNA(2), WR_LNA(3), WR_LNA(4), WR_LNA(5))
+            WR_STORE(xb0, xa0, xa1, xa2, xa3, xa4, xa5)
             WR_PIXELS(k + 2)
             WR_ISSUE_A                               // chunk 0 of the item after next
         }
@@ -1454,9 +1385,6 @@ __global__ __launch_bounds__(WR_T, 1) void conv3x3_fwd_wres_kernel(ConvArgs a) {
 #undef WR_ISSUE_A
 #undef WR_ISSUE_B
 #undef WR_STORE
-#undef WR_SLD
-#undef WR_LNA
-#undef WR_LNB
     } else {
         if constexpr (EPI == 4) ws_mma_role_lnb<P>(a, xb0, xb1, wt, wt + WT_BYTES, gb, wave, lane, o);
         else ws_mma_role<P, EPI>(a, xb0, xb1, wt, wt + WT_BYTES, gb, wave, lane, o, 2);
@@ -2801,8 +2729,6 @@ int launch_fwd_runs(ConvArgs a, void* ws, size_t ws_bytes, hipStream_t s) {
         if (a.y2) b.y2 = a.y2 + pix0 * (a.cout_real - a.cy1) * TSZ;
         if (a.a_out) b.a_out = a.a_out + pix0 * a.cout_real * TSZ;
         if (a.ln_mean) { b.ln_mean = a.ln_mean + pix0; b.ln_rstd = a.ln_rstd + pix0; }
-        for (int k = 0; k < 2; ++k)
-            if (a.li_mean[k]) { b.li_mean[k] = a.li_mean[k] + pix0; b.li_rstd[k] = a.li_rstd[k] + pix0; }
         pick_geo(b.n, b.h, b.w, &b.g);
         b.ntiles = b.g.tiles_x * b.g.tiles_y * b.g.tiles_i;
         const int rc = launch_fwd<P>(b, ws, ws_bytes, s);
@@ -2878,25 +2804,6 @@ int launch_fwd(ConvArgs a, void* ws, size_t ws_bytes, hipStream_t s) {
             if (kind != 1 || a.cout_real != BN) return AD_ERR_UNFUSED;
             conv3x3_fwd_wres_kernel<P, 4><<<NUM_CU, WR_T, WR_LDS, s>>>(a);
             AD_LAUNCH_CHECK("conv3x3_fwd_wres (layernorm-bwd)");
-            return AD_OK;
-        }
-        const bool lnin = a.li_mean[0] != nullptr || a.li_mean[1] != nullptr;
-        if (lnin) {
-            // LayerNorm on load exists where the producers that leave z + statistics feed: the weights-resident kernel with one
-            // 64-channel source and a LayerNorm epilogue (conv_block's second conv, the head's convs)
-            if (kind != 1 || a.c1 != BN || a.c2 != 0 || a.li_mean[1] != nullptr || a.cout_real != BN ||
-                (a.epilogue != AD_EPI_LN_RELU && a.epilogue != AD_EPI_LN_STATS))
-                return ad_set_error(AD_ERR_ARG, "conv3x3_fwd: no LayerNorm-on-load kernel for n=%d %dx%d c1=%d c2=%d cout=%d epilogue=%d "
-                                    "(ask ad_conv3x3_lnin_supported first)", a.n, a.h, a.w, a.c1, a.c2, a.cout_real, a.epilogue);
-            static bool li_attr = false;
-            if (!li_attr) {
-                allow_big_lds(conv3x3_fwd_wres_kernel<P, 2, true>);
-                allow_big_lds(conv3x3_fwd_wres_kernel<P, 5, true>);
-                li_attr = true;
-            }
-            if (a.epilogue == AD_EPI_LN_RELU) conv3x3_fwd_wres_kernel<P, 2, true><<<NUM_CU, WR_T, WR_LDS, s>>>(a);
-            else conv3x3_fwd_wres_kernel<P, 5, true><<<NUM_CU, WR_T, WR_LDS, s>>>(a);
-            AD_LAUNCH_CHECK("conv3x3_fwd_wres (layernorm on load)");
             return AD_OK;
         }
         if (a.epilogue == AD_EPI_LN_STATS) {
@@ -3147,48 +3054,10 @@ extern "C" int ad_conv3x3_ln_stats_is_fused(int n, int h, int w, int c1, int c2,
     return fwd_ws_kind(chunk, h, w, c1, c2, cout, true) == 1 && fwd_ws_kind(last, h, w, c1, c2, cout, true) == 1;
 }
 
-// LayerNorm on load for the forward kernels: 1 when (source x1 with ln1, x2 with ln2) has a kernel
-extern "C" int ad_conv3x3_lnin_supported(int n, int h, int w, int c1, int c2, int cout, int ln1, int ln2, int dtype) {
-    if (!ad_is_half(dtype) || !pixels_ok(n, h, w) || cout != BN || (!ln1 && !ln2)) return 0;
-    if (ln2 || c1 != BN || c2 != 0) return 0;
-    const int chunk = images_per_launch(n, h, w, c1, c2, cout, true, false);
-    const int last = n - (n - 1) / chunk * chunk;
-    return fwd_ws_kind(chunk, h, w, c1, c2, cout, true) == 1 && fwd_ws_kind(last, h, w, c1, c2, cout, true) == 1;
-}
-
-static int conv3x3_ln_relu_fwd_impl(const void* x1, int c1, const void* x2, int c2, const float* const* ln1, const float* const* ln2,
-                                    const void* w_packed, const float* bias, const float* gamma, const float* beta, float eps, void* z,
-                                    void* act, float* mean, float* rstd, int n, int h, int w, int cout, void* ws,
-                                    size_t ws_bytes, int dtype, void* stream);
-
 extern "C" int ad_conv3x3_ln_relu_fwd(const void* x1, int c1, const void* x2, int c2, const void* w_packed,
                                       const float* bias, const float* gamma, const float* beta, float eps, void* z,
                                       void* act, float* mean, float* rstd, int n, int h, int w, int cout, void* ws,
                                       size_t ws_bytes, int dtype, void* stream) {
-    return conv3x3_ln_relu_fwd_impl(x1, c1, x2, c2, nullptr, nullptr, w_packed, bias, gamma, beta, eps, z, act, mean, rstd, n, h, w,
-                                    cout, ws, ws_bytes, dtype, stream);
-}
-
-extern "C" int ad_conv3x3_ln_relu_fwd_lnin(const void* x1, int c1, const void* x2, int c2, const float* const* ln1,
-                                           const float* const* ln2, const void* w_packed, const float* bias, const float* gamma,
-                                           const float* beta, float eps, void* z, void* act, float* mean, float* rstd, int n,
-                                           int h, int w, int cout, void* ws, size_t ws_bytes, int dtype, void* stream) {
-    AD_REQUIRE(ln1 || ln2, "ad_conv3x3_ln_relu_fwd_lnin: neither source carries LayerNorm statistics (use ad_conv3x3_ln_relu_fwd)");
-    for (int k = 0; k < 2; ++k) {
-        const float* const* ln = k ? ln2 : ln1;
-        AD_REQUIRE(!ln || (ln[0] && ln[1] && ln[2] && ln[3]), "ad_conv3x3_ln_relu_fwd_lnin: ln%d needs {mean, rstd, gamma, beta}", k + 1);
-    }
-    AD_REQUIRE(ad_conv3x3_lnin_supported(n, h, w, c1, c2, cout, ln1 != nullptr, ln2 != nullptr, dtype),
-               "ad_conv3x3_ln_relu_fwd_lnin: no kernel for n=%d %dx%d c1=%d c2=%d cout=%d ln1=%d ln2=%d dtype=%d (ask "
-               "ad_conv3x3_lnin_supported first)", n, h, w, c1, c2, cout, ln1 != nullptr, ln2 != nullptr, dtype);
-    return conv3x3_ln_relu_fwd_impl(x1, c1, x2, c2, ln1, ln2, w_packed, bias, gamma, beta, eps, z, act, mean, rstd, n, h, w, cout,
-                                    ws, ws_bytes, dtype, stream);
-}
-
-static int conv3x3_ln_relu_fwd_impl(const void* x1, int c1, const void* x2, int c2, const float* const* ln1, const float* const* ln2,
-                                    const void* w_packed, const float* bias, const float* gamma, const float* beta, float eps, void* z,
-                                    void* act, float* mean, float* rstd, int n, int h, int w, int cout, void* ws,
-                                    size_t ws_bytes, int dtype, void* stream) {
     AD_REQUIRE(ad_dtype_ok(dtype), "ad_conv3x3_ln_relu_fwd: bad dtype %d", dtype);
     AD_REQUIRE(gamma && beta && z && mean && rstd, "ad_conv3x3_ln_relu_fwd: NULL LayerNorm operand");
     AD_REQUIRE(act || ad_conv3x3_ln_stats_is_fused(n, h, w, c1, c2, cout, dtype),
@@ -3209,10 +3078,6 @@ static int conv3x3_ln_relu_fwd_impl(const void* x1, int c1, const void* x2, int 
     a.ln_gamma = gamma; a.ln_beta = beta; a.ln_eps = eps;
     a.a_out = (char*)act; a.ln_mean = mean; a.ln_rstd = rstd;
     a.mask1 = nullptr; a.dbias_part = nullptr; a.lnb_z = nullptr;
-    for (int k = 0; k < 2; ++k) {
-        const float* const* ln = k ? ln2 : ln1;
-        if (ln) { a.li_mean[k] = ln[0]; a.li_rstd[k] = ln[1]; a.li_gamma[k] = ln[2]; a.li_beta[k] = ln[3]; }
-    }
     pick_geo(n, h, w, &a.g);
     a.ntiles = a.g.tiles_x * a.g.tiles_y * a.g.tiles_i;
     hipStream_t s = (hipStream_t)stream;

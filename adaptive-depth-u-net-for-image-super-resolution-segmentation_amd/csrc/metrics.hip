@@ -44,14 +44,16 @@ __global__ __launch_bounds__(256) void sqerr_kernel(const float* __restrict__ a,
     if (threadIdx.x == 0) part[(size_t)img * gridDim.x + blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
 }
 
-// out[img] = (sum of part[img][0..nb)) * scale, fixed order
-__global__ void rows_finish_kernel(const float* __restrict__ part, int nb, int ncol, float scale, float* __restrict__ out, int n) {
+// out[img] = (sum of part[img][0..nb)) / count, fixed order.  A true division (tf.reduce_mean divides): a sum of `count` ones
+// is exactly 1, which sum * (1 / count) is not -- the reference's degenerate row `inf, 1.0, 1.0, 0.0`
+// (exp1_depth3_scale0.20_eval/per_image_metrics.csv:1388) is reproduced exactly (tests/test_metrics_gpu.py).
+__global__ void rows_finish_kernel(const float* __restrict__ part, int nb, int ncol, float count, float* __restrict__ out, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;      // (img, col)
     if (i >= n * ncol) return;
     const int img = i / ncol, col = i - img * ncol;
     float s = 0.f;
     for (int k = 0; k < nb; ++k) s += part[((size_t)img * nb + k) * ncol + col];
-    out[i] = s * scale;
+    out[i] = s / count;
 }
 
 constexpr int ST_W = 32, ST_H = 8, SK = 11, SHW = ST_W + SK - 1, SHH = ST_H + SK - 1;
@@ -98,10 +100,16 @@ __global__ __launch_bounds__(256) void ssim_kernel(const float* __restrict__ a, 
 #pragma unroll
             for (int q = 0; q < 5; ++q) m[q] += g * hb[q][r + k][c];
         }
-        const float va = m[2] - m[0] * m[0], vb = m[3] - m[1] * m[1], cov = m[4] - m[0] * m[1];
-        const float lum = (2.f * m[0] * m[1] + c1) / (m[0] * m[0] + m[1] * m[1] + c1);
-        cs = (2.f * cov + c2) / (va + vb + c2);
-        ssim = lum * cs;
+        // tf.image.ssim's own arrangement (_ssim_helper), every product and sum rounded by itself (no fused multiply-add):
+        //   lum = (2 mu_a mu_b + c1) / (mu_a^2 + mu_b^2 + c1),  cs = (2 E[ab] - 2 mu_a mu_b + c2) / (E[a^2] + E[b^2] - mu_a^2 - mu_b^2 + c2)
+        // On identical planes numerator and denominator are then the SAME floats and both ratios are exactly 1, as TensorFlow
+        // reports for the all-black patch of the reference's evaluation; a contracted a*b+c rounds the two sides differently.
+        const float num0 = __fmul_rn(2.f, __fmul_rn(m[0], m[1]));
+        const float den0 = __fadd_rn(__fmul_rn(m[0], m[0]), __fmul_rn(m[1], m[1]));
+        const float lum = __fdiv_rn(__fadd_rn(num0, c1), __fadd_rn(den0, c1));
+        const float num1 = __fmul_rn(2.f, m[4]), den1 = __fadd_rn(m[2], m[3]);
+        cs = __fdiv_rn(__fadd_rn(__fsub_rn(num1, num0), c2), __fadd_rn(__fsub_rn(den1, den0), c2));
+        ssim = __fmul_rn(lum, cs);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { ssim += __shfl_xor(ssim, o, 64); cs += __shfl_xor(cs, o, 64); }
@@ -149,7 +157,7 @@ extern "C" int ad_mse_per_image(const float* a, const float* b, int n, int h, in
     if (!ws || ws_bytes < (size_t)n * nb * sizeof(float)) return ad_set_error(AD_ERR_WS, "ad_mse_per_image: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     sqerr_kernel<<<dim3(nb, n), 256, 0, s>>>(a, b, h, w, image_stride, row_stride, (float*)ws);
-    rows_finish_kernel<<<(n + 63) / 64, 64, 0, s>>>((const float*)ws, nb, 1, 1.0f / ((float)h * (float)w), mse, n);
+    rows_finish_kernel<<<(n + 63) / 64, 64, 0, s>>>((const float*)ws, nb, 1, (float)h * (float)w, mse, n);
     AD_LAUNCH_CHECK("ad_mse_per_image");
     return AD_OK;
 }
@@ -170,7 +178,7 @@ extern "C" int ad_ssim_per_image(const float* a, const float* b, int n, int h, i
     const float c1 = (0.01f * max_val) * (0.01f * max_val), c2 = (0.03f * max_val) * (0.03f * max_val);
     hipStream_t s = (hipStream_t)stream;
     ssim_kernel<<<dim3(tiles, n), 256, 0, s>>>(a, b, h, w, image_stride, row_stride, gk, c1, c2, (float*)ws, tiles_x);
-    rows_finish_kernel<<<(2 * n + 63) / 64, 64, 0, s>>>((const float*)ws, tiles, 2, 1.0f / ((float)oh * (float)ow), ssim_cs, n);
+    rows_finish_kernel<<<(2 * n + 63) / 64, 64, 0, s>>>((const float*)ws, tiles, 2, (float)oh * (float)ow, ssim_cs, n);
     AD_LAUNCH_CHECK("ad_ssim_per_image");
     return AD_OK;
 }

@@ -266,48 +266,13 @@ def conv3x3_ln_stats_is_fused(x1: torch.Tensor, x2: Optional[torch.Tensor], cout
     return bool(_lib.load().ad_conv3x3_ln_stats_is_fused(n, h, w, c1, c2, cout, dt(x1.dtype)))
 
 
-class LnIn:
-    """A Conv2D -> LayerNormalization -> ReLU output that was never stored (include/adunet.h, "LayerNorm on load"): the
-    layer's conv output z, its per-pixel statistics and its parameters.  Consumers pass it where they took the activation
-    tensor; `materialise()` writes the activation with the LayerNorm kernel for a consumer that has no LN-in kernel."""
-    __slots__ = ("z", "mean", "rstd", "gamma", "beta", "eps")
-
-    def __init__(self, z, mean, rstd, gamma, beta, eps=LN_EPS):
-        self.z, self.mean, self.rstd, self.gamma, self.beta, self.eps = z, mean, rstd, gamma, beta, eps
-
-    @property
-    def shape(self):
-        return self.z.shape
-
-    @property
-    def dtype(self):
-        return self.z.dtype
-
-    def ptrs(self):
-        import ctypes as C
-        return (C.c_void_p * 4)(_p(self.mean), _p(self.rstd), _p(self.gamma), _p(self.beta))
-
-    def materialise(self) -> torch.Tensor:
-        return layernorm_relu_fwd(self.z, self.gamma, self.beta, eps=self.eps)[0]
-
-
-def conv3x3_lnin_supported(x1, x2, cout: int) -> bool:
-    """Whether conv3x3_ln_relu_fwd takes these sources as they are (LnIn sources un-materialised)."""
-    n, h, w, c1 = x1.shape
-    c2 = x2.shape[-1] if x2 is not None else 0
-    return bool(_lib.load().ad_conv3x3_lnin_supported(n, h, w, c1, c2, cout, isinstance(x1, LnIn), isinstance(x2, LnIn), dt(x1.dtype)))
-
-
-def conv3x3_ln_relu_fwd(x1, x2: Optional[torch.Tensor], w_packed: torch.Tensor, bias: Optional[torch.Tensor],
+def conv3x3_ln_relu_fwd(x1: torch.Tensor, x2: Optional[torch.Tensor], w_packed: torch.Tensor, bias: Optional[torch.Tensor],
                         gamma: torch.Tensor, beta: torch.Tensor, cout: int, eps: float = LN_EPS, want_act: bool = True):
     """conv_block's Conv2D -> LayerNormalization -> ReLU.  Returns (z, act, mean, rstd): z is the conv output kept for
     the backward pass.  One launch where the library has the fused epilogue (cout == 64, large bf16 launches), else
     the library runs the convolution and the LayerNorm kernel back to back.
-    want_act=False (conv3x3_ln_stats_is_fused must hold): the activation is not written, act is None -- the consumers
-    re-derive it from z (head_ln_bwd; the LN-in loaders of the next convolution and of the weight gradient).
-    x1 / x2 may be `LnIn` (conv3x3_lnin_supported must hold): that source's activation is re-derived on load."""
-    if isinstance(x1, LnIn) or isinstance(x2, LnIn):
-        return _conv3x3_ln_relu_fwd_lnin(x1, x2, w_packed, bias, gamma, beta, cout, eps, want_act)
+    want_act=False (conv3x3_ln_stats_is_fused must hold): the activation is not written, act is None -- for the layer in
+    front of the head in a train step, whose only consumer (head_ln_bwd) re-derives it from z."""
     n, h, w, c1 = x1.shape
     c2 = x2.shape[-1] if x2 is not None else 0
     if not want_act:
@@ -340,26 +305,6 @@ def conv3x3_ln_relu_fwd(x1, x2: Optional[torch.Tensor], w_packed: torch.Tensor, 
                                          _p(z), _p(act), _p(mean), _p(rstd), n, h, w, cout,
                                          ws.ptr if ws else None, ws.nbytes if ws else 0, dt(x1.dtype), _stream()),
               "ad_conv3x3_ln_relu_fwd")
-    return z, act, mean, rstd
-
-
-def _conv3x3_ln_relu_fwd_lnin(x1, x2, w_packed, bias, gamma, beta, cout, eps, want_act):
-    ln1 = x1 if isinstance(x1, LnIn) else None
-    ln2 = x2 if isinstance(x2, LnIn) else None
-    t1 = ln1.z if ln1 else x1
-    t2 = ln2.z if ln2 else x2
-    n, h, w, c1 = t1.shape
-    c2 = t2.shape[-1] if t2 is not None else 0
-    z = torch.empty((n, h, w, cout), dtype=t1.dtype, device=t1.device)
-    act = torch.empty_like(z) if want_act else None
-    mean = torch.empty(n * h * w, dtype=torch.float32, device=t1.device)
-    rstd = torch.empty(n * h * w, dtype=torch.float32, device=t1.device)
-    p1, p2 = (ln1.ptrs() if ln1 else None), (ln2.ptrs() if ln2 else None)
-    with _timed("conv3x3_ln_relu_fwd", 2.0 * n * h * w * 9 * (c1 + c2) * cout,
-                float(n * h * w * ((c1 + c2 + (2 if want_act else 1) * cout) * t1.element_size() + 8 + 8 * (bool(ln1) + bool(ln2))))):
-        check(_lib.load().ad_conv3x3_ln_relu_fwd_lnin(_p(t1), c1, _p(t2), c2, p1, p2, _p(w_packed), _p(bias), _p(gamma), _p(beta), eps,
-                                                      _p(z), _p(act), _p(mean), _p(rstd), n, h, w, cout, None, 0, dt(t1.dtype),
-                                                      _stream()), "ad_conv3x3_ln_relu_fwd_lnin")
     return z, act, mean, rstd
 
 

@@ -146,24 +146,6 @@ int ad_conv3x3_ln_relu_fwd(const void* x1, int c1, const void* x2, int c2,
                            int n, int h, int w, int cout,
                            void* ws, size_t ws_bytes, int dtype, void* stream);
 
-/* LayerNorm on load ("LN-in").  A conv_block layer whose activation a = relu(gamma * (z - mean) * rstd + beta) is only ever
- * read by convolutions (train_adaptive_unet.py:200-210: conv -> LN -> ReLU -> conv ...) need not store it: the producer
- * leaves z and the per-pixel statistics (ad_conv3x3_ln_relu_fwd / ad_conv3x3_c3_ln_relu_fwd with act == NULL) and every
- * consumer re-derives a -- rounded to the storage type exactly as ad_layernorm_relu_fwd rounds it -- in its loader waves,
- * on the 16-byte slots it moves from HBM to LDS anyway.  One store stream of 128 B per pixel and the normalisation
- * arithmetic leave the producer's MFMA waves; the consumers read z where they read a before (+ 8 B of statistics per pixel).
- * lnK (K = 1: source x1, K = 2: source x2) = {mean[npix], rstd[npix], gamma[cK], beta[cK]} of the layer that produced
- * source K as z, or NULL when source K is an ordinary activation.  An LN-in source has exactly 64 channels (the fused
- * producers have cout == 64).  ad_conv3x3_lnin_supported / ad_conv3x3_wgrad_lnin_supported tell whether a shape has such
- * a kernel; the caller stores the activation (act != NULL) where they do not. */
-int ad_conv3x3_lnin_supported(int n, int h, int w, int c1, int c2, int cout, int ln1, int ln2, int dtype);
-int ad_conv3x3_ln_relu_fwd_lnin(const void* x1, int c1, const void* x2, int c2,
-                                const float* const* ln1, const float* const* ln2,
-                                const void* w_packed, const float* bias, const float* gamma, const float* beta, float eps,
-                                void* z, void* act, float* mean, float* rstd,
-                                int n, int h, int w, int cout,
-                                void* ws, size_t ws_bytes, int dtype, void* stream);
-
 /* The network's first conv_block step -- L.Conv2D(base_channels, 3, padding="same") on the 3-channel input followed
  * by LayerNormalization and ReLU (train_adaptive_unet.py:202-204 with inputs of :225) -- and its weight gradient,
  * without the zero-padded copy of the input: x is the raw [n, h, w, 3] fp32 batch, w_hwio the fp32 master kernel
