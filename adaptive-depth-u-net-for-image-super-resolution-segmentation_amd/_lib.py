@@ -69,6 +69,9 @@ SIGNATURES = {
     "ad_cast": (_i, [_vp, _i, _vp, _i, _i64, _vp]),
     "ad_batchnorm_ws_bytes": (_sz, [_i]),
     "ad_batchnorm_relu_fwd_train": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i64, _i, _f, _i, _vp, _sz, _i, _vp]),
+    "ad_batchnorm_relu_pool_fwd_train": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _f, _i, _vp, _sz,
+                                              _i, _vp]),
+    "ad_batchnorm_relu_bwd_dbias": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _sz, _i, _vp]),
     "ad_batchnorm_relu_fwd_infer": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _i, _i, _vp]),
     "ad_batchnorm_relu_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _sz, _i, _vp]),
     "ad_colsum": (_i, [_vp, _vp, _i64, _i, _vp, _sz, _i, _vp]),

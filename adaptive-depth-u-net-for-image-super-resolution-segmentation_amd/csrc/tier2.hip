@@ -11,7 +11,11 @@ constexpr int NBLK = 512;   // blocks of the column-reduction kernels (partials 
 
 // ------------------------------------------------------------------ per-channel column statistics
 // part[block][2][c] = { sum_p (x[p][ch] - shift[ch]), sum_p (x[p][ch] - shift[ch])^2 }
-template <typename T>
+// FIRST: shift[ch] = x[0][ch], the first pixel's value (r05).  Both moments then come out of ONE pass over x without the
+// cancellation of E[x^2] - mean^2: var = E[(x - s)^2] - (E[x - s])^2 loses (mean - s)^2 / var * 2^-24 of the variance, and a
+// sample of the channel lies a few standard deviations from its mean whatever the mean's offset is (the r04 defect of the
+// fused LayerNorm epilogue was the UNSHIFTED form at mean / std = 1 000).  Until r04: two passes (mean, then centred moment).
+template <typename T, bool FIRST = false>
 __global__ __launch_bounds__(256) void colstats_kernel(const T* __restrict__ x, const float* __restrict__ shift,
                                                        float* __restrict__ part, int64_t npix, int c, int ld) {
     constexpr int EPT = ElemTraits<T>::EPT;
@@ -25,6 +29,11 @@ __global__ __launch_bounds__(256) void colstats_kernel(const T* __restrict__ x, 
     const int64_t ldx = ld;                       // row stride in elements (>= c: the launch may cover a channel slice)
 #pragma unroll
     for (int e = 0; e < EPT; ++e) { s1[e] = s2[e] = 0.f; sh[e] = shift ? shift[v * EPT + e] : 0.f; }
+    if (FIRST && r < rows) {
+        Vec16<T> l0;
+        l0.load(x + v * EPT);
+        l0.to_f32(sh);
+    }
     if (r < rows)
         for (int64_t p = (int64_t)blockIdx.x * rows + r; p < npix; p += (int64_t)gridDim.x * rows) {
             Vec16<T> ld;
@@ -72,6 +81,42 @@ __global__ __launch_bounds__(256) void colstats_finish_kernel(const float* __res
     }
 }
 
+// One-pass BatchNorm statistics: folds the [nblocks][2][c] partials of colstats_kernel<T, true> in the fixed order of
+// colstats_finish_kernel (64 row groups, then a serial sum of the 64), then mean = x0 + S1 / m, var = S2 / m - (S1 / m)^2,
+// rstd and the Keras moving averages.  One block per 2 channels (both moments of a channel meet in one block).
+template <typename T>
+__global__ __launch_bounds__(256) void bn_stats_finish_kernel(const float* __restrict__ part, int nblocks, int c, float inv_m,
+                                                              const T* __restrict__ x0, float* __restrict__ mean,
+                                                              float* __restrict__ var, float* __restrict__ rstd,
+                                                              float* __restrict__ mmean, float* __restrict__ mvar,
+                                                              float momentum, float eps) {
+    __shared__ float sm[64][5];
+    const int tid = threadIdx.x, cl = tid & 3, rg = tid >> 2;
+    const int ch = blockIdx.x * 2 + (cl & 1);
+    const int i = (cl >> 1) * c + ch;                  // column of the [nblocks][2c] partial matrix: moment cl >> 1 of channel ch
+    float s = 0.f;
+    if (ch < c)
+        for (int b = rg; b < nblocks; b += 64) s += part[(size_t)b * 2 * c + i];
+    sm[rg][cl] = s;
+    __syncthreads();
+    if (rg == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 64; ++r) t += sm[r][cl];
+        sm[0][cl] = t;
+    }
+    __syncthreads();
+    if (tid < 2 && blockIdx.x * 2 + tid < c) {
+        const int k = blockIdx.x * 2 + tid;
+        const float d1 = sm[0][tid] * inv_m, d2 = sm[0][2 + tid] * inv_m;
+        const float mu = (float)x0[k] + d1;
+        const float vv = fmaxf(d2 - d1 * d1, 0.f);
+        mean[k] = mu; var[k] = vv; rstd[k] = rsqrtf(vv + eps);
+        if (mmean) mmean[k] = mmean[k] * momentum + mu * (1.f - momentum);
+        if (mvar) mvar[k] = mvar[k] * momentum + vv * (1.f - momentum);
+    }
+}
+
 // rstd = rsqrt(var + eps); moving <- moving * m + batch * (1 - m)   (Keras BatchNormalization, momentum 0.99)
 __global__ void bn_finalize_kernel(const float* __restrict__ mean, const float* __restrict__ var, float* __restrict__ rstd,
                                    float* __restrict__ mmean, float* __restrict__ mvar, float momentum, float eps, int c) {
@@ -112,6 +157,58 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
         }
         st.from_f32(o);
         st.store(y + off);
+    }
+}
+
+// bn_apply_kernel over 2 x 2 windows: writes the activation y AND its MaxPooling2D(2) (the encoder's conv_block ->
+// MaxPooling2D, Segmenation/code/train_adaptive_unet.py:349-351) in one pass, so the pooling never re-reads y.  The maximum is
+// taken of the ROUNDED activations (what a separate pooling kernel would read).  h, w even.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_pool_kernel(const T* __restrict__ x, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, T* __restrict__ y,
+                                                            T* __restrict__ pooled, int n, int h, int w, int c, int relu) {
+    constexpr int EPT = ElemTraits<T>::EPT;
+    const int vecs = c / EPT, oh = h / 2, ow = w / 2;
+    const int64_t total = (int64_t)n * oh * ow * vecs;
+    const int v = (int)(((int64_t)blockIdx.x * 256 + threadIdx.x) % vecs);
+    float mu[EPT], rs[EPT], ga[EPT], be[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int ch = v * EPT + e;
+        mu[e] = mean[ch]; rs[e] = rstd[ch]; ga[e] = gamma[ch]; be[e] = beta[ch];
+    }
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t p = i / vecs;
+        const int ox = (int)(p % ow);
+        const int64_t r = p / ow;
+        const int oy = (int)(r % oh), nn = (int)(r / oh);
+        Vec16<T> in[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            in[k].load(x + (((int64_t)nn * h + 2 * oy + (k >> 1)) * w + 2 * ox + (k & 1)) * c + v * EPT);
+        float m[EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) m[e] = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float f[EPT], o[EPT];
+            in[k].to_f32(f);
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) {
+                const float t = (f[e] - mu[e]) * rs[e] * ga[e] + be[e];
+                o[e] = relu ? fmaxf(t, 0.f) : t;
+            }
+            Vec16<T> st;
+            st.from_f32(o);
+            st.store(y + (((int64_t)nn * h + 2 * oy + (k >> 1)) * w + 2 * ox + (k & 1)) * c + v * EPT);
+            st.to_f32(o);
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) m[e] = fmaxf(m[e], o[e]);
+        }
+        Vec16<T> sp;
+        sp.from_f32(m);
+        sp.store(pooled + p * c + v * EPT);
     }
 }
 
@@ -166,13 +263,20 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
 }
 
 // backward pass 2: dx = gamma * rstd * (dyl - dbeta/m - xhat * dgamma/m); per-thread channel parameters as bn_apply_kernel
-template <typename T>
+// COLSUM (r05): dsum_part[block][c] = column sums of dx AS STORED (the BiasAddGrad of the convolution in front, which until r04
+// was a separate ad_colsum pass over dx): a thread always sees the same EPT channels, so its sums stay in registers and the
+// block folds the threads of a channel vector through LDS in a fixed order.
+template <typename T, bool COLSUM = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            const float* __restrict__ dgamma, const float* __restrict__ dbeta,
-                                                           T* __restrict__ dx, int64_t npix, int c, int relu, int ld) {
+                                                           T* __restrict__ dx, int64_t npix, int c, int relu, int ld,
+                                                           float* __restrict__ dsum_part = nullptr) {
     constexpr int EPT = ElemTraits<T>::EPT;
+    float acc[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) acc[e] = 0.f;
     const int vecs = c / EPT;
     const int64_t total = npix * vecs;
     const float inv_m = 1.0f / (float)npix;
@@ -200,6 +304,42 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         }
         st.from_f32(o);
         st.store(dx + off);
+        if constexpr (COLSUM) {
+            st.to_f32(o);
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) acc[e] += o[e];
+        }
+    }
+    if constexpr (COLSUM) {
+        __shared__ float red[256 * EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) red[threadIdx.x * EPT + e] = acc[e];
+        __syncthreads();
+        // threads t with t % vecs == v hold channel vector v (256 % vecs == 0: chan_ok)
+        for (int ch = threadIdx.x; ch < c; ch += 256) {
+            const int vv = ch / EPT, e = ch - vv * EPT;
+            float t = 0.f;
+            for (int q = vv; q < 256; q += vecs) t += red[q * EPT + e];
+            dsum_part[(size_t)blockIdx.x * c + ch] = t;
+        }
+    }
+}
+
+// out[ch] = sum_b part[b][ch], fixed order (64 row groups, then a serial sum): the dbias partials of bn_bwd_apply_kernel
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, int nblocks, int c, float* __restrict__ out) {
+    __shared__ float sm[64][5];
+    const int tid = threadIdx.x, cl = tid & 3, rg = tid >> 2;
+    const int i = blockIdx.x * 4 + cl;
+    float s = 0.f;
+    if (i < c)
+        for (int b = rg; b < nblocks; b += 64) s += part[(size_t)b * c + i];
+    sm[rg][cl] = s;
+    __syncthreads();
+    if (rg == 0 && i < c) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 64; ++r) t += sm[r][cl];
+        out[i] = t;
     }
 }
 
@@ -434,6 +574,25 @@ __global__ void rows_sum_kernel(const float* __restrict__ part, int nrows, int n
     if (i < n0) o0[i] = s; else o1[i - n0] = s;
 }
 
+// rows_sum_kernel with 64 row groups per column (fixed order: deterministic)
+__global__ __launch_bounds__(256) void rows_sum_par_kernel(const float* __restrict__ part, int nrows, int ncols, float* __restrict__ o0,
+                                                           int n0, float* __restrict__ o1) {
+    __shared__ float sm[64][5];
+    const int tid = threadIdx.x, cl = tid & 3, rg = tid >> 2;
+    const int i = blockIdx.x * 4 + cl;
+    float s = 0.f;
+    if (i < ncols)
+        for (int r = rg; r < nrows; r += 64) s += part[(size_t)r * ncols + i];
+    sm[rg][cl] = s;
+    __syncthreads();
+    if (rg == 0 && i < ncols) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 64; ++r) t += sm[r][cl];
+        if (i < n0) o0[i] = t; else o1[i - n0] = t;
+    }
+}
+
 static int ew_blocks(int64_t total) {
     int64_t b = (total + 255) / 256;
     return (int)(b < 16384 ? b : 16384);
@@ -462,28 +621,35 @@ int colstats(const void* x, const float* shift, float* part, int64_t npix, int c
     return AD_OK;
 }
 
+// pool_{n,h,w} > 0 (whole-width launches only: ld == c): the activation's MaxPooling2D(2) is written to `pooled` in the same pass
 template <typename T>
 int bn_fwd_train(const T* z, const float* gamma, const float* beta, T* y, float* save_mean, float* save_rstd, float* save_var,
                  float* moving_mean, float* moving_var, float momentum, int64_t npix, int c, int ld, float eps, int relu,
-                 float* part, hipStream_t s) {
+                 float* part, hipStream_t s, T* pooled = nullptr, int pool_n = 0, int pool_h = 0, int pool_w = 0) {
     int nb = 0;
-    // pass 1: mean; pass 2: centred second moment (biased variance, as Keras)
-    int rc = colstats<T>(z, nullptr, part, npix, c, ld, s, &nb);
-    if (rc) return rc;
-    colstats_finish_kernel<<<(2 * c + 3) / 4, 256, 0, s>>>(part, nb, c, 1.0f / (float)npix, 0.f, nullptr, save_mean, nullptr);
-    rc = colstats<T>(z, save_mean, part, npix, c, ld, s, &nb);
-    if (rc) return rc;
-    colstats_finish_kernel<<<(2 * c + 3) / 4, 256, 0, s>>>(part, nb, c, 0.f, 1.0f / (float)npix, nullptr, nullptr, save_var);
-    bn_finalize_kernel<<<(c + 255) / 256, 256, 0, s>>>(save_mean, save_var, save_rstd, moving_mean, moving_var, momentum, eps, c);
-    bn_apply_kernel<T><<<ew_blocks(npix * (c / ElemTraits<T>::EPT)), 256, 0, s>>>(z, save_mean, save_rstd, gamma, beta, y, npix,
-                                                                                   c, relu, ld);
+    // ONE pass over z for both moments: deviations from the first pixel's row (colstats_kernel<T, true>), biased variance as Keras
+    const int vecs = c / ElemTraits<T>::EPT;
+    const int rows = 256 / vecs > 0 ? 256 / vecs : 1;
+    int64_t nbl = (npix + rows - 1) / rows;
+    nb = (int)(nbl < NBLK ? nbl : NBLK);
+    size_t lds = (size_t)rows * 2 * c * sizeof(float);
+    if (lds > 64 * 1024) return ad_set_error(AD_ERR_ARG, "batchnorm: c=%d too wide", c);
+    colstats_kernel<T, true><<<nb, 256, lds, s>>>(z, nullptr, part, npix, c, ld);
+    bn_stats_finish_kernel<T><<<(c + 1) / 2, 256, 0, s>>>(part, nb, c, 1.0f / (float)npix, z, save_mean, save_var, save_rstd,
+                                                         moving_mean, moving_var, momentum, eps);
+    if (pooled)
+        bn_apply_pool_kernel<T><<<ew_blocks((int64_t)pool_n * (pool_h / 2) * (pool_w / 2) * vecs), 256, 0, s>>>(
+            z, save_mean, save_rstd, gamma, beta, y, pooled, pool_n, pool_h, pool_w, c, relu);
+    else
+        bn_apply_kernel<T><<<ew_blocks(npix * vecs), 256, 0, s>>>(z, save_mean, save_rstd, gamma, beta, y, npix, c, relu, ld);
     AD_LAUNCH_CHECK("ad_batchnorm_relu_fwd_train");
     return AD_OK;
 }
 
 template <typename T>
 int bn_bwd(const T* dy, const T* z, const float* save_mean, const float* save_rstd, const float* gamma, const float* beta,
-           T* dz, float* dgamma, float* dbeta, int64_t npix, int c, int ld, int relu, float* part, hipStream_t s) {
+           T* dz, float* dgamma, float* dbeta, int64_t npix, int c, int ld, int relu, float* part, hipStream_t s,
+           float* dbias = nullptr) {
     const int vecs = c / ElemTraits<T>::EPT;
     const int rows = 256 / vecs > 0 ? 256 / vecs : 1;
     int64_t nbl = (npix + rows - 1) / rows;
@@ -491,8 +657,17 @@ int bn_bwd(const T* dy, const T* z, const float* save_mean, const float* save_rs
     size_t lds = (size_t)rows * 2 * c * sizeof(float);
     bn_bwd_reduce_kernel<T><<<nb, 256, lds, s>>>(dy, z, save_mean, save_rstd, gamma, beta, part, npix, c, relu, ld);
     colstats_finish_kernel<<<(2 * c + 3) / 4, 256, 0, s>>>(part, nb, c, 1.f, 1.f, nullptr, dgamma, dbeta);
-    bn_bwd_apply_kernel<T><<<ew_blocks(npix * vecs), 256, 0, s>>>(dy, z, save_mean, save_rstd, gamma, beta, dgamma, dbeta, dz, npix,
-                                                                  c, relu, ld);
+    if (dbias) {
+        // the partials of the reduce above have been folded: the workspace now takes [blocks][c] column sums of dz as stored
+        int64_t bl = (npix * vecs + 255) / 256;
+        const int nba = (int)(bl < 2 * NBLK ? bl : 2 * NBLK);
+        bn_bwd_apply_kernel<T, true><<<nba, 256, 0, s>>>(dy, z, save_mean, save_rstd, gamma, beta, dgamma, dbeta, dz, npix, c, relu,
+                                                         ld, part);
+        colsum_finish_kernel<<<(c + 3) / 4, 256, 0, s>>>(part, nba, c, dbias);
+    } else {
+        bn_bwd_apply_kernel<T><<<ew_blocks(npix * vecs), 256, 0, s>>>(dy, z, save_mean, save_rstd, gamma, beta, dgamma, dbeta, dz,
+                                                                      npix, c, relu, ld);
+    }
     AD_LAUNCH_CHECK("ad_batchnorm_relu_bwd");
     return AD_OK;
 }
@@ -522,6 +697,24 @@ extern "C" int ad_batchnorm_relu_fwd_train(const void* z, const float* gamma, co
     return AD_OK;
 }
 
+extern "C" int ad_batchnorm_relu_pool_fwd_train(const void* z, const float* gamma, const float* beta, void* y, void* pooled,
+                                                float* save_mean, float* save_rstd, float* save_var, float* moving_mean,
+                                                float* moving_var, float momentum, int n, int h, int w, int c, float eps,
+                                                int relu, void* ws, size_t ws_bytes, int dtype, void* stream) {
+    AD_REQUIRE(ad_dtype_ok(dtype), "ad_batchnorm_relu_pool_fwd_train: bad dtype %d", dtype);
+    const int ept = ad_is_half(dtype) ? 8 : 4;
+    AD_REQUIRE(n > 0 && h >= 2 && w >= 2 && h % 2 == 0 && w % 2 == 0 && pooled, "ad_batchnorm_relu_pool_fwd_train: bad shape n=%d %dx%d", n, h, w);
+    const int64_t npix = (int64_t)n * h * w;
+    AD_REQUIRE(chan_ok(c, ept) && c / ept <= 256, "ad_batchnorm_relu_pool_fwd_train: unsupported c=%d (at most %d channels)", c, 256 * ept);
+    if (!ws || ws_bytes < ad_batchnorm_ws_bytes(c)) return ad_set_error(AD_ERR_WS, "ad_batchnorm: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    int rc = AD_OK;
+    AD_DISPATCH_DTYPE(dtype, T_,
+        rc = bn_fwd_train<T_>((const T_*)z, gamma, beta, (T_*)y, save_mean, save_rstd, save_var, moving_mean, moving_var, momentum,
+                              npix, c, c, eps, relu, (float*)ws, s, (T_*)pooled, n, h, w);)
+    return rc;
+}
+
 extern "C" int ad_batchnorm_relu_fwd_infer(const void* z, const float* gamma, const float* beta, const float* moving_mean,
                                            const float* moving_var, void* y, float* rstd_tmp, int64_t npix, int c, float eps,
                                            int relu, int dtype, void* stream) {
@@ -540,9 +733,22 @@ extern "C" int ad_batchnorm_relu_fwd_infer(const void* z, const float* gamma, co
     return AD_OK;
 }
 
+extern "C" int ad_batchnorm_relu_bwd_dbias(const void* dy, const void* z, const float* save_mean, const float* save_rstd,
+                                           const float* gamma, const float* beta, void* dz, float* dgamma, float* dbeta,
+                                           float* dbias, int64_t npix, int c, int relu, void* ws, size_t ws_bytes, int dtype,
+                                           void* stream);
+
 extern "C" int ad_batchnorm_relu_bwd(const void* dy, const void* z, const float* save_mean, const float* save_rstd,
                                      const float* gamma, const float* beta, void* dz, float* dgamma, float* dbeta,
                                      int64_t npix, int c, int relu, void* ws, size_t ws_bytes, int dtype, void* stream) {
+    return ad_batchnorm_relu_bwd_dbias(dy, z, save_mean, save_rstd, gamma, beta, dz, dgamma, dbeta, nullptr, npix, c, relu, ws,
+                                       ws_bytes, dtype, stream);
+}
+
+extern "C" int ad_batchnorm_relu_bwd_dbias(const void* dy, const void* z, const float* save_mean, const float* save_rstd,
+                                           const float* gamma, const float* beta, void* dz, float* dgamma, float* dbeta,
+                                           float* dbias, int64_t npix, int c, int relu, void* ws, size_t ws_bytes, int dtype,
+                                           void* stream) {
     AD_REQUIRE(ad_dtype_ok(dtype), "ad_batchnorm_relu_bwd: bad dtype %d", dtype);
     const int ept = ad_is_half(dtype) ? 8 : 4;
     AD_REQUIRE(npix > 0 && chan_ok(c, ept), "ad_batchnorm_relu_bwd: unsupported npix=%ld c=%d", (long)npix, c);
@@ -553,7 +759,7 @@ extern "C" int ad_batchnorm_relu_bwd(const void* dy, const void* z, const float*
         int rc = AD_OK;
         AD_DISPATCH_DTYPE(dtype, T_,
             rc = bn_bwd<T_>((const T_*)dy + c0, (const T_*)z + c0, save_mean + c0, save_rstd + c0, gamma + c0, beta + c0,
-                            (T_*)dz + c0, dgamma + c0, dbeta + c0, npix, cs, c, relu, (float*)ws, s);)
+                            (T_*)dz + c0, dgamma + c0, dbeta + c0, npix, cs, c, relu, (float*)ws, s, dbias ? dbias + c0 : nullptr);)
         if (rc) return rc;
     }
     return AD_OK;
@@ -728,7 +934,8 @@ extern "C" int ad_seg_head_bwd(const void* xh, const float* w, const float* targ
         SEG_DISPATCH(seg_head_bwd_kernel<T_, G_><<<grid, 256, lds, s>>>((const T_*)xh, w, target, prob, sums, (T_*)dxh, (float*)ws,
                                                                         pix_per_img, ch, n, bce_weight, dice_weight, smooth, loss_scale);))
     AD_LAUNCH_CHECK("ad_seg_head_bwd");
-    rows_sum_kernel<<<(ncol + 255) / 256, 256, 0, s>>>((const float*)ws, n * bpi, ncol, dw, ch, db);
+    // (until r04 one thread per column walked all n * bpi rows: 1 024 dependent loads, most of the launch's 0.3 ms)
+    rows_sum_par_kernel<<<(ncol + 3) / 4, 256, 0, s>>>((const float*)ws, n * bpi, ncol, dw, ch, db);
     AD_LAUNCH_CHECK("seg rows_sum");
     return AD_OK;
 }

@@ -127,7 +127,7 @@ def pad_channels(x: torch.Tensor, cpad: int, dtype: torch.dtype) -> torch.Tensor
     n, h, w, c = x.shape
     assert x.dtype == torch.float32
     y = torch.empty((n, h, w, cpad), dtype=dtype, device=x.device)
-    with _timed("pad_channels"):
+    with _timed("pad_channels", 0.0, float(x.numel() * 4 + y.numel() * y.element_size())):
         check(_lib.load().ad_pad_channels(_p(x), _p(y), n * h * w, c, cpad, dt(dtype), _stream()), "ad_pad_channels")
     return y
 
@@ -653,33 +653,59 @@ def batchnorm_relu_fwd_train(z, gamma, beta, moving_mean, moving_var, ws: Worksp
     mean, rstd, var = (torch.empty(c, dtype=torch.float32, device=z.device) for _ in range(3))
     lib = _lib.load()
     ws.ensure(lib.ad_batchnorm_ws_bytes(c))
-    with _timed("batchnorm_fwd"):
+    with _timed("batchnorm_fwd", 0.0, 2.0 * z.numel() * z.element_size()):       # algorithmic: read z once, write y
         check(lib.ad_batchnorm_relu_fwd_train(_p(z), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), _p(var),
                                               _p(moving_mean), _p(moving_var), momentum, npix, c, eps, int(relu),
                                               ws.ptr, ws.nbytes, dt(z.dtype), _stream()), "ad_batchnorm_relu_fwd_train")
     return y, mean, rstd
 
 
+def batchnorm_pool_supported(z) -> bool:
+    """batchnorm_relu_pool_fwd_train takes z: even extents, at most 256 16-byte channel vectors per pixel."""
+    n, h, w, c = z.shape
+    ept = 16 // z.element_size()
+    return h % 2 == 0 and w % 2 == 0 and h >= 2 and w >= 2 and c % ept == 0 and c // ept <= 256 and 256 % (c // ept) == 0
+
+
+def batchnorm_relu_pool_fwd_train(z, gamma, beta, moving_mean, moving_var, ws: Workspace, relu: bool = True,
+                                  eps: float = BN_EPS, momentum: float = BN_MOMENTUM):
+    """batchnorm_relu_fwd_train whose pass over z also writes MaxPooling2D(2) of the activation: returns
+    (y, pooled, save_mean, save_rstd)."""
+    n, h, w, c = z.shape
+    y = torch.empty_like(z)
+    pooled = torch.empty((n, h // 2, w // 2, c), dtype=z.dtype, device=z.device)
+    mean, rstd, var = (torch.empty(c, dtype=torch.float32, device=z.device) for _ in range(3))
+    lib = _lib.load()
+    ws.ensure(lib.ad_batchnorm_ws_bytes(c))
+    with _timed("batchnorm_fwd", 0.0, 2.25 * z.numel() * z.element_size()):      # read z once, write y and its pooling
+        check(lib.ad_batchnorm_relu_pool_fwd_train(_p(z), _p(gamma), _p(beta), _p(y), _p(pooled), _p(mean), _p(rstd), _p(var),
+                                                   _p(moving_mean), _p(moving_var), momentum, n, h, w, c, eps, int(relu),
+                                                   ws.ptr, ws.nbytes, dt(z.dtype), _stream()), "ad_batchnorm_relu_pool_fwd_train")
+    return y, pooled, mean, rstd
+
+
 def batchnorm_relu_fwd_infer(z, gamma, beta, moving_mean, moving_var, relu: bool = True, eps: float = BN_EPS):
     c = z.shape[-1]
     y = torch.empty_like(z)
     tmp = torch.empty(c, dtype=torch.float32, device=z.device)
-    with _timed("batchnorm_fwd"):
+    with _timed("batchnorm_fwd", 0.0, 2.0 * z.numel() * z.element_size()):
         check(_lib.load().ad_batchnorm_relu_fwd_infer(_p(z), _p(gamma), _p(beta), _p(moving_mean), _p(moving_var), _p(y),
                                                       _p(tmp), z.numel() // c, c, eps, int(relu), dt(z.dtype), _stream()),
               "ad_batchnorm_relu_fwd_infer")
     return y
 
 
-def batchnorm_relu_bwd(dy, z, mean, rstd, gamma, beta, dgamma, dbeta, ws: Workspace, relu: bool = True):
+def batchnorm_relu_bwd(dy, z, mean, rstd, gamma, beta, dgamma, dbeta, ws: Workspace, relu: bool = True, dbias=None):
+    """dbias (fp32 [c], optional): receives the column sums of dz as stored -- the bias gradient of the convolution in
+    front -- from the pass that writes dz (no separate colsum launch)."""
     c = z.shape[-1]
     dz = torch.empty_like(z)
     lib = _lib.load()
     ws.ensure(lib.ad_batchnorm_ws_bytes(c))
-    with _timed("batchnorm_bwd"):
-        check(lib.ad_batchnorm_relu_bwd(_p(dy), _p(z), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dz), _p(dgamma),
-                                        _p(dbeta), z.numel() // c, c, int(relu), ws.ptr, ws.nbytes, dt(z.dtype), _stream()),
-              "ad_batchnorm_relu_bwd")
+    with _timed("batchnorm_bwd", 0.0, 3.0 * z.numel() * z.element_size()):       # algorithmic: read dy and z, write dz
+        check(lib.ad_batchnorm_relu_bwd_dbias(_p(dy), _p(z), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dz), _p(dgamma),
+                                              _p(dbeta), _p(dbias), z.numel() // c, c, int(relu), ws.ptr, ws.nbytes,
+                                              dt(z.dtype), _stream()), "ad_batchnorm_relu_bwd")
     return dz
 
 
@@ -687,7 +713,7 @@ def colsum(x, out, ws: Workspace):
     c = x.shape[-1]
     lib = _lib.load()
     ws.ensure(lib.ad_batchnorm_ws_bytes(c))
-    with _timed("colsum"):
+    with _timed("colsum", 0.0, float(x.numel() * x.element_size())):
         check(lib.ad_colsum(_p(x), _p(out), x.numel() // c, c, ws.ptr, ws.nbytes, dt(x.dtype), _stream()), "ad_colsum")
     return out
 
@@ -695,7 +721,7 @@ def colsum(x, out, ws: Workspace):
 def maxpool2_fwd(x):
     n, h, w, c = x.shape
     y = torch.empty((n, h // 2, w // 2, c), dtype=x.dtype, device=x.device)
-    with _timed("maxpool2"):
+    with _timed("maxpool2", 0.0, 1.25 * x.numel() * x.element_size()):
         check(_lib.load().ad_maxpool2_fwd(_p(x), _p(y), n, h, w, c, dt(x.dtype), _stream()), "ad_maxpool2_fwd")
     return y
 
@@ -703,7 +729,7 @@ def maxpool2_fwd(x):
 def maxpool2_bwd(dy, x):
     n, h, w, c = x.shape
     dx = torch.empty_like(x)
-    with _timed("maxpool2"):
+    with _timed("maxpool2", 0.0, 2.25 * x.numel() * x.element_size()):
         check(_lib.load().ad_maxpool2_bwd(_p(dy), _p(x), _p(dx), n, h, w, c, dt(x.dtype), _stream()), "ad_maxpool2_bwd")
     return dx
 
@@ -769,7 +795,7 @@ def seg_head_fwd(xh, w, b, target, ws: Workspace):
     sums = torch.empty((n, 3), dtype=torch.float32, device=xh.device) if target is not None else None
     lib = _lib.load()
     ws.ensure(lib.ad_seg_head_ws_bytes(n, ch))
-    with _timed("seg_head_fwd"):
+    with _timed("seg_head_fwd", 0.0, float(xh.numel() * xh.element_size() + n * h * wd * (8 if target is not None else 4))):
         check(lib.ad_seg_head_fwd(_p(xh), _p(w), _p(b), _p(target), _p(prob), _p(sums), n, h * wd, ch, ws.ptr, ws.nbytes,
                                   dt(xh.dtype), _stream()), "ad_seg_head_fwd")
     return prob, sums
@@ -792,7 +818,7 @@ def seg_head_bwd(xh, w, target, prob, sums, dw, db, bce_weight: float, dice_weig
     dxh = torch.empty_like(xh)
     lib = _lib.load()
     ws.ensure(lib.ad_seg_head_ws_bytes(n, ch))
-    with _timed("seg_head_bwd"):
+    with _timed("seg_head_bwd", 0.0, float(2 * xh.numel() * xh.element_size() + n * h * wd * 8)):
         check(lib.ad_seg_head_bwd(_p(xh), _p(w), _p(target), _p(prob), _p(sums), _p(dxh), _p(dw), _p(db), n, h * wd, ch,
                                   bce_weight, dice_weight, smooth, _p(loss_scale), ws.ptr, ws.nbytes, dt(xh.dtype), _stream()),
               "ad_seg_head_bwd")

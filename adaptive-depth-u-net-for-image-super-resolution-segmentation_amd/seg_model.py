@@ -252,12 +252,18 @@ class SegModel(Model):
             self._up_tabs[key] = ops.ResampleTables(s, w, s, w, self.device)
         return self._up_tabs[key]
 
-    def _block_fwd(self, blk, x1, x2, training, tape, keep):
-        for cs, nn in blk:
+    def _block_fwd(self, blk, x1, x2, training, tape, keep, pool=False):
+        """conv_block; pool=True: also MaxPooling2D(2) of the block's output -- returns (a, pooled), the pooling written by the
+        last BatchNorm's apply pass where that kernel exists (training), else by ad_maxpool2_fwd."""
+        pooled = None
+        for li, (cs, nn) in enumerate(blk):
             g, b = self.param(nn + "/gamma"), self.param(nn + "/beta")
             if self.norm == "bn":
                 z = ops.conv3x3_fwd(x1, x2, self._packs[cs.name][0], self.param(cs.name + "/bias"), cs.cout)
-                if training:
+                if training and pool and li == len(blk) - 1 and ops.batchnorm_pool_supported(z):
+                    a, pooled, mean, rstd = ops.batchnorm_relu_pool_fwd_train(z, g, b, self._state(nn + "/moving_mean"),
+                                                                              self._state(nn + "/moving_variance"), self._ws)
+                elif training:
                     a, mean, rstd = ops.batchnorm_relu_fwd_train(z, g, b, self._state(nn + "/moving_mean"),
                                                                  self._state(nn + "/moving_variance"), self._ws)
                 else:
@@ -271,17 +277,18 @@ class SegModel(Model):
             if self.audit is not None:
                 self.audit.append(("fwd_cna", cs.name, x1, x2, z, a, mean, rstd, training))
             x1, x2 = a, None
+        if pool:
+            return x1, (pooled if pooled is not None else ops.maxpool2_fwd(x1))
         return x1
 
     def _forward_seg(self, img: torch.Tensor, mask: Optional[torch.Tensor], training: bool, keep: bool):
         tape, skips = [], []
         x = ops.pad_channels(img, ops.cin_granule(self.dtype), self.dtype)
         for lvl in range(self.depth):
-            x = self._block_fwd(self.blocks[lvl], x, None, training, tape, keep)
+            x, pooled = self._block_fwd(self.blocks[lvl], x, None, training, tape, keep, pool=True)
             skips.append(x)
             if keep:
                 tape.append(("pool", x, lvl))
-            pooled = ops.maxpool2_fwd(x)
             if self.audit is not None:
                 self.audit.append(("fwd_pool", f"pool{lvl}", x, pooled))
             x = pooled
@@ -344,9 +351,9 @@ class SegModel(Model):
                 _, cs, nn, x1, x2, z, mean, rstd = rec
                 d_in = d
                 g, b = self.param(nn + "/gamma"), self.param(nn + "/beta")
-                if self.norm == "bn":
-                    dz = ops.batchnorm_relu_bwd(d, z, mean, rstd, g, b, self.grad(nn + "/gamma"), self.grad(nn + "/beta"), ws)
-                    ops.colsum(dz.view(-1, cs.cout), self.grad(cs.name + "/bias"), ws)
+                if self.norm == "bn":      # the conv's bias gradient (column sums of dz as stored) comes out of the pass that writes dz
+                    dz = ops.batchnorm_relu_bwd(d, z, mean, rstd, g, b, self.grad(nn + "/gamma"), self.grad(nn + "/beta"), ws,
+                                                dbias=self.grad(cs.name + "/bias"))
                 else:
                     dz = ops.layernorm_relu_bwd(d, z, mean, rstd, g, b, self.grad(nn + "/gamma"), self.grad(nn + "/beta"),
                                                 self.grad(cs.name + "/bias"), ws)

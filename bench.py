@@ -38,6 +38,15 @@ WORKLOADS = {
 # no such path: adunet_amd/multitask.py).  One "step" = one pass over this fixed mixed stream, one captured graph per item:
 # the Experiment-2 rows 0.3 -> 2, 0.5 -> 3, 0.6 -> 4, 0.7 -> 5 at their bench batches and the segmentation task.
 K5_STREAM = [("sr", 0.3, 64), ("sr", 0.5, 64), ("sr", 0.6, 32), ("sr", 0.7, 8), ("seg", None, 16)]
+# BASELINE config 3 as the reference's source defines it (ISIC binary masks at 256 x 256, not Cityscapes):
+# Segmenation/code/train_adaptive_unet.py:335-362 build_adaptive_depth_unet(256, 64, depth) -- Conv3x3 + BatchNorm + ReLU x 2,
+# MaxPool2, bilinear x2, concat, sigmoid head, protocol A/B loss -- and unet_vinillia.py:72-91 build_unet (LayerNorm, Conv2DTranspose)
+SEG_WORKLOADS = {
+    # name: (builder, depth, base channels, per-GPU batch, protocol)
+    "K3": ("bn", 5, 64, 8, "A"),            # build_adaptive_depth_unet(256, 64, 5), protocol A batch 8 (:382-392)
+    "K3d4": ("bn", 4, 64, 16, "B"),         # the reference's default depth 4 (:55-56), protocol B batch 16 (:393-403)
+    "K3ln": ("ln", 4, 64, 16, "B"),         # vanilla baseline build_unet at 64 base channels
+}
 
 
 def conv_flops_per_image(model):
@@ -279,6 +288,126 @@ def run_k5(args, rank, world, device, use_dist):
     return line
 
 
+def run_seg(args, rank, world, device, use_dist):
+    """BASELINE config 3 (restated by SURVEY 8d as K3): one train step of the segmentation U-Net -- forward, BCE + Dice loss,
+    backward, Keras Adam, operand repack -- graph-replayed on a resident synthetic batch (image U[0,1), mask Bernoulli(0.3)).
+    Same line as the SR workloads: whole-step `frac_step` on the reference graph's conv FLOPs, the MFMA families, every
+    HBM-bound op with its algorithmic bytes and rate.  BatchNorm statistics are per replica."""
+    import torch.distributed as dist
+    from adunet_amd import ops
+    from adunet_amd import seg_model as S
+    from adunet_amd.parallel import DataParallel
+    kind, depth, base, batch, proto_name = SEG_WORKLOADS[args.workload]
+    if args.batch:
+        batch = args.batch
+    dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
+    patch = 256
+    model = (S.build_adaptive_depth_unet(patch, base, depth, dtype=dtype, device=device) if kind == "bn"
+             else S.build_unet(patch, 1, base, depth, dtype=dtype, device=device))
+    proto = S.PROTOCOLS[proto_name]
+    model.compile(optimizer=S.build_optimizer(proto, steps_per_epoch=1000, epochs=100), loss=proto.loss_builder())
+    model._require_device()
+    if use_dist:
+        DataParallel(model)
+    rng = np.random.default_rng(1234 + rank)
+    img = torch.from_numpy(rng.random((batch, patch, patch, 3), dtype=np.float32)).to(device)
+    mask = torch.from_numpy((rng.random((batch, patch, patch, 1)) < 0.3).astype(np.float32)).to(device)
+
+    def sync():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    graphed = not args.eager
+    step_fn = model.make_graphed_train_step(img, mask) if graphed else model.train_on_batch
+    for _ in range(args.warmup):
+        step_fn(img, mask)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step_fn(img, mask)
+    sync()
+    elapsed = time.perf_counter() - t0
+    timer = ops.KernelTimer()
+    ops.set_timer(timer)
+    timed_steps = min(args.steps, 3)
+    for _ in range(timed_steps):
+        last = model.train_on_batch(img, mask)
+    torch.cuda.synchronize()
+    ops.set_timer(None)
+    if use_dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+    if rank != 0:
+        return None
+    fwd, first = conv_flops_per_image(model)
+    f_step = 3.0 * fwd - first
+    summ = timer.summary()
+    per_step = 1.0 / timed_steps
+    total_ms = sum(v[1] for v in summ.values()) * per_step
+    pad_first = first * (model._cin_pad(next(iter(model.convs.values()))) / 3.0 - 1.0) * batch     # the 3-channel input is zero-padded
+
+    def family(names, minus=0.0):
+        cnt = sum(summ.get(k, (0, 0.0))[0] for k in names)
+        ms = sum(summ.get(k, (0, 0.0))[1] for k in names) * per_step
+        fl = sum(timer.work(k) for k in names) * per_step - minus
+        nb = sum(timer.nbytes(k) for k in names) * per_step
+        return {"launches_per_step": cnt * per_step, "gflop_per_step": fl / 1e9, "ms_per_step": ms,
+                "tflops": fl / ms / 1e9 if ms > 0 else None, "frac": fl / ms / 1e9 / PEAK_BF16_TFLOPS if ms > 0 else None,
+                "algorithmic_gb_per_step": nb / 1e9, "hbm_tb_per_s": nb / ms / 1e9 if ms > 0 else None,
+                "flop_per_byte": fl / nb if nb > 0 else None, "share_of_step": ms / total_ms if total_ms > 0 else None}
+
+    fam = {"fwd_dgrad": family(["conv3x3_fwd"], pad_first),
+           "fused_ln_fwd": family(["conv3x3_ln_relu_fwd"]),
+           "fused_bn_fwd": family(["conv3x3_bn_stats_fwd"], pad_first),
+           "dgrad_bn_bwd_fused": family(["conv3x3_dgrad_bn_bwd"]),
+           "wgrad": family(["conv3x3_wgrad"], pad_first)}
+    fam = {k: v for k, v in fam.items() if v["launches_per_step"] > 0}
+    conv_ms = sum(f["ms_per_step"] for f in fam.values())
+    conv_gf = sum(f["gflop_per_step"] for f in fam.values())
+    hbm_ops = {}
+    for k, (cnt, t_ms) in sorted(summ.items(), key=lambda kv: -kv[1][1]):
+        if k.startswith("conv3x3_") and k != "conv3x3_pack":
+            continue
+        nb = timer.nbytes(k)
+        hbm_ops[k] = {"launches_per_step": cnt * per_step, "ms_per_step": t_ms * per_step,
+                      "algorithmic_gb_per_step": nb * per_step / 1e9 if nb else None,
+                      "tb_per_s": nb / t_ms / 1e9 if nb else None}
+    if args.breakdown:
+        print(f"{'op family':<26}{'launches/step':>14}{'ms/step':>10}{'share':>8}{'TB/s':>8}", file=sys.stderr)
+        for k, (cnt, t_ms) in sorted(summ.items(), key=lambda kv: -kv[1][1]):
+            nb = timer.nbytes(k)
+            print(f"{k:<26}{cnt * per_step:>14.1f}{t_ms * per_step:>10.3f}{t_ms * per_step / total_ms:>8.1%}"
+                  f"{(nb / t_ms / 1e9 if nb else float('nan')):>8.2f}", file=sys.stderr)
+        print(f"{'(sum of op events)':<26}{'':>14}{total_ms:>10.3f}", file=sys.stderr)
+    dom_name = max(fam, key=lambda k: fam[k]["ms_per_step"])
+    dom = fam[dom_name]
+    img_s = batch * world * args.steps / elapsed
+    ms_step = elapsed * 1e3 / args.steps
+    loss_v, dice_v, iou_v = (float(v) for v in last)
+    line = {"metric": METRIC, "value": img_s, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload}: segmentation U-Net {model.name} (BASELINE config 3 as the reference's source "
+                                   f"defines it: 256 x 256 binary masks), protocol {proto_name} train step",
+                       "global_batch": batch * world, "per_gpu_batch": batch, "params": model.count_params(),
+                       "parallelism": f"dp{world}", "launch": "hipGraph replay" if graphed else "eager",
+                       "conv_gflop_per_image_step": f_step / 1e9, "final_loss": loss_v, "final_dice": dice_v, "final_iou": iou_v},
+            "roofline": {"bound": "mfma", "family": dom_name, "achieved": dom["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": dom["frac"], "traffic": None,
+                         "frac_step": img_s / world * f_step / 1e12 / PEAK_BF16_TFLOPS,
+                         "algorithmic_gflop_per_step": f_step * batch / 1e9, "executed_gflop_per_step": conv_gf,
+                         "frac_all_conv_kernels": conv_gf / conv_ms / PEAK_BF16_TFLOPS if conv_ms > 0 else None,
+                         "families": fam, "hbm_ops": hbm_ops, "non_conv_ms_per_step": total_ms - conv_ms,
+                         "timing": "HIP events around every launch of %d eager steps run right after the graph-replayed timed "
+                                   "region" % timed_steps}}
+    if use_dist:
+        line["ranks"] = dist.get_world_size()
+        line["dist_backend"] = args.backend
+    return line
+
+
 def launch_ranks(n: int) -> int:
     """`python -m torch.distributed.run --nnodes=1 --nproc-per-node n ... bench.py <same flags>` as a child process."""
     import socket
@@ -299,7 +428,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="K2p", choices=sorted(WORKLOADS) + ["K5"],
+    ap.add_argument("--workload", default="K2p", choices=sorted(WORKLOADS) + sorted(SEG_WORKLOADS) + ["K5"],
                     help="K5 = BASELINE config 5, build-defined: a fixed mixed SR (depths 2-5) + segmentation stream, default --dtype f16")
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch override")
     ap.add_argument("--dtype", default=None, choices=["bf16", "f16", "f32"],
@@ -365,8 +494,8 @@ def main():
     from adunet_amd.model import Adam, build_losses_and_metrics, build_super_resolution_unet
     from adunet_amd.parallel import DataParallel
 
-    if args.workload == "K5":
-        line = run_k5(args, rank, world, device, use_dist)
+    if args.workload == "K5" or args.workload in SEG_WORKLOADS:
+        line = run_k5(args, rank, world, device, use_dist) if args.workload == "K5" else run_seg(args, rank, world, device, use_dist)
         if rank == 0:
             print(json.dumps(line), file=record_out, flush=True)
         if use_dist:

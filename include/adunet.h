@@ -257,21 +257,35 @@ int ad_adam_step(float* p, const float* g, float* m, float* v, int64_t count,
 /* ------------------------------------------------- tier 2: segmentation ops -- */
 
 /* L.BatchNormalization() (eps 1e-3, momentum 0.99) + L.Activation("relu"):
- * Segmenation/code/train_adaptive_unet.py:325-332.  Training mode: batch statistics over (N,H,W) (two-pass,
- * biased variance), saved mean/rstd/var [c] for the backward pass, and the Keras moving-average update
- * moving = moving*momentum + batch*(1-momentum) (moving_* may be NULL).  Inference mode uses the moving stats. */
+ * Segmenation/code/train_adaptive_unet.py:325-332.  Training mode: batch statistics over (N,H,W) (biased variance; ONE pass
+ * over z: sums of the deviations from the first pixel's row and of their squares, so the variance has no E[x^2] - mean^2
+ * cancellation), saved mean/rstd/var [c] for the backward pass, and the Keras moving-average update
+ * moving = moving*momentum + batch*(1-momentum) (moving_* may be NULL).  Inference mode uses the moving stats.
+ * ad_batchnorm_relu_pool_fwd_train additionally writes pooled[n, h/2, w/2, c] = MaxPooling2D(2) of y in the pass that writes
+ * y (the encoder's conv_block -> MaxPooling2D, :349-351); h, w even, c at most 256 16-byte vectors.
+ * ad_batchnorm_relu_bwd_dbias additionally returns dbias[c] = column sums of dz AS STORED (the BiasAddGrad of the convolution
+ * in front: what ad_colsum(dz) returns) from the pass that writes dz; dbias == NULL is ad_batchnorm_relu_bwd. */
 size_t ad_batchnorm_ws_bytes(int c);
 int ad_batchnorm_relu_fwd_train(const void* z, const float* gamma, const float* beta, void* y,
                                 float* save_mean, float* save_rstd, float* save_var,
                                 float* moving_mean, float* moving_var, float momentum,
                                 int64_t npix, int c, float eps, int relu,
                                 void* ws, size_t ws_bytes, int dtype, void* stream);
+int ad_batchnorm_relu_pool_fwd_train(const void* z, const float* gamma, const float* beta, void* y, void* pooled,
+                                     float* save_mean, float* save_rstd, float* save_var,
+                                     float* moving_mean, float* moving_var, float momentum,
+                                     int n, int h, int w, int c, float eps, int relu,
+                                     void* ws, size_t ws_bytes, int dtype, void* stream);
 int ad_batchnorm_relu_fwd_infer(const void* z, const float* gamma, const float* beta,
                                 const float* moving_mean, const float* moving_var, void* y, float* rstd_tmp,
                                 int64_t npix, int c, float eps, int relu, int dtype, void* stream);
 int ad_batchnorm_relu_bwd(const void* dy, const void* z, const float* save_mean, const float* save_rstd,
                           const float* gamma, const float* beta, void* dz, float* dgamma, float* dbeta,
                           int64_t npix, int c, int relu, void* ws, size_t ws_bytes, int dtype, void* stream);
+
+int ad_batchnorm_relu_bwd_dbias(const void* dy, const void* z, const float* save_mean, const float* save_rstd,
+                                const float* gamma, const float* beta, void* dz, float* dgamma, float* dbeta, float* dbias,
+                                int64_t npix, int c, int relu, void* ws, size_t ws_bytes, int dtype, void* stream);
 
 /* out[c] = sum over pixels of x[npix, c] (BiasAddGrad of layers without a fused producer); ws as batchnorm. */
 int ad_colsum(const void* x, float* out, int64_t npix, int c, void* ws, size_t ws_bytes, int dtype, void* stream);

@@ -52,6 +52,65 @@ def test_batchnorm_relu(device, ws, dtype, c):
     assert relerr(ops.batchnorm_relu_fwd_infer(zd, f(gamma), f(beta), f(mmean), f(mvar)), want) < TOL[dtype]
 
 
+@pytest.mark.parametrize("dtype", [F32, BF16, torch.float16])
+@pytest.mark.parametrize("shape", [(2, 6, 8, 64), (3, 4, 4, 256), (1, 2, 2, 2048)])
+def test_batchnorm_pool_and_dbias_fusions_equal_the_separate_launches(device, ws, dtype, shape):
+    """r05: ad_batchnorm_relu_pool_fwd_train = ad_batchnorm_relu_fwd_train + ad_maxpool2_fwd (bitwise: the maximum is taken of the
+    stored activations), ad_batchnorm_relu_bwd_dbias = ad_batchnorm_relu_bwd + ad_colsum(dz) (dz bitwise, the sums to fp32
+    summation order), and both against the oracle."""
+    from adunet_amd import ops
+    n, h, w, c = shape
+    if not ops.batchnorm_pool_supported(torch.empty(shape, dtype=dtype)):
+        pytest.skip("wider than 256 channel vectors: the model falls back to the separate pooling launch")
+    rng = np.random.default_rng(sum(shape))
+    z = rnd(rng.standard_normal(shape) * 1.3 - 0.4, dtype)
+    gamma = rng.uniform(0.5, 1.5, c).astype(np.float32).astype(np.float64)
+    beta = rng.uniform(-0.5, 0.5, c).astype(np.float32).astype(np.float64)
+    f = lambda v: torch.tensor(v, dtype=F32, device=device)
+    zd = to_dev(z, dtype, device)
+    y0, mean0, rstd0 = ops.batchnorm_relu_fwd_train(zd, f(gamma), f(beta), f(np.zeros(c)), f(np.ones(c)), ws)
+    p0 = ops.maxpool2_fwd(y0)
+    mm, mv = f(np.zeros(c)), f(np.ones(c))
+    y1, p1, mean1, rstd1 = ops.batchnorm_relu_pool_fwd_train(zd, f(gamma), f(beta), mm, mv, ws)
+    assert torch.equal(y0, y1) and torch.equal(p0, p1) and torch.equal(mean0, mean1) and torch.equal(rstd0, rstd1)
+    y, cache, mu, var = ref.batchnorm_train_fwd(z, gamma, beta)
+    tol = {F32: 1e-3, BF16: 1.5e-2, torch.float16: 2e-3}[dtype]
+    assert relerr(p1, ref.maxpool2_fwd(ref.relu_fwd(y))) < tol
+    assert relerr(mm, 0.01 * mu) < 1e-4 and relerr(mv, 0.99 + 0.01 * var) < 1e-5
+    dy = to_dev(rnd(rng.standard_normal(shape), dtype), dtype, device)
+    g0, b0, g1, b1, db1 = (torch.empty(c, dtype=F32, device=device) for _ in range(5))
+    dz0 = ops.batchnorm_relu_bwd(dy, zd, mean0, rstd0, f(gamma), f(beta), g0, b0, ws)
+    db0 = ops.colsum(dz0.view(-1, c), torch.empty(c, dtype=F32, device=device), ws)
+    dz1 = ops.batchnorm_relu_bwd(dy, zd, mean0, rstd0, f(gamma), f(beta), g1, b1, ws, dbias=db1)
+    assert torch.equal(dz0, dz1) and torch.equal(g0, g1) and torch.equal(b0, b1)
+    want_db = dz1.to(torch.float64).sum(dim=(0, 1, 2)).cpu().numpy()
+    scale = float(dz1.to(torch.float64).abs().sum(dim=(0, 1, 2)).max()) + 1e-30
+    assert np.abs(db1.cpu().numpy() - want_db).max() / scale < 1e-5 and np.abs(db0.cpu().numpy() - want_db).max() / scale < 1e-5
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_batchnorm_statistics_in_one_pass_with_a_large_mean_offset(device, ws, dtype):
+    """The batch moments come out of ONE pass over z (r05) as sums of deviations from the first pixel's row.  A channel whose
+    mean is 1 000 standard deviations away from zero (where the unshifted E[x^2] - mean^2 loses 10 % of the variance in fp32:
+    the r04 defect of the fused LayerNorm epilogue) and one whose FIRST pixel is an outlier 30 deviations from the mean."""
+    from adunet_amd import ops
+    rng = np.random.default_rng(5)
+    c = 64
+    z = rng.standard_normal((4, 16, 16, c))
+    z[..., 0] = z[..., 0] * 0.01 + 10.0              # mean / std = 1 000
+    z[..., 1] = z[..., 1] * 0.5 - 3.0
+    z[0, 0, 0, 1] = 12.0                             # an outlier as the shift
+    z = rnd(z, dtype)
+    gamma, beta = np.ones(c), np.zeros(c)
+    f = lambda v: torch.tensor(v, dtype=F32, device=device)
+    _, cache, mu, var = ref.batchnorm_train_fwd(z, gamma, beta)
+    _, mean, rstd = ops.batchnorm_relu_fwd_train(to_dev(z, dtype, device), f(gamma), f(beta), None, None, ws)
+    got_mu, got_rstd = mean.cpu().numpy().astype(np.float64), rstd.cpu().numpy().astype(np.float64)
+    assert np.abs(got_mu - mu).max() < 1e-5 * np.abs(mu).max()
+    want_rstd = 1.0 / np.sqrt(var + 1e-3)
+    assert np.abs(got_rstd / want_rstd - 1.0).max() < 1e-4, np.abs(got_rstd / want_rstd - 1.0).max()
+
+
 @pytest.mark.parametrize("dtype", [F32, BF16])
 @pytest.mark.parametrize("hw", [(8, 8), (7, 10)])
 def test_maxpool2(device, dtype, hw):
