@@ -77,6 +77,7 @@ SIGNATURES = {
     "ad_colsum": (_i, [_vp, _vp, _i64, _i, _vp, _sz, _i, _vp]),
     "ad_maxpool2_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ad_maxpool2_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ad_maxpool2_bwd_add": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ad_pixel_shuffle2": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ad_seg_head_ws_bytes": (_sz, [_i, _i]),
     "ad_seg_head_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _sz, _i, _vp]),

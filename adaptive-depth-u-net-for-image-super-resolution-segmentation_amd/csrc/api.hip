@@ -20,7 +20,8 @@ extern "C" int ad_version(void) { return 1; }
 // ---- the only process-wide state of the library besides the last error string: the CU count of the device (read once)
 // and the options a caller sets explicitly
 int ad_num_cu() {
-    // per device (a process may drive several, one thread each): the count sizes every persistent grid, workspace and the XCD
+    // per device (a process may drive several, one thread each; the one-time dynamic-LDS raises are per device too:
+    // ad_first_on_device): the count sizes every persistent grid, workspace and the XCD
     // tile order.  Relaxed atomics: racing first calls compute the same value.
     static std::atomic<int> cache[16];
     int dev = 0;

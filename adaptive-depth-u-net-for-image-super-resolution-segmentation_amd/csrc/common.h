@@ -18,6 +18,18 @@ typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 int ad_set_error(int code, const char* fmt, ...);
 // Compute units of the current device, queried once (api.hip): the persistent kernels launch one workgroup per CU.
 int ad_num_cu();
+// One-time per-DEVICE set-up (hipFuncSetAttribute applies to the current device's function object: a process that drives several
+// devices must raise the dynamic-LDS limit on each of them).  `done` holds one bit per device ordinal; true = this caller sets up.
+// Racing first calls on one device both run the set-up, which is idempotent.
+#include <atomic>
+static inline bool ad_first_on_device(std::atomic<unsigned long long>& done) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 63;      // beyond 63 ordinals: set up on every call
+    const unsigned long long bit = 1ULL << dev;
+    if (dev != 63 && (done.load(std::memory_order_acquire) & bit)) return false;
+    done.fetch_or(bit, std::memory_order_release);
+    return true;
+}
 // Explicit library options (ad_set_option, include/adunet.h): the library itself never reads the environment.
 enum { AD_OPT_NO_MAP1 = 0, AD_OPT_NO_MAP4 = 1, AD_OPT_NO_DGRAD_LN = 2, AD_OPT_NO_MOSAIC = 3, AD_OPT_COUNT = 4 };
 int ad_option(int which);

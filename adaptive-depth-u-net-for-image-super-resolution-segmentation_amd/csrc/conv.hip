@@ -2748,8 +2748,8 @@ int launch_fwd(ConvArgs a, void* ws, size_t ws_bytes, hipStream_t s) {
     const int nblk = a.cout / BN;
     const int nch = (a.c1 + a.c2) / P::CK;
     const int nitems = a.ntiles * nblk;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<unsigned long long> attr_set{0};
+    if (ad_first_on_device(attr_set)) {
         allow_big_lds(conv3x3_fwd_kernel<P, 6, true>);
         allow_big_lds(conv3x3_fwd_kernel<P, 16, true>);
         allow_big_lds(conv3x3_fwd_kernel<P, 6, false>);
@@ -2764,16 +2764,14 @@ int launch_fwd(ConvArgs a, void* ws, size_t ws_bytes, hipStream_t s) {
             allow_big_lds(conv3x3_fwd_wres_kernel<P, 4>);
             allow_big_lds(conv3x3_fwd_wres_kernel<P, 5>);
         }
-        attr_set = true;
     }
     if constexpr (sizeof(typename P::T) == 2) {
         a.ksplit = 1; a.slab = nullptr;
         if (map4_ok(a.n, a.h, a.w, a.c1, a.c2, a.cout_real, a.cy1) && a.epilogue <= AD_EPI_RELU) {
-            static bool m4_attr = false;
-            if (!m4_attr) {
+            static std::atomic<unsigned long long> m4_attr{0};
+            if (ad_first_on_device(m4_attr)) {
                 allow_big_lds(conv3x3_map4_kernel<P, 2>);
                 allow_big_lds(conv3x3_map4_kernel<P, 4>);
-                m4_attr = true;
             }
             const int mblk = (a.n + M4_IMG - 1) / M4_IMG;
             // 64-channel blocks keep the LDS and L1 traffic per MFMA lowest; 32-channel blocks when that leaves CUs idle
@@ -2825,11 +2823,10 @@ int launch_fwd(ConvArgs a, void* ws, size_t ws_bytes, hipStream_t s) {
             // maps whose extent is not a multiple of 16: all images as one mosaic when that needs fewer tiles (Geo)
             Geo mg = a.g;
             if (fwd_mosaic(a.n, a.h, a.w, nblk, &mg)) {
-                static bool mos_attr = false;
-                if (!mos_attr) {
+                static std::atomic<unsigned long long> mos_attr{0};
+                if (ad_first_on_device(mos_attr)) {
                     allow_big_lds(conv3x3_fwd_ws_kernel<P, 0, true>);
                     allow_big_lds(conv3x3_fwd_ws_kernel<P, 1, true>);
-                    mos_attr = true;
                 }
                 a.g = mg;
                 a.ntiles = mg.tiles_x * mg.tiles_y;
@@ -2915,21 +2912,19 @@ int launch_wgrad(WgradArgs a, const WgradPlan& p, hipStream_t s) {
     g.NPHP = xs * 256 / 4;
     size_t lds = 2 * (size_t)g.NPHP * 4 + TM * 4 + (((size_t)g.NPH * PIXB + 15) & ~15) + (size_t)TM * WP::DZS;
     if (lds > 160 * 1024) return ad_set_error(AD_ERR_ARG, "conv3x3_wgrad: LDS %zu too large", lds);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<unsigned long long> attr_set{0};
+    if (ad_first_on_device(attr_set)) {
         allow_big_lds(conv3x3_wgrad_kernel<P, 6, true>);
         allow_big_lds(conv3x3_wgrad_kernel<P, 16, true>);
         allow_big_lds(conv3x3_wgrad_kernel<P, 6, false>);
-        attr_set = true;
     }
     dim3 grid(p.nsplit, p.ncib, p.ncob);
     if constexpr (sizeof(typename P::T) == 2) {
         if (p.specialised) {
-            static bool attr2 = false;
-            if (!attr2) {
+            static std::atomic<unsigned long long> attr2{0};
+            if (ad_first_on_device(attr2)) {
                 allow_big_lds(conv3x3_wgrad_ws_kernel<typename P::T>);
                 allow_big_lds(conv3x3_wgrad_ws_kernel<typename P::T, true>);
-                attr2 = true;
             }
             if (g.mos) conv3x3_wgrad_ws_kernel<typename P::T, true><<<grid, W2_T, W2_LDS, s>>>(a);
             else conv3x3_wgrad_ws_kernel<typename P::T><<<grid, W2_T, W2_LDS, s>>>(a);
@@ -3092,16 +3087,19 @@ extern "C" int ad_conv3x3_ln_relu_fwd(const void* x1, int c1, const void* x2, in
 
 extern "C" int ad_conv3x3_mosaic(int n, int h, int w, int c1, int c2, int cout, int dtype, int wgrad) {
     if (!ad_is_half(dtype) || !pixels_ok(n, h, w) || c1 <= 0 || c2 < 0 || cout <= 0 || (c1 + c2) % ad_cin_granule(dtype)) return 0;
+    // follows the launch path: a batch of 2 GiB and more runs as image chunks, each planned on its own (launch_fwd_runs, the run
+    // loop of ad_conv3x3_wgrad); the answer describes the full-size runs of `chunk` images
+    const int chunk = images_per_launch(n, h, w, c1, c2, cout, false, wgrad != 0);
     if (wgrad) {
         WgradPlan p;
-        plan_wgrad(n, h, w, c1, c2, cout, dtype, &p);
+        plan_wgrad(chunk, h, w, c1, c2, cout, dtype, &p);
         return p.specialised && p.g.mos ? p.g.mix : 0;
     }
-    if (map4_ok(n, h, w, c1, c2, cout, cout) || map1_ok(n, h, w, c1, c2, cout, cout)) return 0;
-    if (images_per_launch(n, h, w, c1, c2, cout, false, false) < n || fwd_ws_kind(n, h, w, c1, c2, cout, false) != 2) return 0;
+    if (map4_ok(chunk, h, w, c1, c2, cout, cout) || map1_ok(chunk, h, w, c1, c2, cout, cout)) return 0;
+    if (fwd_ws_kind(chunk, h, w, c1, c2, cout, false) != 2) return 0;
     Geo g;
-    pick_geo(n, h, w, &g);
-    return fwd_mosaic(n, h, w, cout / BN, &g) ? g.mix : 0;
+    pick_geo(chunk, h, w, &g);
+    return fwd_mosaic(chunk, h, w, pad64(cout) / BN, &g) ? g.mix : 0;        // the block count launch_fwd uses
 }
 
 extern "C" size_t ad_conv3x3_fwd_ws_bytes(int n, int h, int w, int cin, int cout, int dtype) {

@@ -376,10 +376,14 @@ __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const T* __restrict__
     }
 }
 
-// gradient goes to the FIRST maximal element of each window (TF MaxPoolGrad); untouched rows/cols get zero
+// gradient goes to the FIRST maximal element of each window (TF MaxPoolGrad); untouched rows/cols get zero.
+// add != NULL (r05): dx = pooling gradient + add, summed in fp32 and rounded once -- the encoder junction "gradient through
+// MaxPooling2D + gradient of the skip connection" (Segmenation/code/train_adaptive_unet.py:349-351,358) in the pass that
+// writes dx (until r04 an accumulating identity ad_resample re-read and re-wrote dx).
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
-                                                           T* __restrict__ dx, int n, int h, int w, int c) {
+                                                           T* __restrict__ dx, int n, int h, int w, int c,
+                                                           const T* __restrict__ add) {
     constexpr int EPT = ElemTraits<T>::EPT;
     const int vecs = c / EPT, oh = h / 2, ow = w / 2;
     const int64_t total = (int64_t)n * h * w * vecs;
@@ -414,6 +418,14 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const T* __restrict__
                     if (win[k][e] > best) { best = win[k][e]; arg = k; }
                 o[e] = arg == me ? g[e] : 0.f;
             }
+        }
+        if (add) {
+            Vec16<T> la;
+            float a8[EPT];
+            la.load(add + p * c + v * EPT);
+            la.to_f32(a8);
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) o[e] += a8[e];
         }
         Vec16<T> st;
         st.from_f32(o);
@@ -794,13 +806,21 @@ extern "C" int ad_maxpool2_fwd(const void* x, void* y, int n, int h, int w, int 
     return AD_OK;
 }
 
+extern "C" int ad_maxpool2_bwd_add(const void* dy, const void* x, const void* add, void* dx, int n, int h, int w, int c, int dtype,
+                                   void* stream);
 extern "C" int ad_maxpool2_bwd(const void* dy, const void* x, void* dx, int n, int h, int w, int c, int dtype, void* stream) {
+    return ad_maxpool2_bwd_add(dy, x, nullptr, dx, n, h, w, c, dtype, stream);
+}
+
+extern "C" int ad_maxpool2_bwd_add(const void* dy, const void* x, const void* add, void* dx, int n, int h, int w, int c, int dtype,
+                                   void* stream) {
     AD_REQUIRE(ad_dtype_ok(dtype), "ad_maxpool2_bwd: bad dtype %d", dtype);
     const int ept = ad_is_half(dtype) ? 8 : 4;
     AD_REQUIRE(n > 0 && h >= 2 && w >= 2 && c > 0 && c % ept == 0, "ad_maxpool2_bwd: bad shape");
     hipStream_t s = (hipStream_t)stream;
     const int blocks = ew_blocks((int64_t)n * h * w * (c / ept));
-    AD_DISPATCH_DTYPE(dtype, T_, maxpool2_bwd_kernel<T_><<<blocks, 256, 0, s>>>((const T_*)dy, (const T_*)x, (T_*)dx, n, h, w, c);)
+    AD_DISPATCH_DTYPE(dtype, T_, maxpool2_bwd_kernel<T_><<<blocks, 256, 0, s>>>((const T_*)dy, (const T_*)x, (T_*)dx, n, h, w, c,
+                                                                                  (const T_*)add);)
     AD_LAUNCH_CHECK("ad_maxpool2_bwd");
     return AD_OK;
 }

@@ -871,11 +871,10 @@ extern "C" int ad_pw_gemm(const void* x, const void* bank, void* y, int64_t m, i
         const int depth = variant;
 #define PL_LAUNCH(E_, NW_, D_)                                                                                       \
     {                                                                                                                \
-        static bool attr_ = false;                                                                                   \
-        if (!attr_) {                                                                                                \
+        static std::atomic<unsigned long long> attr_{0};                                                             \
+        if (ad_first_on_device(attr_)) {                                                                             \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pw_gemm_lds_kernel<E_, NW_, D_>),                \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PlGeo<NW_>::STAGE);            \
-            attr_ = true;                                                                                            \
         }                                                                                                            \
         pw_gemm_lds_kernel<E_, NW_, D_><<<grid, PL_T, 2 * PlGeo<NW_>::STAGE, s>>>(a);                                \
     }
@@ -948,11 +947,10 @@ extern "C" int ad_pw_wgrad(const void* x, const void* dybank, float* dw_hwio, in
     int nsplit;
     pw_wgrad_plan(m, a.k, a.n, &a.mps, &nsplit);
     hipStream_t s = (hipStream_t)stream;
-    static bool attr = false;
-    if (!attr) {
+    static std::atomic<unsigned long long> attr{0};
+    if (ad_first_on_device(attr)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pw_wgrad_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, PWG_LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pw_wgrad_kernel<f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, PWG_LDS);
-        attr = true;
     }
     dim3 grid(nsplit, a.k / PWG_KT, a.n / PWG_NT);
     if (dtype == AD_BF16) pw_wgrad_kernel<bf16_t><<<grid, PWG_T, PWG_LDS, s>>>(a);
@@ -1024,12 +1022,11 @@ extern "C" int ad_upconv_gather_fwd(const void* ybank, const float* bias, void* 
 #define GF_LAUNCH(GW_, NSL_)                                                                                              \
     {                                                                                                                     \
         AD_DISPATCH_DTYPE(dtype, T_,                                                                                      \
-            static std::atomic<bool> big_(false);                                                                         \
-            if (lds > 48 * 1024 && !big_.load(std::memory_order_acquire)) {                                               \
+            static std::atomic<unsigned long long> big_{0};                       /* one bit per device ordinal */        \
+            if (lds > 48 * 1024 && ad_first_on_device(big_)) {                                                            \
                 if (hipFuncSetAttribute(reinterpret_cast<const void*>(upconv_gather_fwd_kernel<T_, GW_, NSL_>),           \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024) != hipSuccess)            \
                     return ad_set_error(AD_ERR_LAUNCH, "ad_upconv_gather_fwd: cannot raise the dynamic LDS limit to %zu bytes", lds); \
-                big_.store(true, std::memory_order_release);                                                              \
             }                                                                                                             \
             upconv_gather_fwd_kernel<T_, GW_, NSL_><<<grid, 256, lds, s>>>(a);)                                           \
     }

@@ -815,6 +815,18 @@ class Model:
                           b1=opt.beta_1, b2=opt.beta_2, eps=opt.epsilon, gscale=gscale)
         self._repack()
 
+    def _publish(self, dev_scalar: torch.Tensor, value: float):
+        """value -> a 1-float device tensor as a stream-ordered host-to-device copy from a ring of page-locked slots (a slot is
+        reused 256 steps later, long after its copy has run).  Until r04 this was `fill_`: a torch elementwise kernel per step,
+        the one framework compute op beside the library's launches."""
+        ring = getattr(self, "_pub_ring", None)
+        if ring is None:
+            ring = self._pub_ring = [torch.empty(256, dtype=torch.float32).pin_memory(), 0]
+        slot = ring[1] % 256
+        ring[1] += 1
+        ring[0][slot] = value
+        dev_scalar.copy_(ring[0][slot:slot + 1], non_blocking=True)
+
     def _begin_step(self, alpha_dev: Optional[torch.Tensor] = None):
         """Host-side bookkeeping before a step: advance the step count and publish the step size / learning rate."""
         opt = self.optimizer
@@ -825,13 +837,13 @@ class Model:
                 # Keras evaluates a schedule at the inner optimizer's `iterations` = APPLIED steps (a step skipped on
                 # overflow does not advance it): read the applied-step count back (one small device -> host copy per step,
                 # only for scheduled learning rates under the float16 policy)
-                sc.lr_dev.fill_(opt.lr_at(int(sc.state[4].item())))
+                self._publish(sc.lr_dev, opt.lr_at(int(sc.state[4].item())))
             else:
-                sc.lr_dev.fill_(opt.lr_at(0))
+                self._publish(sc.lr_dev, opt.lr_at(0))
         else:
             opt.iterations += 1
             if alpha_dev is not None:
-                alpha_dev.fill_(ops.adam_alpha(opt.lr_at(opt.iterations - 1), opt.beta_1, opt.beta_2, opt.iterations))
+                self._publish(alpha_dev, ops.adam_alpha(opt.lr_at(opt.iterations - 1), opt.beta_1, opt.beta_2, opt.iterations))
 
     def forward_loss(self, lr_img, hr_img, keep: bool = False, need_out: bool = True):
         """Forward + fused loss.  Returns (out, loss_mean [device scalar], psnr_mean [device scalar], tape).

@@ -726,11 +726,12 @@ def maxpool2_fwd(x):
     return y
 
 
-def maxpool2_bwd(dy, x):
+def maxpool2_bwd(dy, x, add=None):
+    """add ([n,h,w,c], optional): summed into the result in the same pass (the skip connection's gradient at an encoder junction)."""
     n, h, w, c = x.shape
     dx = torch.empty_like(x)
-    with _timed("maxpool2", 0.0, 2.25 * x.numel() * x.element_size()):
-        check(_lib.load().ad_maxpool2_bwd(_p(dy), _p(x), _p(dx), n, h, w, c, dt(x.dtype), _stream()), "ad_maxpool2_bwd")
+    with _timed("maxpool2", 0.0, (2.25 + (add is not None)) * x.numel() * x.element_size()):
+        check(_lib.load().ad_maxpool2_bwd_add(_p(dy), _p(x), _p(add), _p(dx), n, h, w, c, dt(x.dtype), _stream()), "ad_maxpool2_bwd")
     return dx
 
 

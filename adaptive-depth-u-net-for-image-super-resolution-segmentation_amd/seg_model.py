@@ -386,19 +386,10 @@ class SegModel(Model):
             elif kind == "pool":
                 _, xin, lvl = rec
                 d_in = d
-                dp = ops.maxpool2_bwd(d, xin)
                 skip_grad = dskips.pop(lvl)
-                d = ops.resample(skip_grad, self._identity_tables(xin.shape[1]), out=dp, accumulate=True)
+                d = ops.maxpool2_bwd(d, xin, add=skip_grad)          # pooling gradient + skip gradient, one pass, one rounding
                 if audit is not None:
                     audit.append(("bwd_pool", f"pool{lvl}", xin, d_in, skip_grad, d))
-
-    def _identity_tables(self, h: int):
-        """1-tap identity map: lets ad_resample add the skip gradient into the pooling gradient in place."""
-        key = ("id", h)
-        if key not in self._up_tabs:
-            s, w = np.arange(h, dtype=np.int32), np.ones((h, 1), np.float32)
-            self._up_tabs[key] = ops.ResampleTables(s, w, s, w, self.device)
-        return self._up_tabs[key]
 
     # ------------------------------------------------------------------ Keras call surface
     def _to_dev_mask(self, a) -> torch.Tensor:

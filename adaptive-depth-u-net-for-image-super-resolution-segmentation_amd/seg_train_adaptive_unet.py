@@ -153,12 +153,16 @@ class IsicDataset:
         return math.ceil(len(self.pairs) / self.batch_size)
 
     def _item(self, i: int) -> Tuple[np.ndarray, np.ndarray]:
-        if self._cache is not None and i in self._cache:
-            img, msk8 = self._cache[i]
-            return img, msk8.astype(np.float32)
+        # the lock covers ONE item's cache read / fill (never a whole pass: a producer that is blocked on a full queue
+        # must not keep the next pass's producer out -- ADVICE r04)
+        with self._cache_lock:
+            if self._cache is not None and i in self._cache:
+                img, msk8 = self._cache[i]
+                return img, msk8.astype(np.float32)
         img, msk = load_isic_image(self.pairs[i][0], self.size), load_isic_mask(self.pairs[i][1], self.size)
         if self._cache is not None:
-            self._cache[i] = (img, msk.astype(np.uint8))
+            with self._cache_lock:
+                self._cache[i] = (img, msk.astype(np.uint8))
         return img, msk
 
     def _batches(self, rng: np.random.Generator, order: np.ndarray) -> Iterator[Tuple[np.ndarray, np.ndarray]]:
@@ -188,6 +192,11 @@ class IsicDataset:
         q: "queue.Queue" = queue.Queue(maxsize=self.prefetch)
         done = object()
         stop = threading.Event()       # set when the consumer leaves (break, exception, garbage-collected generator)
+        # one active pass per dataset: a new iteration ends the previous one's producer even if its generator is still referenced
+        prev = getattr(self, "_active_stop", None)
+        if prev is not None:
+            prev.set()
+        self._active_stop = stop
 
         def put(item) -> bool:
             while not stop.is_set():
@@ -200,10 +209,9 @@ class IsicDataset:
 
         def produce():
             try:
-                with self._cache_lock:          # one pass fills / reads the cache at a time (an abandoned pass ends first)
-                    for item in source:
-                        if not put(item):
-                            return
+                for item in source:
+                    if not put(item):
+                        return
                 put(done)
             except BaseException as exc:        # surfaces in the consumer
                 put(exc)
@@ -212,7 +220,12 @@ class IsicDataset:
         worker.start()
         try:
             while True:
-                item = q.get()
+                try:
+                    item = q.get(timeout=0.5)
+                except queue.Empty:
+                    if stop.is_set() and not worker.is_alive():      # superseded by a newer pass over this dataset
+                        raise RuntimeError("IsicDataset: this iteration was ended by a newer iteration over the same dataset")
+                    continue
                 if item is done:
                     return
                 if isinstance(item, BaseException):

@@ -98,7 +98,9 @@ int ad_conv3x3_pack_batch(const void* jobs_dev, int njobs, int nblocks, int dtyp
 /* Images per mosaic row when a bias / bias + ReLU forward or dgrad launch (wgrad = 0; outputs split on a 64-channel block)
  * or a weight-gradient launch (wgrad = 1) of this shape walks the image mosaic -- all n images as one virtual map with a
  * single zero line between neighbours, for maps whose extent is not a multiple of the 16 x 16 tile -- and 0 when it tiles
- * image by image.  Only addresses differ: forward results are bitwise those of the per-image tiling (option "no_mosaic"). */
+ * image by image.  Only addresses differ: forward results are bitwise those of the per-image tiling (option "no_mosaic").
+ * A batch whose tensors reach 2 GiB is launched as runs of images, each planned on its own: the answer then describes the
+ * full-size runs (the last, shorter run may plan differently). */
 int ad_conv3x3_mosaic(int n, int h, int w, int c1, int c2, int cout, int dtype, int wgrad);
 
 /* Conv2D 3x3, stride 1, padding "same" (+bias, +optional ReLU):
@@ -294,6 +296,10 @@ int ad_colsum(const void* x, float* out, int64_t npix, int c, void* ws, size_t w
  * (first maximal element of each window, as TF MaxPoolGrad). y: [n, h/2, w/2, c]. */
 int ad_maxpool2_fwd(const void* x, void* y, int n, int h, int w, int c, int dtype, void* stream);
 int ad_maxpool2_bwd(const void* dy, const void* x, void* dx, int n, int h, int w, int c, int dtype, void* stream);
+/* dx = pooling gradient + add[n,h,w,c] (fp32 sum, one rounding): the encoder junction of the U-Net's backward pass, where the
+ * gradient through MaxPooling2D meets the skip connection's (:349-351,358). */
+int ad_maxpool2_bwd_add(const void* dy, const void* x, const void* add, void* dx, int n, int h, int w, int c, int dtype,
+                        void* stream);
 
 /* Pixel shuffle behind L.Conv2DTranspose(nf, 2, strides=2) (Segmenation/code/unet_vinillia.py:67): the
  * transposed conv is one pointwise GEMM to 4*nf channels (ad_conv3x3_fwd on a 1x1 geometry) followed by

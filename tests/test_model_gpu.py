@@ -183,7 +183,7 @@ def test_r3_config_against_oracle(device, dtype):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("case", [(0.5, 2, 32, 3, "charbonnier"), (0.25, 4, 256, 8, "charbonnier"), (0.6, 3, 40, 2, "l1")])
-def test_train_step_reports_the_loss_and_metric_of_the_forward_pass(device, dtype, case):
+def test_train_step_reports_the_loss_and_metric_of_the_forward_pass(device, dtype, case, monkeypatch):
     """A train step (model.fit, :622-632) returns only loss and PSNR, so it runs NO forward launch over the head: the head's
     backward kernel (ad_head_ln_bwd), which re-derives the output for the gradient anyway, reports both.  They must be the
     numbers of the forward head kernel (checked against the oracle elsewhere) on the same weights: same per-element terms,
@@ -197,7 +197,7 @@ def test_train_step_reports_the_loss_and_metric_of_the_forward_pass(device, dtyp
     rng = np.random.default_rng(9)
     lr, hr = synth(rng, n, p)
     finals = []
-    os.environ["ADUNET_KEEP_HEAD_ACT"] = "1"
+    monkeypatch.setenv("ADUNET_KEEP_HEAD_ACT", "1")         # undone by pytest even when an assert below fails
     for keep_fwd in (False, True):
         model, _ = build_super_resolution_unet(scale, depth_override=depth, input_size=p, dtype=dtype, device=device)
         loss, metrics = build_losses_and_metrics(loss_name)
@@ -215,7 +215,6 @@ def test_train_step_reports_the_loss_and_metric_of_the_forward_pass(device, dtyp
         assert abs(float(got_loss) - want_loss) < 2e-6 * want_loss, (float(got_loss), want_loss)
         assert abs(float(got_psnr) - want_psnr) < 1e-4, (float(got_psnr), want_psnr)
         finals.append(model.P.clone())
-    os.environ.pop("ADUNET_KEEP_HEAD_ACT", None)
     assert torch.equal(finals[0], finals[1])
 
 

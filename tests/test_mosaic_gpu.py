@@ -178,4 +178,5 @@ def test_batches_of_2gib_and_more_take_the_mosaic_run_by_run(device, ws):
         ops.conv3x3_wgrad(x, None, dz, dw0, c, ws)
     assert torch.equal(y, y0)
     assert float((dw - dw0).abs().max() / dw0.abs().max()) < 1e-5
-    assert mosaic_row((n // 2, h, w, c, 0, 128), BF16) > 0 and mosaic_row((n // 2, h, w, c, 0, 128), BF16, wgrad=1) > 0
+    # the query follows the launch path (image runs planned one by one): it is asked about the whole batch
+    assert mosaic_row((n, h, w, c, 0, 128), BF16) > 0 and mosaic_row((n, h, w, c, 0, 128), BF16, wgrad=1) > 0

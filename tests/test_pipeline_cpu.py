@@ -283,3 +283,17 @@ def test_isic_dataset_cache_and_prefetch_give_the_same_stream(tmp_path):
     list(ref_ds)
     want = list(ref_ds)
     assert len(full) == 3 and all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(full, want))
+    # a first iterator that is still REFERENCED (neither closed nor collected) while a second pass starts must not
+    # dead-lock the second pass (its producer used to hold the cache lock for the whole pass while blocked on its full queue)
+    held = S.IsicDataset(pairs, 1, 32, augment=False, shuffle=False, seed=5, prefetch=1)
+    it1 = iter(held)
+    first_item = next(it1)                               # producer 1 is now blocked in put(): queue of 1 is full
+    done = []
+    t = threading.Thread(target=lambda: done.append(list(held)), daemon=True)
+    t.start()
+    t.join(timeout=20.0)
+    assert not t.is_alive() and len(done) == 1 and len(done[0]) == 5        # the second pass ran to completion
+    with pytest.raises((RuntimeError, StopIteration)):   # the superseded iterator ends instead of hanging
+        for _ in range(10):
+            next(it1)
+    assert first_item[0].shape == (1, 32, 32, 3)

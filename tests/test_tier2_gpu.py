@@ -123,6 +123,11 @@ def test_maxpool2(device, dtype, hw):
     assert relerr(y, ref.maxpool2_fwd(x)) == 0.0
     dy = rnd(rng.standard_normal(tuple(y.shape)), dtype)
     assert relerr(ops.maxpool2_bwd(to_dev(dy, dtype, device), xd), ref.maxpool2_bwd(dy, x)) == 0.0
+    # the encoder junction: pooling gradient + skip gradient in one pass, summed in fp32 and rounded once
+    skip = rnd(rng.standard_normal(x.shape), dtype)
+    got = ops.maxpool2_bwd(to_dev(dy, dtype, device), xd, add=to_dev(skip, dtype, device))
+    want = rnd(ref.maxpool2_bwd(dy, x) + skip, dtype)
+    assert relerr(got, want) == 0.0
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])

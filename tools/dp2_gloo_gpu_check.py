@@ -50,7 +50,7 @@ def scaler_state(m):
     sc = m._scaler()
     return sc.state.clone() if sc is not None else torch.zeros(8, device=dev)
 
-results = {}
+results, g0 = {}, {}
 for mode in ("eager", "graph"):
     m = make()
     DataParallel(m, bucket_bytes=1 << 18)
@@ -59,10 +59,14 @@ for mode in ("eager", "graph"):
         step = m.make_graphed_train_step(batches[0][0][sl], batches[0][1][sl], capture_only=True)
     else:
         step = m.train_on_batch
-    for lr, hr in batches:
+    for k, (lr, hr) in enumerate(batches):
         step(lr[sl], hr[sl])
+        if k == 0:
+            torch.cuda.synchronize()
+            g0[mode] = m.G.clone()           # the all-reduced (summed) flat gradient of step 0, before any optimizer effect
     torch.cuda.synchronize()
     results[mode] = (m.P.clone(), scaler_state(m))
+    index = m.index
     del m, step
 
 # every rank must hold the same weights and the same scaler state (bitwise): compare through rank 0
@@ -79,10 +83,28 @@ for mode, (p, st) in results.items():
 ref = None
 if rank == 0:
     m = make()                               # one process, whole batch
-    for lr, hr in batches:
+    for k, (lr, hr) in enumerate(batches):
         m.train_on_batch(lr, hr)
+        if k == 0:
+            torch.cuda.synchronize()
+            ref_g0 = m.G.clone()
     torch.cuda.synchronize()
     ref, ref_state = m.P.clone(), scaler_state(m)
+    # The exchange itself, BEFORE Adam (which normalises magnitudes and would hide a dropped or mis-scaled bucket behind its
+    # one-step bound -- ADVICE r04): the summed gradient of step 0 over the ranks / world against the single process's, per
+    # parameter tensor, relative to that tensor's largest gradient.  fp32: summation order; 16-bit: stored roundings of
+    # activations that differ between a 2-image and a 4-image launch (a dropped bucket reads 1.0, a missing 1 / world 1.0 too)
+    gtol = 1e-4 if dtype == torch.float32 else 5e-2
+    for mode, g in g0.items():
+        worst, where = 0.0, None
+        for name, (off, shape) in index.items():
+            cnt = int(np.prod(shape))
+            a, b = g[off:off + cnt] / world, ref_g0[off:off + cnt]
+            e = float((a - b).abs().max() / (b.abs().max() + 1e-30))
+            if e > worst:
+                worst, where = e, name
+        print(f"{mode}: step-0 gradient, worst tensor {where}: max |G_dp / world - G_single| / max|G_single| = {worst:.3e}", flush=True)
+        ok &= worst < gtol
     # fp32: summation order of the two halves only.  16-bit: a rank's launches see 2 images, the single process 4 -- other tile
     # geometries / split factors, i.e. another fp32 accumulation order inside the convolutions, which flips stored 16-bit
     # roundings and cascades; where a gradient element is noise, Adam's g / sqrt(v) turns that into up to a whole
