@@ -39,6 +39,56 @@ class EarlyStopping(Callback):
                     self.model._repack()
 
 
+class ReduceLROnPlateau(Callback):
+    """tf.keras.callbacks.ReduceLROnPlateau(monitor="val_loss", factor, patience, min_lr) as the vanilla segmentation baseline
+    uses it (Segmenation/code/unet_vinillia.py:283): when `monitor` has not improved by more than `min_delta` for `patience`
+    epochs the optimizer's learning rate is multiplied by `factor` (not below `min_lr`), then `cooldown` epochs pass before
+    the count resumes.  The optimizer must hold a plain float learning rate (Keras raises for a schedule as well); the new
+    value reaches the kernels with the next step's step-size publication, also under graph replay."""
+
+    def __init__(self, monitor="val_loss", factor=0.1, patience=10, verbose=0, mode="auto", min_delta=1e-4, cooldown=0, min_lr=0.0):
+        if factor >= 1.0:
+            raise ValueError("ReduceLROnPlateau does not support a factor >= 1.0.")
+        if mode not in ("auto", "min", "max"):
+            mode = "auto"
+        self.monitor, self.factor, self.patience, self.verbose = monitor, factor, patience, verbose
+        self.min_delta, self.cooldown, self.min_lr = min_delta, cooldown, min_lr
+        self.mode = ("max" if "acc" in monitor else "min") if mode == "auto" else mode
+        self.on_train_begin({})
+
+    def on_train_begin(self, logs):
+        self.best = math.inf if self.mode == "min" else -math.inf
+        self.wait = self.cooldown_counter = 0
+
+    def _improved(self, v):
+        return v < self.best - self.min_delta if self.mode == "min" else v > self.best + self.min_delta
+
+    def on_epoch_end(self, epoch, logs):
+        opt = self.model.optimizer
+        inner = getattr(opt, "inner_optimizer", opt)                   # LossScaleOptimizer wraps the Adam that holds the rate
+        if callable(inner.learning_rate):
+            raise TypeError("ReduceLROnPlateau needs a float learning rate, not a schedule")
+        logs["learning_rate"] = float(inner.learning_rate)
+        v = logs.get(self.monitor)
+        if v is None:
+            return
+        if self.cooldown_counter > 0:
+            self.cooldown_counter -= 1
+            self.wait = 0
+        if self._improved(v):
+            self.best, self.wait = v, 0
+        elif self.cooldown_counter <= 0:
+            self.wait += 1
+            if self.wait >= self.patience:
+                old = float(inner.learning_rate)
+                if old > self.min_lr:
+                    inner.learning_rate = max(old * self.factor, self.min_lr)
+                    if self.verbose:
+                        print(f"\nEpoch {epoch + 1}: ReduceLROnPlateau reducing learning rate to {inner.learning_rate}.")
+                    self.cooldown_counter = self.cooldown
+                    self.wait = 0
+
+
 class ModelCheckpoint(Callback):
     """ModelCheckpoint(filepath, monitor="val_loss", save_best_only=True) writing flat .safetensors files."""
 

@@ -465,14 +465,19 @@ __device__ __forceinline__ float gsum2(float v) {
     return v;
 }
 
-template <typename T, int G>
+// COUNTS: six more per-sample sums for the vanilla baseline's Keras metrics (Segmenation/code/unet_vinillia.py:266-271:
+// BinaryAccuracy / Precision / Recall at threshold 0.5 and its global dice_coefficient on the UNCLIPPED probability, :94-99):
+//   [3] = sum [p > .5] y (true positives), [4] = sum [p > .5], [5] = sum y, [6] = sum [(p > .5) == (y > .5)], [7] = sum y p, [8] = sum (y + p)
+template <typename T, int G, bool COUNTS = false>
 __global__ __launch_bounds__(256) void seg_head_fwd_kernel(const T* __restrict__ xh, const float* __restrict__ w,
                                                            const float* __restrict__ b, const float* __restrict__ target,
                                                            float* __restrict__ prob, float* __restrict__ part, int64_t ppi,
                                                            int ch) {
     constexpr int EPT = ElemTraits<T>::EPT;
     constexpr int PPB = 256 / G;
-    __shared__ float sm[3][4];
+    constexpr int NS = COUNTS ? 9 : 3;
+    __shared__ float sm[NS][4];
+    float cnt[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int tid = threadIdx.x, gl = tid % G, gp = tid / G;
     const int img = blockIdx.y;
     float wl[EPT];
@@ -499,28 +504,45 @@ __global__ __launch_bounds__(256) void seg_head_fwd_kernel(const T* __restrict__
                 s0 += -(y * __logf(pc) + (1.f - y) * __logf(1.f - pc));
                 s1 += y * pc;
                 s2 += y + pc;
+                if (COUNTS) {
+                    const bool pos = p > 0.5f, truth = y > 0.5f;
+                    cnt[0] += pos && truth ? 1.f : 0.f;
+                    cnt[1] += pos ? 1.f : 0.f;
+                    cnt[2] += truth ? 1.f : 0.f;
+                    cnt[3] += pos == truth ? 1.f : 0.f;
+                    cnt[4] += y * p;
+                    cnt[5] += y + p;
+                }
             }
         }
     }
-    float v[3] = {s0, s1, s2};
+    float v[NS];
+    v[0] = s0; v[1] = s1; v[2] = s2;
+    if (COUNTS) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
+        for (int k = 0; k < 6; ++k) v[3 + (k < NS - 3 ? k : 0)] = cnt[k];
+    }
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o, 64);
         if ((tid & 63) == 0) sm[k][tid >> 6] = v[k];
     }
     __syncthreads();
-    if (tid < 3 && part)
-        part[((size_t)img * gridDim.x + blockIdx.x) * 3 + tid] = sm[tid][0] + sm[tid][1] + sm[tid][2] + sm[tid][3];
+    if (tid < NS && part)
+        part[((size_t)img * gridDim.x + blockIdx.x) * NS + tid] = sm[tid][0] + sm[tid][1] + sm[tid][2] + sm[tid][3];
 }
 
-__global__ void seg_sums_kernel(const float* __restrict__ part, int n, int bpi, float* __restrict__ sums) {
+// sums[img][0..3) (and counts[img][0..6) when the partial rows have 9 columns) = column sums of part[img][0..bpi)
+__global__ void seg_sums_kernel(const float* __restrict__ part, int n, int bpi, float* __restrict__ sums, int ncol,
+                                float* __restrict__ counts) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n * 3) return;
-    int img = i / 3, k = i % 3;
+    if (i >= n * ncol) return;
+    int img = i / ncol, k = i % ncol;
     float s = 0.f;
-    for (int j = 0; j < bpi; ++j) s += part[((size_t)img * bpi + j) * 3 + k];
-    sums[i] = s;
+    for (int j = 0; j < bpi; ++j) s += part[((size_t)img * bpi + j) * ncol + k];
+    if (k < 3) sums[img * 3 + k] = s;
+    else counts[img * 6 + k - 3] = s;
 }
 
 // backward: dL/dp = wb * dBCE/dp / count + wd * (-(1/n) * d dice_n / dp); dlogit = dL/dp * p (1 - p)
@@ -898,24 +920,41 @@ static int seg_bpi(int64_t ppi, int g) {
 
 extern "C" size_t ad_seg_head_ws_bytes(int n, int ch) { return (size_t)n * 64 * (ch + 3) * sizeof(float); }
 
+extern "C" int ad_seg_head_fwd_counts(const void* xh, const float* w, const float* b, const float* target, float* prob,
+                                      float* sums, float* counts, int n, int64_t pix_per_img, int ch, void* ws, size_t ws_bytes,
+                                      int dtype, void* stream);
+
 extern "C" int ad_seg_head_fwd(const void* xh, const float* w, const float* b, const float* target, float* prob, float* sums,
                                int n, int64_t pix_per_img, int ch, void* ws, size_t ws_bytes, int dtype, void* stream) {
+    return ad_seg_head_fwd_counts(xh, w, b, target, prob, sums, nullptr, n, pix_per_img, ch, ws, ws_bytes, dtype, stream);
+}
+
+extern "C" int ad_seg_head_fwd_counts(const void* xh, const float* w, const float* b, const float* target, float* prob,
+                                      float* sums, float* counts, int n, int64_t pix_per_img, int ch, void* ws, size_t ws_bytes,
+                                      int dtype, void* stream) {
     AD_REQUIRE(ad_dtype_ok(dtype), "ad_seg_head_fwd: bad dtype %d", dtype);
     int g;
     AD_REQUIRE(n > 0 && pix_per_img > 0 && seg_group(ch, ad_is_half(dtype) ? 8 : 4, &g), "ad_seg_head_fwd: unsupported shape ch=%d", ch);
+    AD_REQUIRE(!counts || (target && sums), "ad_seg_head_fwd_counts: counts need a target and sums");
     const int bpi = seg_bpi(pix_per_img, g);
+    const int ncol = counts ? 9 : 3;
     float* part = nullptr;
     if (target) {
-        if (!ws || ws_bytes < (size_t)n * bpi * 3 * sizeof(float)) return ad_set_error(AD_ERR_WS, "ad_seg_head_fwd: workspace too small");
+        if (!ws || ws_bytes < (size_t)n * bpi * ncol * sizeof(float)) return ad_set_error(AD_ERR_WS, "ad_seg_head_fwd: workspace too small");
         part = (float*)ws;
     }
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(bpi, n);
-    AD_DISPATCH_DTYPE(dtype, T_,
-        SEG_DISPATCH(seg_head_fwd_kernel<T_, G_><<<grid, 256, 0, s>>>((const T_*)xh, w, b, target, prob, part, pix_per_img, ch);))
+    if (counts) {
+        AD_DISPATCH_DTYPE(dtype, T_,
+            SEG_DISPATCH((seg_head_fwd_kernel<T_, G_, true><<<grid, 256, 0, s>>>((const T_*)xh, w, b, target, prob, part, pix_per_img, ch));))
+    } else {
+        AD_DISPATCH_DTYPE(dtype, T_,
+            SEG_DISPATCH((seg_head_fwd_kernel<T_, G_><<<grid, 256, 0, s>>>((const T_*)xh, w, b, target, prob, part, pix_per_img, ch));))
+    }
     AD_LAUNCH_CHECK("ad_seg_head_fwd");
     if (target) {
-        seg_sums_kernel<<<(n * 3 + 255) / 256, 256, 0, s>>>(part, n, bpi, sums);
+        seg_sums_kernel<<<(n * ncol + 255) / 256, 256, 0, s>>>(part, n, bpi, sums, ncol, counts);
         AD_LAUNCH_CHECK("seg_sums");
     }
     return AD_OK;

@@ -1051,8 +1051,13 @@ class Model:
                 break
         if nb == 0:
             raise ValueError("evaluate() received an empty dataset")
-        res = {k: float(v) / nb for k, v in zip(keys, tot)}
+        res = self._reduce_logs(keys, tot, nb)
         return res if return_dict else [res[k] for k in keys]
+
+    def _reduce_logs(self, keys, totals, nbatches) -> dict:
+        """Epoch value of every metric from the per-batch values summed over the epoch: Keras' Mean (the loss and every
+        function metric).  Models with ratio metrics (Precision / Recall: running sums) override this."""
+        return {k: float(v) / nbatches for k, v in zip(keys, totals)}
 
     def _fit_step(self, lr_img, hr_img):
         """One training step of fit(): replayed from a hipGraph captured per batch shape on the GPU (bitwise the eager
@@ -1118,12 +1123,13 @@ class Model:
                 it = iter(dataset)
             if nb == 0:
                 raise ValueError("fit() received an empty dataset")
-            logs = {k: float(v) / nb for k, v in zip(keys, tot)}
+            logs = self._reduce_logs(keys, tot, nb)
             if validation_data is not None:
                 if val_it is not None:
                     vl = [self.test_on_batch(*next(val_it)[:2]) for _ in range(validation_steps)]
-                    for i, k in enumerate(keys):
-                        logs["val_" + k] = float(sum(v[i] for v in vl)) / len(vl)
+                    vres = self._reduce_logs(keys, [sum(v[i] for v in vl) for i in range(len(vl[0]))], len(vl))
+                    for k in keys:
+                        logs["val_" + k] = vres[k]
                 else:
                     res = self.evaluate(validation_data, return_dict=True)
                     for k in keys:

@@ -789,16 +789,20 @@ def conv_transpose2x2s2_bwd(x, dy, w_dgrad, dw_t: torch.Tensor, db: torch.Tensor
     return dx
 
 
-def seg_head_fwd(xh, w, b, target, ws: Workspace):
-    """Returns (prob [n,h,w,1] fp32, sums [n,3] or None)."""
+def seg_head_fwd(xh, w, b, target, ws: Workspace, counts: bool = False):
+    """Returns (prob [n,h,w,1] fp32, sums [n,3] or None); counts=True: sums is [n,9], columns 3.. = the thresholded counts
+    and unclipped dice sums of ad_seg_head_fwd_counts (the vanilla baseline's Keras metrics)."""
     n, h, wd, ch = xh.shape
     prob = torch.empty((n, h, wd, 1), dtype=torch.float32, device=xh.device)
     sums = torch.empty((n, 3), dtype=torch.float32, device=xh.device) if target is not None else None
+    cnt = torch.empty((n, 6), dtype=torch.float32, device=xh.device) if (counts and target is not None) else None
     lib = _lib.load()
     ws.ensure(lib.ad_seg_head_ws_bytes(n, ch))
     with _timed("seg_head_fwd", 0.0, float(xh.numel() * xh.element_size() + n * h * wd * (8 if target is not None else 4))):
-        check(lib.ad_seg_head_fwd(_p(xh), _p(w), _p(b), _p(target), _p(prob), _p(sums), n, h * wd, ch, ws.ptr, ws.nbytes,
-                                  dt(xh.dtype), _stream()), "ad_seg_head_fwd")
+        check(lib.ad_seg_head_fwd_counts(_p(xh), _p(w), _p(b), _p(target), _p(prob), _p(sums), _p(cnt), n, h * wd, ch, ws.ptr,
+                                         ws.nbytes, dt(xh.dtype), _stream()), "ad_seg_head_fwd")
+    if cnt is not None:
+        return prob, (sums, cnt)
     return prob, sums
 
 

@@ -87,6 +87,9 @@ def build_optimizer(protocol: ProtocolConfig, steps_per_epoch: int, epochs: int)
     return Adam(learning_rate=protocol.initial_lr)
 
 
+BASELINE_METRICS = ("accuracy", "precision", "recall", "dice_coefficient")      # Segmenation/code/unet_vinillia.py:266-271
+
+
 class SegModel(Model):
     """U-Net for binary masks; norm in {"bn", "ln"}, up in {"bilinear", "convT"}."""
 
@@ -321,7 +324,10 @@ class SegModel(Model):
                 self.audit.append(("fwd_softmax_head", self.head_name, x, prob))
             return prob, None, tape
         w = self.param(self.head_name + "/kernel").view(self.head_channels)
-        prob, sums = ops.seg_head_fwd(x, w, self.param(self.head_name + "/bias"), mask, self._ws)
+        prob, sums = ops.seg_head_fwd(x, w, self.param(self.head_name + "/bias"), mask, self._ws,
+                                      counts=getattr(self, "_baseline_metrics", False))
+        if isinstance(sums, tuple):              # (sums [n,3], counts [n,6]): the counts feed the vanilla baseline's metrics only
+            sums, self._last_counts = sums
         if keep:
             tape.append(("head", x, prob, sums))
         if self.audit is not None:
@@ -421,13 +427,60 @@ class SegModel(Model):
         self.optimizer = self._wrap_optimizer(optimizer if optimizer is not None else Adam())
         self.loss = loss
         self.metrics_names = ["loss", "dice", "iou"]
+        # metrics=[...] naming accuracy / precision / recall / dice_coefficient (strings, or objects / functions with such a
+        # `name` / `__name__`): the vanilla baseline's set, Segmenation/code/unet_vinillia.py:266-271
+        names = [m if isinstance(m, str) else getattr(m, "name", getattr(m, "__name__", "")) for m in (metrics or [])]
+        self._baseline_metrics = any(n in BASELINE_METRICS for n in names)
+        if self._baseline_metrics:
+            unknown = [n for n in names if n not in BASELINE_METRICS]
+            if unknown:
+                raise ValueError(f"unknown metrics {unknown}: the baseline set is {list(BASELINE_METRICS)}")
+            self.metrics_names = ["loss"] + [n for n in BASELINE_METRICS if n in names]
 
     def _metrics_from(self, sums: torch.Tensor, count: float, smooth: float = 1e-6):
+        if getattr(self, "_baseline_metrics", False):
+            return self._baseline_metrics_from(sums, count, smooth)
         bce = sums[:, 0].sum() / count
         dice = ((2.0 * sums[:, 1] + smooth) / (sums[:, 2] + smooth)).mean()
         iou = ((sums[:, 1] + smooth) / (sums[:, 2] - sums[:, 1] + smooth)).mean()       # :272-281
         loss = self.loss.bce_weight * bce + self.loss.dice_weight * (1.0 - dice)
         return loss, dice, iou
+
+    def _baseline_metrics_from(self, sums: torch.Tensor, count: float, smooth: float):
+        """The vanilla baseline's per-batch values (unet_vinillia.py:266-271) followed by the running sums Keras' stateful
+        metrics keep: (loss, accuracy, precision, recall, dice_coefficient | correct, elements, tp, predicted positives,
+        positives).  `_reduce_logs` forms the epoch values: BinaryAccuracy = sum correct / sum elements, Precision = sum tp /
+        sum predicted, Recall = sum tp / sum positives (all over the epoch, as Keras accumulates them), loss and the function
+        metric dice_coefficient (global over the batch, smooth 1e-6, unclipped probability: :94-99) as batch means."""
+        c = self._last_counts.sum(dim=0)                              # [tp, pp, pos, correct, sum y p, sum (y + p)]
+        bce = sums[:, 0].sum() / count
+        dice_b = ((2.0 * sums[:, 1] + smooth) / (sums[:, 2] + smooth)).mean()
+        loss = self.loss.bce_weight * bce + self.loss.dice_weight * (1.0 - dice_b)
+        tiny = 1e-7                                                   # Keras: divide_no_nan -> 0 when the denominator is 0
+        acc = c[3] / count
+        prec = torch.where(c[1] > 0, c[0] / torch.clamp(c[1], min=tiny), torch.zeros_like(c[0]))
+        rec = torch.where(c[2] > 0, c[0] / torch.clamp(c[2], min=tiny), torch.zeros_like(c[0]))
+        dice = (2.0 * c[4] + smooth) / (c[5] + smooth)
+        vals = {"loss": loss, "accuracy": acc, "precision": prec, "recall": rec, "dice_coefficient": dice}
+        cnt = torch.full_like(c[0], float(count))
+        return tuple(vals[k] for k in self.metrics_names) + (c[3], cnt, c[0], c[1], c[2])
+
+    def _reduce_logs(self, keys, totals, nbatches) -> dict:
+        if not getattr(self, "_baseline_metrics", False):
+            return Model._reduce_logs(self, keys, totals, nbatches)
+        k = len(self.metrics_names)
+        correct, elems, tp, pp, pos = (float(v) for v in totals[k:k + 5])
+        out = {}
+        for name, tot in zip(self.metrics_names, totals):
+            if name == "accuracy":
+                out[name] = correct / elems if elems > 0 else 0.0
+            elif name == "precision":
+                out[name] = tp / pp if pp > 0 else 0.0
+            elif name == "recall":
+                out[name] = tp / pos if pos > 0 else 0.0
+            else:
+                out[name] = float(tot) / nbatches
+        return out
 
     def train_on_batch(self, img, mask):
         if self.optimizer is None:

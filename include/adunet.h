@@ -312,6 +312,13 @@ int ad_pixel_shuffle2(const void* x, void* y, int n, int h, int w, int c, int to
 size_t ad_seg_head_ws_bytes(int n, int ch);
 int ad_seg_head_fwd(const void* xh, const float* w, const float* b, const float* target, float* prob, float* sums,
                     int n, int64_t pix_per_img, int ch, void* ws, size_t ws_bytes, int dtype, void* stream);
+/* ad_seg_head_fwd plus counts[n][6] for the vanilla baseline's Keras metrics (Segmenation/code/unet_vinillia.py:266-271:
+ * BinaryAccuracy / Precision / Recall at threshold 0.5, and its dice_coefficient on the unclipped probability, :94-99):
+ *   counts[img] = { sum [p > .5] y, sum [p > .5], sum y, sum [(p > .5) == (y > .5)], sum y p, sum (y + p) }.
+ * counts == NULL is ad_seg_head_fwd. */
+int ad_seg_head_fwd_counts(const void* xh, const float* w, const float* b, const float* target, float* prob,
+                           float* sums, float* counts, int n, int64_t pix_per_img, int ch,
+                           void* ws, size_t ws_bytes, int dtype, void* stream);
 int ad_seg_head_bwd(const void* xh, const float* w, const float* target, const float* prob, const float* sums,
                     void* dxh, float* dw, float* db, int n, int64_t pix_per_img, int ch,
                     float bce_weight, float dice_weight, float smooth,

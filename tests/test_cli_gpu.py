@@ -117,6 +117,57 @@ def test_segmentation_train_entry_point(device, tmp_path):
         T.train(T.parse_args(["--protocol", "A"]))
 
 
+def test_vanilla_segmentation_baseline_entry_point(device, tmp_path):
+    """Segmenation/code/unet_vinillia.py:236-293 end to end on a synthetic folder: BinaryCrossentropy, the four Keras metrics
+    (accuracy / precision / recall as running sums over the epoch, dice_coefficient as a batch mean), checkpoints on
+    val_dice_coefficient, ReduceLROnPlateau's learning-rate log; and one batch's metric values against NumPy on the model's
+    own probabilities."""
+    from PIL import Image
+    from adunet_amd import seg_unet_vinillia as V
+    rng = np.random.default_rng(0)
+    folders = {}
+    for split, n in (("train", 6), ("val", 3)):
+        for kind in ("img", "mask"):
+            folders[(split, kind)] = tmp_path / f"{split}_{kind}"
+            folders[(split, kind)].mkdir()
+        for i in range(n):
+            m = np.zeros((48, 48), np.uint8)
+            m[8 + i: 30, 10: 28 + i] = 255
+            img = (rng.random((48, 48, 3)) * 80 + m[..., None] * 0.5).astype(np.uint8)
+            Image.fromarray(img).save(folders[(split, "img")] / f"ISIC_{i:07d}.jpg")
+            Image.fromarray(m).save(folders[(split, "mask")] / f"ISIC_{i:07d}_segmentation.png")
+    argv = ["--epochs", "2", "--batch_size", "4", "--depth", "2", "--image_size", "32", "--base_channels", "32", "--augment",
+            "--train_image_dir", str(folders[("train", "img")]), "--train_mask_dir", str(folders[("train", "mask")]),
+            "--val_image_dir", str(folders[("val", "img")]), "--val_mask_dir", str(folders[("val", "mask")]),
+            "--model_dir", str(tmp_path / "models"), "--run_name", "vanilla", "--fit_verbose", "0"]
+    model, history = V.train(V.parse_args(argv))
+    keys = {"loss", "accuracy", "precision", "recall", "dice_coefficient"}
+    assert history.epoch == [0, 1] and keys | {"val_" + k for k in keys} | {"learning_rate"} <= set(history.history)
+    assert history.history["learning_rate"] == [1e-4, 1e-4]
+    assert all(0.0 <= history.history[k][-1] <= 1.0 for k in keys - {"loss"})
+    assert (tmp_path / "models" / "vanilla_best.safetensors").exists() and (tmp_path / "models" / "vanilla_final.safetensors").exists()
+    assert model.name == "unet_isic_baseline" and model.metrics_names == ["loss", "accuracy", "precision", "recall", "dice_coefficient"]
+    # one batch against NumPy on the probabilities the model itself returns
+    val = V.build_dataset(V._discover_pairs(folders[("val", "img")], folders[("val", "mask")], ".jpg", "_segmentation.png", None),
+                          32, 3, shuffle=False, augment=False, seed=0)
+    img, mask = next(iter(val))
+    got = [float(v) for v in model.test_on_batch(img, mask)]
+    p = model(img).astype(np.float64)
+    pos, truth = p > 0.5, mask > 0.5
+    pc = np.clip(p, 1e-7, 1 - 1e-7)
+    want = [float(np.mean(-(mask * np.log(pc) + (1 - mask) * np.log(1 - pc)))), float(np.mean(pos == truth)),
+            float((pos & truth).sum() / max(pos.sum(), 1)), float((pos & truth).sum() / max(truth.sum(), 1)),
+            V.dice_coefficient(mask, p)]
+    assert np.allclose(got[:5], want, rtol=2e-4, atol=2e-5), (got[:5], want)
+    assert got[5:] == [float((pos == truth).sum()), float(mask.size), float((pos & truth).sum()), float(pos.sum()), float(truth.sum())]
+    res = model.evaluate(val, return_dict=True)
+    assert list(res) == model.metrics_names and res["accuracy"] == pytest.approx(want[1], abs=1e-6)
+    with pytest.raises(FileNotFoundError):
+        V.train(V.parse_args([]))
+    with pytest.raises(ValueError, match="unknown metrics"):
+        model.compile(optimizer=None, loss=V.binary_crossentropy(), metrics=["accuracy", "auc"])
+
+
 def test_bench_plain_and_under_torchrun_agree(device):
     """The driver starts N = 1 as `python bench.py --gpus 1 ...` and N > 1 through torch.distributed.run: both start-up
     paths must run and report the same workload (throughput within 5 %; at world size 1 the second goes through RCCL,
