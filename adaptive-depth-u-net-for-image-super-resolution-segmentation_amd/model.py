@@ -1140,12 +1140,14 @@ class Model:
                 step_txt = f"{ms:.0f}ms/step" if ms >= 1 else f"{ms * 1000:.0f}us/step"
                 print(f"{nb}/{nb} - {dt:.0f}s - {step_txt} - " + " - ".join(f"{k}: {v:.4f}" for k, v in logs.items()),
                       flush=True)
-            hist.epoch.append(epoch)
-            for k, v in logs.items():
-                hist.history.setdefault(k, []).append(v)
             for cb in callbacks:
                 if hasattr(cb, "on_epoch_end"):
                     cb.on_epoch_end(epoch, logs)
+            # Keras' History is itself a callback and runs LAST: keys a callback adds to `logs` (ReduceLROnPlateau's
+            # `learning_rate`) are part of the history
+            hist.epoch.append(epoch)
+            for k, v in logs.items():
+                hist.history.setdefault(k, []).append(v)
             if self.stop_training:
                 break
         for cb in callbacks:
