@@ -423,6 +423,16 @@ class Model:
                 opt.iterations = int(state["optimizer/iterations"][0])
 
     def save_weights(self, path: str, include_optimizer: bool = True):
+        """`.safetensors`: weights under their Keras variable names (+ `optimizer/...` training state).  `.weights.h5` /
+        `.keras`: Keras 3's own layouts, written without h5py (keras_archive.py: interchange unpinned) -- weights and
+        BatchNorm moving statistics only, as `model.load_weights` reads them."""
+        path = str(path)
+        if path.endswith(".keras"):
+            from . import keras_archive
+            return keras_archive.save_keras(self, path)
+        if path.endswith(".h5"):
+            from . import keras_archive
+            return keras_archive.save_weights_h5(self, path)
         from safetensors.numpy import save_file
         tensors = {k: np.ascontiguousarray(v) for k, v in self.get_weights().items()}
         if include_optimizer and self.optimizer is not None:
@@ -430,9 +440,15 @@ class Model:
         save_file(tensors, str(path), metadata={"model": self.name, "format": "adunet_amd-flat-v2",
                                                 "compute_dtype": str(self.dtype).replace("torch.", "")})
 
+    def save(self, path: str):
+        """`model.save(path)` (Segmenation/code/unet_vinillia.py:292; ModelCheckpoint(save_weights_only=False), :276)."""
+        self.save_weights(path)
+
     def load_weights(self, path: str, restore_optimizer: bool = False):
         """Weights by Keras variable name (as `model.load_weights`).  restore_optimizer: also the Adam moments, iteration
-        count and loss scaler when the file has them, so that training continues its trajectory bit for bit."""
+        count and loss scaler when the file has them, so that training continues its trajectory bit for bit.
+        `.keras` / `.h5`: Keras-3 archives and weight files (train_adaptive_unet.py:511-516, evaluate_model.py:79-91), read
+        without h5py by keras_archive.py -- weights only, which is all Keras' `load_weights` restores."""
         path = str(path)
         if path.endswith(".safetensors"):
             from safetensors.numpy import load_file
@@ -446,8 +462,8 @@ class Model:
                 if restore_optimizer and "optimizer/iterations" in z.files:
                     self.set_training_state({k: z[k] for k in z.files})
         elif path.endswith(".keras") or path.endswith(".h5"):
-            raise RuntimeError("Keras .keras/.h5 archives need h5py, which is not available in this image; "
-                               "convert to .safetensors/.npz with the Keras layer names as keys")
+            from . import keras_archive
+            keras_archive.load_into(self, path)
         else:
             raise RuntimeError(f"unsupported checkpoint format: {path}")
 

@@ -86,7 +86,8 @@ def train(args: argparse.Namespace):
     if args.resume_from:
         resume = Path(args.resume_from).expanduser()
         if resume.is_dir():
-            cands = sorted(resume.glob("*.safetensors"), key=lambda p: p.stat().st_mtime)
+            # the reference looks for its `.keras` archives (:500); this build's own checkpoints are `.safetensors`: newest of either
+            cands = sorted(list(resume.glob("*.safetensors")) + list(resume.glob("*.keras")), key=lambda p: p.stat().st_mtime)
             if not cands:
                 raise FileNotFoundError(f"No checkpoints found in {resume}")
             resume = cands[-1]

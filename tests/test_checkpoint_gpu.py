@@ -105,3 +105,55 @@ def test_backup_and_restore_resumes_an_interrupted_fit(device, tmp_path):
     assert hist.epoch == [2, 3]
     assert torch.equal(fresh.P, straight.P)
     assert not (tmp_path / "bk" / "backup.safetensors").exists()   # removed after a completed fit, as Keras does
+
+
+@pytest.mark.parametrize("suffix", [".keras", ".weights.h5"])
+def test_keras_archive_round_trip_of_a_trained_model(device, tmp_path, suffix):
+    """the reference's checkpoints are Keras-3 `.keras` archives (train_adaptive_unet.py:531,617) that
+    `--resume_from` / evaluate_model read back with `load_weights` (:511-516, evaluate_model.py:79-91).  Written and read here
+    without h5py (keras_archive.py, hdf5_min.py -- INTERCHANGE UNPINNED: no real archive exists to read): a trained model's
+    weights go through the archive bit for bit, Keras' `load_weights` semantics (weights only, the optimizer restarts)."""
+    rng = np.random.default_rng(4)
+    batches = [synth(rng, 3, 32) for _ in range(3)]
+    first = sr_model(device, torch.bfloat16)
+    for b in batches:
+        first.train_on_batch(*b)
+    path = tmp_path / ("unet_adaptive_scale_new_loss0.50_depth2" + suffix)
+    first.save(path) if suffix == ".keras" else first.save_weights(path)
+    other = sr_model(device, torch.bfloat16)
+    assert not torch.equal(other.P, first.P)
+    other.load_weights(path)
+    assert torch.equal(other.P, first.P) and int(other.optimizer.iterations) == 0 and float(other.M.abs().max()) == 0.0
+    lr, _ = batches[0]
+    assert np.array_equal(other(lr), first(lr))
+    if suffix == ".keras":
+        from adunet_amd import keras_archive
+        info = keras_archive.describe(path)
+        assert info["model_name"] == "U-Net_SR_scale0.50_depth2" and info["metadata"]["keras_version"] == "3.3.3"
+    deeper, _ = __import__("adunet_amd.model", fromlist=["x"]).build_super_resolution_unet(0.5, depth_override=3, input_size=32,
+                                                                                           dtype=torch.bfloat16, device=device)
+    with pytest.raises(ValueError):
+        deeper.load_weights(path)
+
+
+def test_keras_archive_carries_batchnorm_moving_statistics(device, tmp_path):
+    from adunet_amd import seg_model as S
+    rng = np.random.default_rng(2)
+    data = [(rng.random((2, 32, 32, 3), dtype=np.float32), (rng.random((2, 32, 32, 1)) < 0.4).astype(np.float32)) for _ in range(3)]
+
+    def make():
+        m = S.build_adaptive_depth_unet(32, 32, 2, dtype=torch.bfloat16, device=device)
+        proto = S.PROTOCOLS["B"]
+        m.compile(optimizer=S.build_optimizer(proto, steps_per_epoch=10, epochs=2), loss=proto.loss_builder())
+        m._require_device()
+        return m
+
+    a = make()
+    for img, mask in data:
+        a.train_on_batch(img, mask)
+    assert float((a._state("batch_normalization/moving_mean")).abs().max()) > 0        # the statistics have moved
+    a.save(tmp_path / "seg.keras")
+    b = make()
+    b.load_weights(tmp_path / "seg.keras")
+    assert torch.equal(a.P, b.P) and torch.equal(a.S, b.S)
+    assert np.array_equal(a(data[0][0]), b(data[0][0]))                                 # inference uses the moving statistics

@@ -41,6 +41,19 @@ def test_train_then_evaluate(device, tmp_path):
     assert m["samples"] == 10 and m["psnr_mean"] > 10
     rows = (tmp_path / "eval" / "e" / "per_image_metrics.csv").read_text().splitlines()
     assert rows[0] == "index,filename,psnr_y,ssim_y,msssim_y,mse_y" and rows[1].split(",")[1] == "img0.png#patch0000"
+    # the same weights as a Keras-3 `.keras` archive (what the reference's ModelCheckpoint writes and evaluate_model / --resume_from
+    # read, :57-91 / train :496-522; written and read without h5py -- interchange unpinned): identical evaluation report, and a
+    # directory holding only the archive resumes from it
+    from adunet_amd.evaluate_model import load_checkpoint_model
+    keras_dir = tmp_path / "keras_models"
+    keras_dir.mkdir()
+    load_checkpoint_model(ckpt, 0.5, 32, 1).save(keras_dir / "unet_adaptive_scale_new_loss0.50_depth1.keras")
+    for name, path in (("e_st", ckpt), ("e_keras", keras_dir / "unet_adaptive_scale_new_loss0.50_depth1.keras")):
+        evaluate_model.main(["--model-path", str(path), "--scale", "0.5", "--hr-dir", str(hr), "--patch-size", "32", "--dtype", "bfloat16",
+                             "--depth-override", "1", "--output-dir", str(tmp_path / "eval"), "--run-name", name, "--batch-size", "4"])
+    assert (tmp_path / "eval" / "e_st" / "metrics.json").read_text() == (tmp_path / "eval" / "e_keras" / "metrics.json").read_text()
+    h3, _ = T.train(T.parse_args(argv + ["--resume_from", str(keras_dir), "--initial_epoch", "1"]))
+    assert h3.epoch == [1]
     # resume path and argument validation
     argv2 = argv + ["--resume_from", str(tmp_path / "models"), "--initial_epoch", "1"]
     h2, _ = T.train(T.parse_args(argv2))
