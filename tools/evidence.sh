@@ -33,4 +33,15 @@ python3 tools/layer_table.py --workload K2p > "$out/layers_K2p.txt" 2>&1 || exit
 if [ -f ab/clock.so ]; then
     ADUNET_LIB=ab/clock.so python3 tools/inkernel_clock.py --json "$out/inkernel_clock.json" > "$out/inkernel_clock.txt" 2>&1 || exit 1
 fi
+#   6. r05: BASELINE config 3 as the reference's source defines it (segmentation U-Nets, bench.py SEG_WORKLOADS): bench lines with
+#      the op table, the BatchNorm model under rocprofv3 --kernel-trace --stats; and the per-launch tables that size the round
+#      quantisation of the small-batch Experiment-2 rows
+for w in K3 K3d4 K3ln; do
+    python3 bench.py --workload $w --no-cpu-baseline --breakdown > "$out/bench_$w.json" 2> "$out/op_breakdown_$w.txt" || exit 1
+done
+rm -rf "$out/prof_K3"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof_K3" -- python3 bench.py --workload K3d4 --no-cpu-baseline > "$out/bench_K3d4_under_rocprof.json" 2> "$out/bench_K3d4_under_rocprof.err" || exit 1
+cp "$(ls $out/prof_K3/*/*_kernel_stats.csv | head -1)" "$out/kernel_stats_K3d4.csv"
+python3 tools/layer_table.py --workload E2s07 > "$out/layers_E2s07.txt" 2>&1 || exit 1
+python3 tools/layer_table.py --workload 0.6,5,256,8 > "$out/layers_s06_d5_b8.txt" 2>&1 || exit 1
 tail -3 "$out/pmc_summary.txt"; cat "$out/bench.json" | head -c 600; echo
