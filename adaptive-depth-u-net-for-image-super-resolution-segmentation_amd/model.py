@@ -424,7 +424,7 @@ class Model:
 
     def save_weights(self, path: str, include_optimizer: bool = True):
         """`.safetensors`: weights under their Keras variable names (+ `optimizer/...` training state).  `.weights.h5` /
-        `.keras`: Keras 3's own layouts, written without h5py (keras_archive.py: interchange unpinned) -- weights and
+        `.keras`: Keras 3's own layouts, written without h5py (keras_archive.py: container pinned against libhdf5, Keras' store naming restated) -- weights and
         BatchNorm moving statistics only, as `model.load_weights` reads them."""
         path = str(path)
         if path.endswith(".keras"):

@@ -42,7 +42,7 @@ def test_train_then_evaluate(device, tmp_path):
     rows = (tmp_path / "eval" / "e" / "per_image_metrics.csv").read_text().splitlines()
     assert rows[0] == "index,filename,psnr_y,ssim_y,msssim_y,mse_y" and rows[1].split(",")[1] == "img0.png#patch0000"
     # the same weights as a Keras-3 `.keras` archive (what the reference's ModelCheckpoint writes and evaluate_model / --resume_from
-    # read, :57-91 / train :496-522; written and read without h5py -- interchange unpinned): identical evaluation report, and a
+    # read, :57-91 / train :496-522; written and read without h5py; store naming restated, container pinned): identical evaluation report, and a
     # directory holding only the archive resumes from it
     from adunet_amd.evaluate_model import load_checkpoint_model
     keras_dir = tmp_path / "keras_models"
