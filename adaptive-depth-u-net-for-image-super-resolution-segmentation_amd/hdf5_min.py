@@ -2,7 +2,7 @@
 
 STATUS: the CONTAINER is pinned against the real library, both ways.  h5py is not importable in the interpreter this package
 runs in (and must not become a dependency); the image carries a second interpreter, /opt/conda/bin/python3.9, with h5py 3.3.0 on
-libhdf5 1.10.6, which tests/test_hdf5_against_libhdf5.py uses in a subprocess as an independent implementation: real h5py opens
+libhdf5 1.10.6, which tests/test_against_second_interpreter.py uses in a subprocess as an independent implementation: real h5py opens
 the files `write_file` produces and reads every dataset identically (values, dtype, shape incl. rank 0, empty groups), and
 `read_file` returns exactly the tree real h5py wrote with its default `libver` (as Keras opens its weight files) -- more than 256
 links in a group (two-level B-tree), attributes (continuation blocks), float16 / float64 / rank-0 int64 -- and refuses

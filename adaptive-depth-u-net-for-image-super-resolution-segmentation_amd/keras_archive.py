@@ -7,7 +7,7 @@ What the reference writes and reads (TensorFlow 2.16.1 / Keras 3.3.3, Super_reso
     (evaluate_model.py:71-91: rebuild the architecture, then `load_weights`) read ONLY `model.weights.h5` out of it.
 
 STATUS.  The HDF5 container (hdf5_min.py) is pinned both ways against libhdf5 1.10.6 through the h5py of the image's second
-interpreter (tests/test_hdf5_against_libhdf5.py: incl. a model.weights.h5 from `save_keras` re-written by real h5py and loaded
+interpreter (tests/test_against_second_interpreter.py: incl. a model.weights.h5 from `save_keras` re-written by real h5py and loaded
 back bit for bit).  The STORE NAMING below is restated from Keras 3's `saving_lib` and is NOT pinned: Keras is absent from both
 interpreters and the reference git-ignores its `.keras` checkpoints, so no archive written by Keras exists to read.
   model.weights.h5:  /layers/<store name>/vars/<i>   float32, i = position in trainable + non-trainable variables

@@ -1,4 +1,5 @@
-"""The h5py-free HDF5 subset (adunet_amd/hdf5_min.py) against the REAL library, both ways (CPU).
+"""Independent implementations from the image's SECOND interpreter as checkers (CPU): real libhdf5 for the h5py-free HDF5
+subset (adunet_amd/hdf5_min.py), both ways, and scikit-image for the oracle's SSIM.
 
 h5py is not importable in the interpreter the product and the tests run in, and it must not become a dependency.  The image
 does carry a second interpreter, /opt/conda/bin/python3.9 (Anaconda), with h5py 3.3.0 on libhdf5 1.10.6.  It is used here ONLY
@@ -168,3 +169,33 @@ with h5py.File(sys.argv[1], "r") as a, h5py.File(sys.argv[2], "w") as b:
     dst = HostWeights(model, seed=77)
     K.load_into(dst, tmp_path / "rewritten.weights.h5")
     assert set(dst.loaded) == set(src.w) and all(np.array_equal(dst.loaded[k], src.w[k]) for k in src.w)
+
+
+def test_oracle_ssim_against_scikit_image(tmp_path, h5py_version):
+    """The same second interpreter carries scikit-image 0.18: `structural_similarity(gaussian_weights=True, sigma=1.5,
+    use_sample_covariance=False)` is Wang et al.'s SSIM with the 11-tap Gaussian window, K1 = 0.01, K2 = 0.03, averaged over the
+    region the full window covers -- tf.image.ssim's definition, implemented by a third party.  oracle.metrics.ssim_per_image (what
+    the device kernels are tested against) must agree with it on ordinary patches; TensorFlow itself stays unavailable."""
+    from oracle import metrics as ref_metrics
+    rng = np.random.default_rng(3)
+    a = rng.random((3, 48, 40)).astype(np.float64)
+    from scipy.ndimage import gaussian_filter
+    a = np.stack([gaussian_filter(x, 1.5) for x in a])
+    a = (a - a.min()) / (a.max() - a.min())
+    b = np.clip(a + 0.08 * rng.standard_normal(a.shape), 0, 1)
+    np.savez(tmp_path / "planes.npz", a=a, b=b)
+    try:
+        out = run_h5py("""
+import sys, numpy as np, warnings
+warnings.filterwarnings("ignore")
+from skimage.metrics import structural_similarity
+z = np.load(sys.argv[1])
+print(" ".join(repr(float(structural_similarity(x, y, gaussian_weights=True, sigma=1.5, use_sample_covariance=False, data_range=1.0)))
+               for x, y in zip(z["a"], z["b"])))
+""", str(tmp_path / "planes.npz"))
+    except AssertionError as exc:
+        pytest.skip(f"scikit-image not usable in {CONDA_PY}: {exc}")
+    theirs = np.array([float(v) for v in out.split()])
+    ours = ref_metrics.ssim_per_image(a[..., None], b[..., None]).astype(np.float64)
+    assert theirs.shape == (3,) and (theirs < 0.99).all() and (theirs > 0.2).all()          # ordinary patches, not degenerate ones
+    assert np.abs(ours - theirs).max() < 2e-6, (ours, theirs)

@@ -111,7 +111,7 @@ def test_backup_and_restore_resumes_an_interrupted_fit(device, tmp_path):
 def test_keras_archive_round_trip_of_a_trained_model(device, tmp_path, suffix):
     """the reference's checkpoints are Keras-3 `.keras` archives (train_adaptive_unet.py:531,617) that
     `--resume_from` / evaluate_model read back with `load_weights` (:511-516, evaluate_model.py:79-91).  Written and read here
-    without h5py (keras_archive.py, hdf5_min.py; the container is pinned against libhdf5 in test_hdf5_against_libhdf5.py, Keras'
+    without h5py (keras_archive.py, hdf5_min.py; the container is pinned against libhdf5 in test_against_second_interpreter.py, Keras'
     store naming is restated -- no archive written by Keras exists to read): a trained model's
     weights go through the archive bit for bit, Keras' `load_weights` semantics (weights only, the optimizer restarts)."""
     rng = np.random.default_rng(4)

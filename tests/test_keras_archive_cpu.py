@@ -2,7 +2,7 @@
 
 Round trips through the module and checks of the layout rules restated from Keras 3's saving_lib (store names by class counter
 in `model.layers` order, variable order per class): Keras is absent, so the STORE NAMING is unpinned.  The HDF5 container
-underneath is pinned against real libhdf5 in tests/test_hdf5_against_libhdf5.py.  The GPU side (a model's weights through an archive and back) is tests/test_checkpoint_gpu.py."""
+underneath is pinned against real libhdf5 in tests/test_against_second_interpreter.py.  The GPU side (a model's weights through an archive and back) is tests/test_checkpoint_gpu.py."""
 import json
 import zipfile
 from collections import OrderedDict
