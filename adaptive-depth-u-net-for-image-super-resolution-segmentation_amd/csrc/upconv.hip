@@ -232,11 +232,54 @@ __global__ __launch_bounds__(PL_T, 1) void pw_gemm_lds_kernel(PwArgs a) {
     // parity, static): a stage is ~0.9 us of MFMAs per SIMD, less than the latency of its loads when K is long (one stage
     // ahead: 763 TFLOP/s at K = 1 024)
     u32x4 xr[DEPTH][4], wr[DEPTH][G::WSL];
-    int it = blockIdx.x, iks = 0;                    // cursor of the next stage to issue (tile, k-stage)
+    // XCD-aware tile order (r05).  Workgroup b runs on XCD b % 8 and every XCD has its own 4 MiB L2.  Until r04 workgroup b took
+    // tiles b, b + grid, ... of the n-fastest list: the tiles_n tiles that share a block of pixel rows sat on all eight XCDs, every
+    // XCD pulled every pixel row AND the whole bank through its L2 -- the launch read its operands at ~7 TB/s, the rate the Infinity
+    // Cache serves (MI355X_MICROARCH.md: 33.5 GB/s per CU from the Infinity Cache against 66-73 from the XCD's own L2), with 20 %
+    // of a wave's time in MFMAs (tools/stamps_pw.py).  Now XCD x owns the row-tile GROUPS g with g % 8 == x (a group = GM row
+    // tiles), and in one round its gridDim.x / 8 workgroups form a block of GM row tiles x GN column tiles: a staged slice of
+    // pixel rows is read by GN workgroups behind ONE L2, a bank slice by GM.  Rounds sweep the column groups of a row group first
+    // (its pixel rows stay hot), then the XCD's next row group.  GN: the largest of 8, 4, 2, 1 (dividing the workgroups of an XCD)
+    // that leaves no slot of the block without a tile, e.g. 8 for the 24 column tiles of 1 024 -> 4 608, 1 for the 3 of 128 -> 576.
+    // Only the order changes: every tile is the same arithmetic as before.
+    const bool xo = (gridDim.x & 7) == 0 && ntiles >= (int)gridDim.x;          // (smaller launches keep the linear order)
+    const int xcd = blockIdx.x & 7, rr = blockIdx.x >> 3, per_xcd = (int)gridDim.x >> 3;
+    int GN = 1;
+    if (xo) {
+        int best_idle = 1 << 30;
+        for (int c = 8; c >= 1; c >>= 1) {
+            if (c > per_xcd || per_xcd % c) continue;
+            const int idle = (tiles_n + c - 1) / c * c - tiles_n;
+            if (idle < best_idle) { best_idle = idle; GN = c; }
+        }
+    }
+    const int GM = xo ? per_xcd / GN : 1;
+    const int n_ng = (tiles_n + GN - 1) / GN;
+    const int mg_total = (tiles_m + GM - 1) / GM;
+    const int S_total = xo ? (mg_total > xcd ? (mg_total - xcd + 7) / 8 : 0) * n_ng
+                           : ((int)blockIdx.x < ntiles ? (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0);
+    // the tile of this workgroup's round sq; false where the block has no tile there (ragged last row / column group)
+    auto tile_at = [&](int sq, int& tm, int& tn) -> bool {
+        if (!xo) {
+            const int t = blockIdx.x + sq * gridDim.x;
+            tm = t / tiles_n; tn = t - tm * tiles_n;
+            return true;
+        }
+        const int gl = sq / n_ng, ng = sq - gl * n_ng;
+        tm = (gl * 8 + xcd) * GM + rr / GN; tn = ng * GN + rr % GN;
+        return tm < tiles_m && tn < tiles_n;
+    };
+    auto next_round = [&](int sq) -> int {
+        int tm, tn;
+        while (sq < S_total && !tile_at(sq, tm, tn)) ++sq;
+        return sq;
+    };
+    int qs = next_round(0), iks = 0;                 // cursor of the next stage to issue (round, k-stage)
+    int qtm = 0, qtn = 0;                            // its tile; past the end: the last one again (re-read, never stored)
+    if (qs < S_total) tile_at(qs, qtm, qtn);
 #define PL_ISSUE(SLOT)                                                                                           \
     {                                                                                                            \
-        const int tq_ = min(it, ntiles - 1);          /* past the end: re-read the last stage, never stored */   \
-        const int tm_ = tq_ / tiles_n, tn_ = tq_ - tm_ * tiles_n;                                                \
+        const int tm_ = qtm, tn_ = qtn;                                                                          \
         const int kk_ = iks;                                                                                     \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                          \
             const int mrow_ = tm_ * 256 + xrow[i];                                                               \
@@ -246,7 +289,11 @@ __global__ __launch_bounds__(PL_T, 1) void pw_gemm_lds_kernel(PwArgs a) {
         const unsigned wb_ = (unsigned)((kk_ * 8 * a.n + tn_ * G::NT) * 16);                                     \
         _Pragma("unroll") for (int i = 0; i < G::WSL; ++i)                                                       \
             wr[SLOT][i] = __builtin_amdgcn_raw_buffer_load_b128(rsb, (unsigned)wsrc[i], wb_, 0);                 \
-        if (++iks == ks_per_tile) { iks = 0; it += gridDim.x; }                                                  \
+        if (++iks == ks_per_tile) {                                                                              \
+            iks = 0;                                                                                             \
+            qs = next_round(qs + 1);                                                                             \
+            if (qs < S_total) tile_at(qs, qtm, qtn);                                                             \
+        }                                                                                                        \
     }
 #ifdef AD_STAMP
     unsigned long long pst[6] = {0, 0, 0, 0, 0, 0};
@@ -284,7 +331,7 @@ __global__ __launch_bounds__(PL_T, 1) void pw_gemm_lds_kernel(PwArgs a) {
     PL_ISSUE(0)
     if (DEPTH == 2) PL_ISSUE(DEPTH - 1)
     int buf = 0;
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    for (int sc = next_round(0); sc < S_total; sc = next_round(sc + 1)) {
         f32x4 acc[4][NW];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -294,7 +341,8 @@ __global__ __launch_bounds__(PL_T, 1) void pw_gemm_lds_kernel(PwArgs a) {
             PL_STAGE(0)
             if (DEPTH == 2) PL_STAGE(DEPTH - 1)
         }
-        const int tm = t / tiles_n, tn = t - tm * tiles_n;
+        int tm, tn;
+        tile_at(sc, tm, tn);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             const int mrow = tm * 256 + wm * 64 + mt * 16 + l15;
