@@ -144,7 +144,8 @@ def write_file(tree: dict) -> bytes:
 class _Reader:
     def __init__(self, data: bytes):
         self.d = data
-        if data[:8] != SIGNATURE:
+        self.visiting = set()                 # object headers on the current path (a link cycle must not recurse for ever)
+        if len(data) < 96 or data[:8] != SIGNATURE:
             raise Hdf5Unsupported("not an HDF5 file (signature missing at offset 0; user blocks are not supported)")
         ver = data[8]
         if ver not in (0, 1):
@@ -156,19 +157,31 @@ class _Reader:
         self.root_entry = off + 32
 
     def u(self, fmt: str, off: int):
+        """Bounds-checked little-endian unpack: a truncated or corrupt file raises Hdf5Unsupported, never struct.error."""
+        size = struct.calcsize("<" + fmt)
+        if off < 0 or off + size > len(self.d):
+            raise Hdf5Unsupported(f"address {off} (+{size}) lies outside the file of {len(self.d)} bytes: truncated or corrupt")
         return struct.unpack_from("<" + fmt, self.d, off)
+
+    def span(self, off: int, size: int) -> bytes:
+        if off < 0 or size < 0 or off + size > len(self.d):
+            raise Hdf5Unsupported(f"bytes {off} .. {off + size} lie outside the file of {len(self.d)} bytes: truncated or corrupt")
+        return self.d[off:off + size]
 
     def messages(self, addr: int):
         """(type, data offset, size) of every message of a version-1 object header, continuation blocks included."""
         addr += self.base
-        if self.d[addr:addr + 4] == b"OHDR":
+        if self.span(addr, 4) == b"OHDR":
             raise Hdf5Unsupported("version-2 object header (libver='latest' files)")
         ver, _, nmsg, _, hsize = self.u("BBHII", addr)
         if ver != 1:
             raise Hdf5Unsupported(f"object header version {ver}")
-        blocks, out = [(addr + 16, hsize)], []
+        blocks, out, nblocks = [(addr + 16, hsize)], [], 0
         while blocks and len(out) < nmsg:
             pos, size = blocks.pop(0)
+            nblocks += 1
+            if nblocks > 4096 or pos + size > len(self.d):
+                raise Hdf5Unsupported("object header continuation chain is cyclic or leaves the file")
             end = pos + size
             while pos + 8 <= end and len(out) < nmsg:
                 mtype, msize, _flags = self.u("HHB", pos)
@@ -182,24 +195,33 @@ class _Reader:
     def group_links(self, btree: int, heap: int) -> Dict[str, Tuple[int, int, int, int]]:
         """name -> (object header address, cache type, scratch B-tree, scratch heap) of an old-style group."""
         heap += self.base
-        if self.d[heap:heap + 4] != b"HEAP":
+        if self.span(heap, 4) != b"HEAP":
             raise Hdf5Unsupported("local heap signature missing")
         seg = self.u("Q", heap + 24)[0] + self.base
         links: Dict[str, Tuple[int, int, int, int]] = {}
+        seen_nodes = set()
 
         def name_at(off: int) -> str:
-            end = self.d.index(b"\0", seg + off)
-            return self.d[seg + off:end].decode("utf-8")
+            start = seg + off
+            if start < 0 or start >= len(self.d):
+                raise Hdf5Unsupported("link name offset leaves the file")
+            end = self.d.find(b"\0", start, start + 4096)
+            if end < 0:
+                raise Hdf5Unsupported("unterminated link name")
+            return self.d[start:end].decode("utf-8", "replace")
 
-        def walk(addr: int):
+        def walk(addr: int, depth: int = 0):
             addr += self.base
-            sig = self.d[addr:addr + 4]
+            if addr in seen_nodes or depth > 16:
+                raise Hdf5Unsupported("group B-tree is cyclic or deeper than 16 levels")
+            seen_nodes.add(addr)
+            sig = self.span(addr, 4)
             if sig == b"TREE":
                 ntype, _level, used = self.u("BBH", addr + 4)
                 if ntype != 0:
                     raise Hdf5Unsupported("a chunk B-tree where a group B-tree is expected")
                 for i in range(used):
-                    walk(self.u("Q", addr + 24 + 8 + 16 * i)[0])            # key0 | child0 key1 | child1 key2 ...
+                    walk(self.u("Q", addr + 24 + 8 + 16 * i)[0], depth + 1)  # key0 | child0 key1 | child1 key2 ...
             elif sig == b"SNOD":
                 nsym = self.u("H", addr + 6)[0]
                 for i in range(nsym):
@@ -242,28 +264,38 @@ class _Reader:
                     raise Hdf5Unsupported(f"data layout message version {ver}")
                 if lclass == 1:
                     daddr, dlen = self.u("QQ", pos + 2)
-                    raw = b"" if daddr == UNDEF else self.d[daddr + self.base:daddr + self.base + dlen]
+                    raw = b"" if daddr == UNDEF else self.span(daddr + self.base, dlen)
                 elif lclass == 0:
                     dlen = self.u("H", pos + 2)[0]
-                    raw = self.d[pos + 4:pos + 4 + dlen]
+                    raw = self.span(pos + 4, dlen)
                 else:
                     raise Hdf5Unsupported("chunked dataset (Keras writes its weights contiguous)")
             elif mtype == 0x000B:
                 raise Hdf5Unsupported("filtered (compressed) dataset")
         if shape is None or dtype is None or raw is None:
             raise Hdf5Unsupported("dataset without dataspace / datatype / layout message")
-        count = int(np.prod(shape, dtype=np.int64)) if shape else 1
+        if len(shape) > 32 or any(d > 1 << 40 for d in shape):
+            raise Hdf5Unsupported(f"implausible dataspace {shape[:4]}...")
+        count = 1
+        for d in shape:
+            count *= int(d)
         if len(raw) < count * dtype.itemsize:
             raise Hdf5Unsupported("dataset shorter than its dataspace")
         return np.frombuffer(raw, dtype=dtype, count=count).reshape(shape).copy()
 
     def node(self, oh: int, ctype: int, bt: int, hp: int):
-        if ctype != 1:                       # not cached in the link: the object header says what it is
-            sym = [(p, s) for t, p, s in self.messages(oh) if t == MSG_SYMTAB]
-            if not sym:
-                return self.dataset(oh)
-            bt, hp = self.u("QQ", sym[0][0])
-        return {name: self.node(*link) for name, link in self.group_links(bt, hp).items()}
+        if oh in self.visiting or len(self.visiting) > 64:
+            raise Hdf5Unsupported("links form a cycle (or groups nest deeper than 64)")
+        self.visiting.add(oh)
+        try:
+            if ctype != 1:                       # not cached in the link: the object header says what it is
+                sym = [(p, s) for t, p, s in self.messages(oh) if t == MSG_SYMTAB]
+                if not sym:
+                    return self.dataset(oh)
+                bt, hp = self.u("QQ", sym[0][0])
+            return {name: self.node(*link) for name, link in self.group_links(bt, hp).items()}
+        finally:
+            self.visiting.discard(oh)
 
     def root(self) -> dict:
         _noff, oh, ctype = self.u("QQI", self.root_entry)
@@ -272,5 +304,12 @@ class _Reader:
 
 
 def read_file(data: bytes) -> dict:
-    """The file as nested dicts (groups) of numpy arrays (datasets); raises Hdf5Unsupported for anything outside the subset."""
-    return _Reader(bytes(data)).root()
+    """The file as nested dicts (groups) of numpy arrays (datasets).  Raises Hdf5Unsupported -- and nothing else -- for anything
+    outside the subset and for truncated or corrupt input (every address is bounds-checked, B-trees and links are checked for
+    cycles): a file from outside must not crash, hang or be misread."""
+    try:
+        return _Reader(bytes(data)).root()
+    except Hdf5Unsupported:
+        raise
+    except (struct.error, ValueError, IndexError, OverflowError, RecursionError, MemoryError, UnicodeError) as exc:
+        raise Hdf5Unsupported(f"corrupt HDF5 structure ({type(exc).__name__}: {exc})") from exc

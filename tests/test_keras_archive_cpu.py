@@ -137,3 +137,39 @@ def test_archives_of_another_architecture_are_refused(tmp_path):
     (tmp_path / "legacy.h5").write_bytes(H.write_file({"model_weights": {}}))
     with pytest.raises(ValueError, match="no /layers group"):
         K.load_into(a, tmp_path / "legacy.h5")
+
+
+def test_the_reader_survives_corrupt_files():
+    """A `.keras` / `.h5` file comes from outside.  Truncations, flipped bytes, addresses redirected to the file's start, end or
+    beyond it (cycles, out-of-file pointers) and zeroed spans must each either read or raise Hdf5Unsupported -- no other
+    exception type, no endless walk of a cyclic B-tree (every address is bounds-checked, trees and links are checked for cycles)."""
+    import random
+    import time
+    rng = np.random.default_rng(0)
+    good = H.write_file({"layers": {f"c{i}": {"vars": {"0": rng.standard_normal((3, 4)).astype(np.float32)}} for i in range(20)},
+                         "vars": {}})
+    random.seed(1)
+    refused = 0
+    t0 = time.time()
+    for trial in range(1500):
+        b = bytearray(good)
+        mode = trial % 4
+        if mode == 0:
+            b = b[:random.randrange(0, len(b))]
+        elif mode == 1:
+            for _ in range(random.randint(1, 8)):
+                b[random.randrange(len(b))] = random.randrange(256)
+        elif mode == 2:
+            o = random.randrange(8, len(b) - 8) & ~7
+            b[o:o + 8] = random.choice([0, 96, len(b) - 8, len(b) + 100, random.randrange(len(b)), H.UNDEF]).to_bytes(8, "little")
+        else:
+            o = random.randrange(len(b))
+            b[o:o + random.randint(1, 64)] = b"\0" * min(64, len(b) - o)
+        try:
+            H.read_file(bytes(b))
+        except H.Hdf5Unsupported:
+            refused += 1
+    assert refused > 300 and time.time() - t0 < 30
+    for junk in (b"", b"\x89HDF\r\n\x1a\n", b"\x89HDF\r\n\x1a\n" + b"\xff" * 200):
+        with pytest.raises(H.Hdf5Unsupported):
+            H.read_file(junk)
