@@ -4,6 +4,7 @@ import json
 
 import numpy as np
 import pytest
+import torch
 
 from conftest import free_port
 
@@ -130,7 +131,8 @@ def test_segmentation_train_entry_point(device, tmp_path):
         T.train(T.parse_args(["--protocol", "A"]))
 
 
-def test_vanilla_segmentation_baseline_entry_point(device, tmp_path):
+@pytest.mark.parametrize("policy", [[], ["--dtype", "bfloat16"], ["--mixed_precision"]], ids=["float32", "bfloat16", "mixed_float16"])
+def test_vanilla_segmentation_baseline_entry_point(device, tmp_path, policy):
     """Segmenation/code/unet_vinillia.py:236-293 end to end on a synthetic folder: BinaryCrossentropy, the four Keras metrics
     (accuracy / precision / recall as running sums over the epoch, dice_coefficient as a batch mean), checkpoints on
     val_dice_coefficient, ReduceLROnPlateau's learning-rate log; and one batch's metric values against NumPy on the model's
@@ -152,8 +154,12 @@ def test_vanilla_segmentation_baseline_entry_point(device, tmp_path):
     argv = ["--epochs", "2", "--batch_size", "4", "--depth", "2", "--image_size", "32", "--base_channels", "32", "--augment",
             "--train_image_dir", str(folders[("train", "img")]), "--train_mask_dir", str(folders[("train", "mask")]),
             "--val_image_dir", str(folders[("val", "img")]), "--val_mask_dir", str(folders[("val", "mask")]),
-            "--model_dir", str(tmp_path / "models"), "--run_name", "vanilla", "--fit_verbose", "0"]
+            "--model_dir", str(tmp_path / "models"), "--run_name", "vanilla", "--fit_verbose", "0"] + policy
     model, history = V.train(V.parse_args(argv))
+    want_dtype = {"": torch.float32, "--dtype": torch.bfloat16, "--mixed_precision": torch.float16}[policy[0] if policy else ""]
+    assert model.dtype == want_dtype
+    if policy == ["--mixed_precision"]:          # Keras wraps the optimizer under mixed_float16; ReduceLROnPlateau reaches the inner rate
+        assert type(model.optimizer).__name__ == "LossScaleOptimizer" and model.optimizer.inner_optimizer.learning_rate == 1e-4
     keys = {"loss", "accuracy", "precision", "recall", "dice_coefficient"}
     assert history.epoch == [0, 1] and keys | {"val_" + k for k in keys} | {"learning_rate"} <= set(history.history)
     assert history.history["learning_rate"] == [1e-4, 1e-4]
@@ -171,7 +177,7 @@ def test_vanilla_segmentation_baseline_entry_point(device, tmp_path):
     want = [float(np.mean(-(mask * np.log(pc) + (1 - mask) * np.log(1 - pc)))), float(np.mean(pos == truth)),
             float((pos & truth).sum() / max(pos.sum(), 1)), float((pos & truth).sum() / max(truth.sum(), 1)),
             V.dice_coefficient(mask, p)]
-    assert np.allclose(got[:5], want, rtol=2e-4, atol=2e-5), (got[:5], want)
+    assert np.allclose(got[:5], want, rtol=2e-4, atol=2e-5), (got[:5], want)       # (on the model's OWN probabilities: any dtype)
     assert got[5:] == [float((pos == truth).sum()), float(mask.size), float((pos & truth).sum()), float(pos.sum()), float(truth.sum())]
     res = model.evaluate(val, return_dict=True)
     assert list(res) == model.metrics_names and res["accuracy"] == pytest.approx(want[1], abs=1e-6)
