@@ -357,6 +357,9 @@ struct ConvArgs {
     // stored conv output (laid out like y1), ln_mean / ln_rstd / ln_gamma / ln_beta its statistics and parameters (inputs
     // here); y1 receives dz of that layer, dbias_part[workgroup][wave][3][64] the column sums for dgamma / dbeta / dbias
     const char* lnb_z;
+    // weight pack row length in output channels when the launch computes a slice of the pack's output blocks (wp then
+    // points at the slice's first block); 0: the pack is exactly a.cout wide.  Wave-specialised 16-bit kernels only.
+    int wcout = 0;
     Geo g;
 };
 
@@ -1297,7 +1300,7 @@ __global__ __launch_bounds__(WR_T, 1) void conv3x3_fwd_wres_kernel(ConvArgs a) {
     for (int i = 0; i < 2 * 9 * 4 * BN / WR_T; ++i) {
         const int s = tid + i * WR_T;               // 0 .. 4607: chunk s / 2304, slot s % 2304
         const int ch = s >= 9 * 4 * BN;
-        *reinterpret_cast<uint4*>(wt + s * 16) = load_w_slot(a.wp, kc_total, ch, a.cout, nb, s - ch * 9 * 4 * BN);
+        *reinterpret_cast<uint4*>(wt + s * 16) = load_w_slot(a.wp, kc_total, ch, a.wcout ? a.wcout : a.cout, nb, s - ch * 9 * 4 * BN);
     }
 
     float* gb = reinterpret_cast<float*>(wt + 2 * WT_BYTES);
@@ -1433,7 +1436,8 @@ __global__ __launch_bounds__(WR_T, 1) void conv3x3_fwd_ws_kernel(ConvArgs a) {
         const int lt = tid - 256;
         const auto rsx1 = wave_uniform_rsrc(a.x1, npix * a.c1 * TSZ);
         const auto rsx2 = wave_uniform_rsrc(a.c2 ? a.x2 : a.x1, npix * (a.c2 ? a.c2 : a.c1) * TSZ);
-        const auto rsw = wave_uniform_rsrc(a.wp, 9 * cin * a.cout * TSZ);
+        const int wrow = a.wcout ? a.wcout : a.cout;   // pack row length (>= cout: a launch may take a slice of the blocks)
+        const auto rsw = wave_uniform_rsrc(a.wp, 9 * cin * wrow * TSZ);
         const int part16 = (lt & 3) * 16;
         int hyx[WR_XS];
 #pragma unroll
@@ -1444,8 +1448,8 @@ __global__ __launch_bounds__(WR_T, 1) void conv3x3_fwd_ws_kernel(ConvArgs a) {
         }
         const int lds_slot = (lt >> 2) * PIXB + part16;
         // weight slot i: s = lt + 256 i -> (tap s>>8 = i, kc (s>>6)&3, co s&63): byte offset inside chunk 0, block nb
-        const int woff = ((((lt >> 6) & 3) * a.cout) + nb * BN + (lt & 63)) * 16;       // + i * kc_total * cout * 16
-        const int wtap = kc_total * a.cout * 16;
+        const int woff = ((((lt >> 6) & 3) * wrow) + nb * BN + (lt & 63)) * 16;       // + i * kc_total * wrow * 16
+        const int wtap = kc_total * wrow * 16;
         int pix0, pix1, pix2, pix3, pix4, pix5;
 #define WS_PIX(I, NN, Y0, X0)                                                                    \
     {                                                                                            \
@@ -1467,7 +1471,7 @@ __global__ __launch_bounds__(WR_T, 1) void conv3x3_fwd_ws_kernel(ConvArgs a) {
     }
 #define WS_XLD(RS, RB, OB, PIXV) \
     __builtin_amdgcn_raw_buffer_load_b128((RS), (PIXV) >= 0 ? (unsigned)((PIXV) * (RB) + (OB) + part16) : WR_OOB, 0, 0)
-#define WS_WLD(I, CH) __builtin_amdgcn_raw_buffer_load_b128(rsw, (unsigned)(woff + (I) * wtap + (CH) * 4 * a.cout * 16), 0, 0)
+#define WS_WLD(I, CH) __builtin_amdgcn_raw_buffer_load_b128(rsw, (unsigned)(woff + (I) * wtap + (CH) * 4 * wrow * 16), 0, 0)
         u32x4 xa0, xa1, xa2, xa3, xa4, xa5, wa0, wa1, wa2, wa3, wa4, wa5, wa6, wa7, wa8;
         u32x4 xb_0, xb_1, xb_2, xb_3, xb_4, xb_5, wb0, wb1, wb2, wb3, wb4, wb5, wb6, wb7, wb8;
 #define WS_ISSUE(X0_, X1_, X2_, X3_, X4_, X5_, W0_, W1_, W2_, W3_, W4_, W5_, W6_, W7_, W8_, CH)              \
@@ -2790,6 +2794,22 @@ int launch_fwd(ConvArgs a, void* ws, size_t ws_bytes, hipStream_t s) {
         }
         int kind = fwd_ws_kind(a.n, a.h, a.w, a.c1, a.c2, a.cout_real, a.epilogue == AD_EPI_LN_RELU || a.epilogue == AD_EPI_LN_STATS);
         if (a.cy1 % BN && a.cy1 != a.cout_real) kind = 0;          // a split inside a 64-channel block: generic kernel
+        // Two output tensors whose block counts each suit the XCD-aware work order although their sum does not (the
+        // dgrad of a Concatenate of 2 nf + nf channels: 3, 6, 12, 24 blocks): one launch per output on a slice of the
+        // pack's output blocks (wcout).  The input is read twice; the generic kernel it replaces runs at 0.25 - 0.35 of peak.
+        if (kind == 0 && a.y2 && a.wcout == 0 && a.epilogue <= AD_EPI_RELU && a.cy1 % BN == 0 && a.cout_real % BN == 0 &&
+            fwd_ws_kind(a.n, a.h, a.w, a.c1, a.c2, a.cy1, false) && fwd_ws_kind(a.n, a.h, a.w, a.c1, a.c2, a.cout_real - a.cy1, false)) {
+            ConvArgs b = a;
+            b.wcout = a.cout; b.y2 = nullptr;
+            b.cout = b.cout_real = a.cy1;
+            int rc = launch_fwd<P>(b, ws, ws_bytes, s);
+            if (rc) return rc;
+            b.cout = b.cout_real = b.cy1 = a.cout_real - a.cy1;
+            b.y1 = a.y2;
+            b.wp = a.wp + (size_t)a.cy1 * 16;                      // [tap][Cin / KV][Cout][KV]: 16 bytes per output channel
+            if (a.bias) b.bias = a.bias + a.cy1;
+            return launch_fwd<P>(b, ws, ws_bytes, s);
+        }
         // the ReLU-grad mask epilogue exists for the weights-resident kernel only (the streamed-weights variant would
         // spill: 256 registers + scratch); ad_conv3x3_dgrad_relu_is_fused says so to the caller
         if (a.epilogue == AD_EPI_MASK) {

@@ -313,6 +313,31 @@ def test_conv3x3_dgrad_large_launch_split_outputs(device):
     _window_check(torch.cat([d1, d2], dim=-1), dz, wt, None, False, TOL[BF16])
 
 
+@pytest.mark.parametrize("case", [(128, 64, 64), (256, 128, 128)])
+def test_conv3x3_dgrad_of_a_three_to_one_concat_runs_as_two_block_slices(device, case):
+    """dgrad of the segmentation decoder's Concatenate(up: 2 nf, skip: nf) conv (Segmenation/code/train_adaptive_unet.py:353-355):
+    3 / 6 output blocks do not suit the XCD-aware work order (it needs a divisor of 32), each output alone does -- the launch
+    runs as one wave-specialised launch per output on a slice of the pack's blocks (weights-resident at nf = 64, streamed at
+    128).  Oracle on windows; and each output bitwise equal to a dgrad with only that output's weights packed."""
+    from adunet_amd import ops
+    c_up, c_skip, cout = case
+    cin = c_up + c_skip
+    n, h, w = BIG
+    rng = np.random.default_rng(14)
+    wk = rnd(rng.standard_normal((3, 3, cin, cout)) * 0.1, BF16)
+    dz = rnd(rng.standard_normal((n, h, w, cout)), BF16)
+    dzd = to_dev(dz, BF16, device)
+    _, wd = ops.conv3x3_pack(torch.tensor(wk, dtype=F32, device=device), cin, BF16)
+    d1, d2 = ops.conv3x3_fwd(dzd, None, wd, None, cin, split=c_up)
+    assert d1.shape[-1] == c_up and d2.shape[-1] == c_skip
+    wt = np.ascontiguousarray(np.transpose(wk[::-1, ::-1], (0, 1, 3, 2)))
+    _window_check(torch.cat([d1, d2], dim=-1), dz, wt, None, False, TOL[BF16])
+    for got, lo, hi in ((d1, 0, c_up), (d2, c_up, cin)):
+        _, wd_s = ops.conv3x3_pack(torch.tensor(np.ascontiguousarray(wk[:, :, lo:hi]), dtype=F32, device=device), hi - lo, BF16)
+        alone = ops.conv3x3_fwd(dzd, None, wd_s, None, hi - lo)
+        assert torch.equal(got, alone), (lo, hi)
+
+
 @pytest.mark.parametrize("case", [(64, 0, 64), (64, 64, 64), (32, 32, 128)])
 def test_conv3x3_wgrad_large_launch(device, ws, case):
     from adunet_amd import ops
