@@ -2219,14 +2219,30 @@ __global__ __launch_bounds__(W2_T, 1) void conv3x3_wgrad_ws_kernel(WgradArgs a) 
             lds_barrier();                           // B1
             w2_half<E>(acc, smem + 2 * W2_XB + xw, smem + 4 * W2_XB + W2_DZB, xa, xb, dzo);
         }
-        float* slab = a.ws + ((size_t)(split * a.ncib + cib) * a.ncob + cob) * (9 * 64 * BN);
+        if (a.dw) {
+            // one split (>= 256 channel-block pairs: the 512 ... 1 536-channel levels): this workgroup's sums ARE the gradient
+            // of its 64 x 64 block; they go to dw_hwio [tap][cin_real][cout] directly, no slab and no reduce launch
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap)
+            for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+                for (int r = 0; r < 4; ++r) {
+                    const int ci = cib * 64 + wave * 16 + (lane >> 4) * 4 + r;
+                    float* row = a.dw + ((size_t)tap * a.cin_real + ci) * a.cout + cob * BN + (lane & 15);
+                    if (ci < a.cin_real) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    slab[(tap * 64 + wave * 16 + (lane >> 4) * 4 + r) * BN + j * 16 + (lane & 15)] = acc[tap][j][r];
+                        for (int j = 0; j < 4; ++j) row[j * 16] = acc[tap][j][r];
+                    }
+                }
+        } else {
+            float* slab = a.ws + ((size_t)(split * a.ncib + cib) * a.ncob + cob) * (9 * 64 * BN);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        slab[(tap * 64 + wave * 16 + (lane >> 4) * 4 + r) * BN + j * 16 + (lane & 15)] = acc[tap][j][r];
+        }
         AD_CLOCK_END(wave, lane, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z))
     }
 }
@@ -3318,7 +3334,7 @@ extern "C" int ad_conv3x3_wgrad(const void* x1, int c1, const void* x2, int c2, 
         a.n = nr; a.h = h; a.w = w; a.cout = cout;
         a.ntiles = p.ntiles; a.tiles_per_split = p.tiles_per_split; a.ncib = p.ncib; a.ncob = p.ncob;
         a.g = p.g;
-        const bool direct = p.nsplit == 1 && !p.specialised && chunk >= n;
+        const bool direct = p.nsplit == 1 && chunk >= n;       // (the specialised kernel too, r05: cout % 64 == 0 there)
         a.dw = direct ? dw_hwio : nullptr; a.cin_real = cin_real;
         int rc = dtype == AD_BF16 ? launch_wgrad<PolBF16>(a, p, s)
                  : dtype == AD_F16 ? launch_wgrad<PolF16>(a, p, s) : launch_wgrad<PolF32>(a, p, s);

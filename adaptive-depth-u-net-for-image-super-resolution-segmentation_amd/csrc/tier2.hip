@@ -545,6 +545,31 @@ __global__ void seg_sums_kernel(const float* __restrict__ part, int n, int bpi, 
     else counts[img * 6 + k - 3] = s;
 }
 
+// out[0..3) = { loss, dice, iou } of one batch from the per-sample sums of ad_seg_head_fwd (Segmenation/code/train_adaptive_unet.py:
+// 258-304): bce = sum_n sums[n][0] / count, dice = mean_n (2 I_n + s) / (U_n + s), iou = mean_n (I_n + s) / (U_n - I_n + s),
+// loss = wb * bce + wd * (1 - dice).  One wave, samples summed in index order (deterministic).
+__global__ __launch_bounds__(64) void seg_metrics_kernel(const float* __restrict__ sums, int n, float count, float wb, float wd,
+                                                         float smooth, float* __restrict__ out) {
+    __shared__ float sm[3][64];
+    float b = 0.f, d = 0.f, u = 0.f;
+    for (int i = threadIdx.x; i < n; i += 64) {
+        const float ce = sums[i * 3], inter = sums[i * 3 + 1], tot = sums[i * 3 + 2];
+        b += ce;
+        d += (2.0f * inter + smooth) / (tot + smooth);
+        u += (inter + smooth) / (tot - inter + smooth);
+    }
+    sm[0][threadIdx.x] = b; sm[1][threadIdx.x] = d; sm[2][threadIdx.x] = u;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float tb = 0.f, td = 0.f, tu = 0.f;
+        for (int i = 0; i < 64; ++i) { tb += sm[0][i]; td += sm[1][i]; tu += sm[2][i]; }
+        const float bce = tb / count, dice = td / (float)n, iou = tu / (float)n;
+        out[0] = wb * bce + wd * (1.0f - dice);
+        out[1] = dice;
+        out[2] = iou;
+    }
+}
+
 // backward: dL/dp = wb * dBCE/dp / count + wd * (-(1/n) * d dice_n / dp); dlogit = dL/dp * p (1 - p)
 template <typename T, int G>
 __global__ __launch_bounds__(256) void seg_head_bwd_kernel(const T* __restrict__ xh, const float* __restrict__ w,
@@ -957,6 +982,14 @@ extern "C" int ad_seg_head_fwd_counts(const void* xh, const float* w, const floa
         seg_sums_kernel<<<(n * ncol + 255) / 256, 256, 0, s>>>(part, n, bpi, sums, ncol, counts);
         AD_LAUNCH_CHECK("seg_sums");
     }
+    return AD_OK;
+}
+
+extern "C" int ad_seg_metrics(const float* sums, int n, float count, float bce_weight, float dice_weight, float smooth,
+                              float* out3, void* stream) {
+    AD_REQUIRE(sums && out3 && n > 0 && count > 0.f, "ad_seg_metrics: bad arguments n=%d count=%g", n, (double)count);
+    seg_metrics_kernel<<<1, 64, 0, (hipStream_t)stream>>>(sums, n, count, bce_weight, dice_weight, smooth, out3);
+    AD_LAUNCH_CHECK("ad_seg_metrics");
     return AD_OK;
 }
 

@@ -806,6 +806,15 @@ def seg_head_fwd(xh, w, b, target, ws: Workspace, counts: bool = False):
     return prob, sums
 
 
+def seg_metrics(sums, count: float, bce_weight: float, dice_weight: float, smooth: float = 1e-6):
+    """(loss, dice, iou) of a batch from seg_head_fwd's per-sample sums, as a device tensor [3] (one launch)."""
+    out = torch.empty(3, dtype=torch.float32, device=sums.device)
+    with _timed("seg_metrics"):
+        check(_lib.load().ad_seg_metrics(_p(sums), sums.shape[0], float(count), float(bce_weight), float(dice_weight),
+                                         float(smooth), _p(out), _stream()), "ad_seg_metrics")
+    return out
+
+
 def softmax_head_fwd(xh, w, b):
     """Conv2D(K, 1, softmax) head: xh [n,h,w,ch], w [ch,K] fp32, b [K] -> probabilities [n,h,w,K] fp32 (forward only)."""
     n, h, wd, ch = xh.shape

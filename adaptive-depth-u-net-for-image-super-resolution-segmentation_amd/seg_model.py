@@ -440,11 +440,8 @@ class SegModel(Model):
     def _metrics_from(self, sums: torch.Tensor, count: float, smooth: float = 1e-6):
         if getattr(self, "_baseline_metrics", False):
             return self._baseline_metrics_from(sums, count, smooth)
-        bce = sums[:, 0].sum() / count
-        dice = ((2.0 * sums[:, 1] + smooth) / (sums[:, 2] + smooth)).mean()
-        iou = ((sums[:, 1] + smooth) / (sums[:, 2] - sums[:, 1] + smooth)).mean()       # :272-281
-        loss = self.loss.bce_weight * bce + self.loss.dice_weight * (1.0 - dice)
-        return loss, dice, iou
+        m = ops.seg_metrics(sums, count, self.loss.bce_weight, self.loss.dice_weight, smooth)        # :258-304
+        return m[0], m[1], m[2]
 
     def _baseline_metrics_from(self, sums: torch.Tensor, count: float, smooth: float):
         """The vanilla baseline's per-batch values (unet_vinillia.py:266-271) followed by the running sums Keras' stateful

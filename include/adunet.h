@@ -319,6 +319,11 @@ int ad_seg_head_fwd(const void* xh, const float* w, const float* b, const float*
 int ad_seg_head_fwd_counts(const void* xh, const float* w, const float* b, const float* target, float* prob,
                            float* sums, float* counts, int n, int64_t pix_per_img, int ch,
                            void* ws, size_t ws_bytes, int dtype, void* stream);
+/* The batch values Keras logs from those sums (:258-304, :307-314): out3 = { loss = bce_weight * sum_n sums[n][0] / count +
+ * dice_weight * (1 - dice), dice = mean_n (2 I_n + smooth) / (U_n + smooth), iou = mean_n (I_n + smooth) / (U_n - I_n + smooth) }
+ * with I_n = sums[n][1], U_n = sums[n][2]; count = elements of the mask batch.  One launch, stays on the device (graph replay). */
+int ad_seg_metrics(const float* sums, int n, float count, float bce_weight, float dice_weight, float smooth, float* out3,
+                   void* stream);
 int ad_seg_head_bwd(const void* xh, const float* w, const float* target, const float* prob, const float* sums,
                     void* dxh, float* dw, float* db, int n, int64_t pix_per_img, int ch,
                     float bce_weight, float dice_weight, float smooth,

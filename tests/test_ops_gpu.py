@@ -338,6 +338,29 @@ def test_conv3x3_dgrad_of_a_three_to_one_concat_runs_as_two_block_slices(device,
         assert torch.equal(got, alone), (lo, hi)
 
 
+@pytest.mark.parametrize("case", [(1024, 0, 1024), (1024, 512, 512)])
+def test_conv3x3_wgrad_with_one_split_writes_dw_itself(device, ws, case):
+    """>= 256 pairs of 64-channel blocks (the segmentation bottleneck, Segmenation/code/train_adaptive_unet.py:352-355): the
+    wave-specialised wgrad runs as ONE split and writes dw_hwio from its accumulators -- no slab, no reduce launch.  Oracle
+    on the whole tensor; a NaN-filled dw shows an element the kernel did not write."""
+    from adunet_amd import ops
+    c1, c2, cout = case
+    cin = c1 + c2
+    n, h, w = 4, 16, 16
+    rng = np.random.default_rng(15)
+    x = rnd(rng.standard_normal((n, h, w, cin)), BF16)
+    dz = rnd(rng.standard_normal((n, h, w, cout)), BF16)
+    _, want, _ = ref.conv2d_same_bwd(x, np.zeros((3, 3, cin, cout)), dz, need_dx=False)
+    x1 = to_dev(x[..., :c1], BF16, device)
+    x2 = to_dev(x[..., c1:], BF16, device) if c2 else None
+    dw = torch.full((3, 3, cin, cout), float("nan"), dtype=F32, device=device)
+    ops.conv3x3_wgrad(x1, x2, to_dev(dz, BF16, device), dw, cin, ws)
+    assert relerr(dw, want) < 1e-3
+    dw2 = torch.full_like(dw, float("nan"))
+    ops.conv3x3_wgrad(x1, x2, to_dev(dz, BF16, device), dw2, cin, ws)
+    assert torch.equal(dw, dw2)
+
+
 @pytest.mark.parametrize("case", [(64, 0, 64), (64, 64, 64), (32, 32, 128)])
 def test_conv3x3_wgrad_large_launch(device, ws, case):
     from adunet_amd import ops

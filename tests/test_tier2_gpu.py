@@ -175,6 +175,8 @@ def test_seg_head(device, ws, dtype, weights):
     dice = ((2 * s[:, 1] + 1e-6) / (s[:, 2] + 1e-6)).mean()
     got_loss = wb * s[:, 0].sum() / y.size + wdice * (1 - dice)
     assert abs(got_loss - loss) < 1e-5 and abs(dice - ref.dice_coefficient(y, p)) < 1e-6
+    m = ops.seg_metrics(sums, float(y.size), wb, wdice).double().cpu().numpy()      # the batch values a train step logs, one launch
+    assert abs(m[0] - loss) < 1e-5 and abs(m[1] - ref.dice_coefficient(y, p)) < 1e-6 and abs(m[2] - ref.iou_score(y, p)) < 1e-6
     gw, gb = torch.empty(ch, dtype=F32, device=device), torch.empty(1, dtype=F32, device=device)
     gx = ops.seg_head_bwd(xd, f(wk.reshape(ch)), f(y), prob, sums, gw, gb, wb, wdice, ws)
     assert relerr(gx, dxh) < TOL[dtype] and relerr(gw, dw.reshape(ch)) < 1e-3 and relerr(gb, db) < 1e-3
