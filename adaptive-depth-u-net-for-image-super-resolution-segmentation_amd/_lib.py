@@ -81,6 +81,8 @@ SIGNATURES = {
     "ad_pixel_shuffle2": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ad_seg_head_ws_bytes": (_sz, [_i, _i]),
     "ad_seg_head_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _sz, _i, _vp]),
+    "ad_pw_gemm_tile_channels": (_i, [_i64, _i, _i, _i]),
+    "ad_pw_gemm_tile_order": (_i, [_i, _i, _i, _vp, _i]),
     "ad_seg_metrics": (_i, [_vp, _i, _f, _f, _f, _f, _vp, _vp]),
     "ad_seg_head_fwd_counts": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _sz, _i, _vp]),
     "ad_seg_head_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _f, _f, _f, _vp, _vp, _sz, _i, _vp]),

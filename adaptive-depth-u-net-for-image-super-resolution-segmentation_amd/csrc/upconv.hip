@@ -72,6 +72,7 @@ struct PwArgs {
     const char* x; const char* bp; char* y;
     int m, k, n;               // pixels, contraction, output channels (n % 64 == 0, k % 64 == 0)
     int nb_per_wg;             // 64-channel output blocks per workgroup
+    int whole_groups;          // LDS-tiled kernel: PlOrder's A/B switch
     unsigned long long* dbg;   // diagnostic builds only (-DAD_STAMP, tools/stamps_pw.py): cycle sums by phase of wave 0
 };
 #ifdef AD_STAMP
@@ -187,6 +188,80 @@ __global__ __launch_bounds__(PW_T, 2) void pw_gemm_kernel(PwArgs a) {
 // next tile's first stage are in flight while a tile's results are packed and stored.
 constexpr int PL_T = 512;
 constexpr int PL_XB = 256 * 96;                 // one 32-k chunk of 256 pixel rows (24,576 B)
+
+// XCD-aware tile order of pw_gemm_lds_kernel (r05), shared by the kernel and the host (ad_pw_gemm_tile_order: the coverage
+// test and the launcher's round count).  Workgroup b runs on XCD b % 8 and every XCD has its own 4 MiB L2.  Until r04
+// workgroup b took tiles b, b + grid, ... of the n-fastest list: the tiles_n tiles that share a block of pixel rows sat on all
+// eight XCDs, every XCD pulled every pixel row AND the whole bank through its L2 -- the launch read its operands at ~7 TB/s, the
+// rate the Infinity Cache serves (MI355X_MICROARCH.md: 33.5 GB/s per CU from the Infinity Cache against 66-73 from the XCD's own
+// L2), with 20 % of a wave's time in MFMAs (tools/stamps_pw.py).  Now a round of an XCD's gridDim.x / 8 workgroups is a BLOCK of
+// GM row tiles x GN column tiles: a staged slice of pixel rows is read by GN workgroups behind ONE L2, a bank slice by GM.
+// Blocks are ordered row group by row group (a row group = GM row tiles; its n_ng column groups in sequence: its pixel rows
+// stay hot).  Whole sets of eight row groups go one group per XCD.  The mg_total % 8 row groups left over are dealt to the XCDs
+// BLOCK by block (second half of r05: until then each was one XCD's, and e.g. 10 row groups of 9 column groups cost 18 rounds
+// on XCDs 0 and 1 against 9 on the others -- 0.57 of the launch's workgroup-rounds did work).
+// GN: the largest of 8, 4, 2, 1 (dividing the workgroups of an XCD) that leaves the fewest slots of the block without a tile,
+// e.g. 8 for the 24 column tiles of 1 024 -> 4 608, 1 for the 3 of 128 -> 576.  Only the order changes: every tile is the same
+// arithmetic as before.
+struct PlOrder {
+    int tiles_m, tiles_n, grid, bid;
+    bool xo;
+    int xcd, rr, GN, GM, n_ng, mg_total, S_full, S_total;
+    __host__ __device__ void init(int tiles_m_, int tiles_n_, int grid_, int bid_, bool whole_groups = false) {
+        tiles_m = tiles_m_; tiles_n = tiles_n_; grid = grid_; bid = bid_;
+        const int ntiles = tiles_m * tiles_n;
+        xo = (grid & 7) == 0 && ntiles >= grid;            // (smaller launches keep the linear order)
+        xcd = bid & 7; rr = bid >> 3;
+        const int per_xcd = grid >> 3;
+        GN = 1;
+        if (xo) {
+            int best_idle = 1 << 30;
+            for (int c = 8; c >= 1; c >>= 1) {
+                if (c > per_xcd || per_xcd % c) continue;
+                const int idle = (tiles_n + c - 1) / c * c - tiles_n;
+                if (idle < best_idle) { best_idle = idle; GN = c; }
+            }
+        }
+        GM = xo ? per_xcd / GN : 1;
+        n_ng = (tiles_n + GN - 1) / GN;
+        mg_total = (tiles_m + GM - 1) / GM;
+        if (xo) {
+            // whole_groups (A/B switch, AD_PW_NW8=0): the order until the first half of r05, every row group one XCD's
+            const int tail_blocks = whole_groups ? 0 : (mg_total & 7) * n_ng;   // blocks of the row groups beyond the whole sets of eight
+            S_full = (whole_groups ? (mg_total > xcd ? (mg_total - xcd + 7) / 8 : 0) : mg_total >> 3) * n_ng;
+            S_total = S_full + (tail_blocks > xcd ? (tail_blocks - xcd + 7) / 8 : 0);
+        } else {
+            S_full = 0;
+            S_total = bid < ntiles ? (ntiles - bid + grid - 1) / grid : 0;
+        }
+    }
+    // the tile of this workgroup's round sq; false where the block has no tile there (ragged last row / column group)
+    __host__ __device__ bool tile_at(int sq, int& tm, int& tn) const {
+        if (!xo) {
+            const int t = bid + sq * grid;
+            tm = t / tiles_n; tn = t - tm * tiles_n;
+            return true;
+        }
+        int g, ng;
+        if (sq < S_full) {
+            const int gl = sq / n_ng;
+            ng = sq - gl * n_ng;
+            g = gl * 8 + xcd;
+        } else {
+            const int t = (sq - S_full) * 8 + xcd;         // tail block t of the (mg_total % 8) * n_ng left over
+            const int gt = t / n_ng;
+            ng = t - gt * n_ng;
+            g = (mg_total & ~7) + gt;
+        }
+        tm = g * GM + rr / GN; tn = ng * GN + rr % GN;
+        return tm < tiles_m && tn < tiles_n;
+    }
+    __host__ __device__ int next_round(int sq) const {
+        int tm, tn;
+        while (sq < S_total && !tile_at(sq, tm, tn)) ++sq;
+        return sq;
+    }
+};
 template <int NW> struct PlGeo {
     static constexpr int NT = 32 * NW;                      // channels per tile
     static constexpr int WB = 4 * NT * 16;                  // one 32-k chunk of the bank tile
@@ -232,48 +307,11 @@ __global__ __launch_bounds__(PL_T, 1) void pw_gemm_lds_kernel(PwArgs a) {
     // parity, static): a stage is ~0.9 us of MFMAs per SIMD, less than the latency of its loads when K is long (one stage
     // ahead: 763 TFLOP/s at K = 1 024)
     u32x4 xr[DEPTH][4], wr[DEPTH][G::WSL];
-    // XCD-aware tile order (r05).  Workgroup b runs on XCD b % 8 and every XCD has its own 4 MiB L2.  Until r04 workgroup b took
-    // tiles b, b + grid, ... of the n-fastest list: the tiles_n tiles that share a block of pixel rows sat on all eight XCDs, every
-    // XCD pulled every pixel row AND the whole bank through its L2 -- the launch read its operands at ~7 TB/s, the rate the Infinity
-    // Cache serves (MI355X_MICROARCH.md: 33.5 GB/s per CU from the Infinity Cache against 66-73 from the XCD's own L2), with 20 %
-    // of a wave's time in MFMAs (tools/stamps_pw.py).  Now XCD x owns the row-tile GROUPS g with g % 8 == x (a group = GM row
-    // tiles), and in one round its gridDim.x / 8 workgroups form a block of GM row tiles x GN column tiles: a staged slice of
-    // pixel rows is read by GN workgroups behind ONE L2, a bank slice by GM.  Rounds sweep the column groups of a row group first
-    // (its pixel rows stay hot), then the XCD's next row group.  GN: the largest of 8, 4, 2, 1 (dividing the workgroups of an XCD)
-    // that leaves no slot of the block without a tile, e.g. 8 for the 24 column tiles of 1 024 -> 4 608, 1 for the 3 of 128 -> 576.
-    // Only the order changes: every tile is the same arithmetic as before.
-    const bool xo = (gridDim.x & 7) == 0 && ntiles >= (int)gridDim.x;          // (smaller launches keep the linear order)
-    const int xcd = blockIdx.x & 7, rr = blockIdx.x >> 3, per_xcd = (int)gridDim.x >> 3;
-    int GN = 1;
-    if (xo) {
-        int best_idle = 1 << 30;
-        for (int c = 8; c >= 1; c >>= 1) {
-            if (c > per_xcd || per_xcd % c) continue;
-            const int idle = (tiles_n + c - 1) / c * c - tiles_n;
-            if (idle < best_idle) { best_idle = idle; GN = c; }
-        }
-    }
-    const int GM = xo ? per_xcd / GN : 1;
-    const int n_ng = (tiles_n + GN - 1) / GN;
-    const int mg_total = (tiles_m + GM - 1) / GM;
-    const int S_total = xo ? (mg_total > xcd ? (mg_total - xcd + 7) / 8 : 0) * n_ng
-                           : ((int)blockIdx.x < ntiles ? (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0);
-    // the tile of this workgroup's round sq; false where the block has no tile there (ragged last row / column group)
-    auto tile_at = [&](int sq, int& tm, int& tn) -> bool {
-        if (!xo) {
-            const int t = blockIdx.x + sq * gridDim.x;
-            tm = t / tiles_n; tn = t - tm * tiles_n;
-            return true;
-        }
-        const int gl = sq / n_ng, ng = sq - gl * n_ng;
-        tm = (gl * 8 + xcd) * GM + rr / GN; tn = ng * GN + rr % GN;
-        return tm < tiles_m && tn < tiles_n;
-    };
-    auto next_round = [&](int sq) -> int {
-        int tm, tn;
-        while (sq < S_total && !tile_at(sq, tm, tn)) ++sq;
-        return sq;
-    };
+    PlOrder ord;                                     // XCD-aware tile order (PlOrder above)
+    ord.init(tiles_m, tiles_n, (int)gridDim.x, (int)blockIdx.x, a.whole_groups != 0);
+    const int S_total = ord.S_total;
+    auto tile_at = [&](int sq, int& tm, int& tn) -> bool { return ord.tile_at(sq, tm, tn); };
+    auto next_round = [&](int sq) -> int { return ord.next_round(sq); };
     int qs = next_round(0), iks = 0;                 // cursor of the next stage to issue (round, k-stage)
     int qtm = 0, qtn = 0;                            // its tile; past the end: the last one again (re-read, never stored)
     if (qs < S_total) tile_at(qs, qtm, qtn);
@@ -893,8 +931,58 @@ static int pw_gemm_variant(int64_t m, int k, int n, int dtype) {
     if (!(ad_is_half(dtype) && m >= 2048 && (n % 192 == 0 || n % 128 == 0))) return 0;
     return (k / 64) % 2 == 0 && k >= 256 ? 2 : 1;
 }
+// rounds of the slowest workgroup of an LDS-tiled launch with NT-channel tiles (PlOrder; workgroup 0 sits on XCD 0, which takes
+// the first block of every ragged set)
+static int pw_rounds(int64_t m, int n, int nt, int* grid_out) {
+    const int tiles_m = (int)((m + 255) / 256), tiles_n = n / nt;
+    const int ntiles = tiles_m * tiles_n;
+    const int grid = ntiles < ad_num_cu() ? ntiles : ad_num_cu();
+    PlOrder o;
+    o.init(tiles_m, tiles_n, grid, 0);
+    if (grid_out) *grid_out = grid;
+    return o.S_total;
+}
+// channels per tile / 32.  256-channel tiles (a wave: 64 pixels x 128 channels, fewer LDS bytes per MFMA than the 192- and
+// 128-channel tiles: +5 ... +19 % per tile-column on the dx products of the Experiment-2 levels) where the width allows, K is
+// long enough for the arithmetic to dominate and the launch does not lose more to whole rounds than the tile gains
+// (rounds x tile width / measured relative rate).  AD_PW_NW8=0 in the environment: off.
+static bool pw_new_order() {
+    static const bool on = !(getenv("AD_PW_NW8") && getenv("AD_PW_NW8")[0] == '0');
+    return on;
+}
+static int pw_gemm_nw(int64_t m, int k, int n) {
+    const bool nw8 = pw_new_order();
+    const int base = n % 192 == 0 ? 6 : 4;
+    if (!(nw8 && n % 256 == 0 && k >= 256)) return base;
+    // measured per-column rates relative to the 192-channel tile at equal round quantisation (E2s07's levels): 256: 1.05-1.08,
+    // 128: 0.88
+    const double c8 = (double)pw_rounds(m, n, 256, nullptr) * 256 / 1.08;
+    const double cb = (double)pw_rounds(m, n, 32 * base, nullptr) * 32 * base / (base == 6 ? 1.0 : 0.88);
+    return c8 <= cb ? 8 : base;
+}
 extern "C" int ad_pw_gemm_variant(int64_t m, int k, int n, int dtype) {
     return ad_pw_supported(m, k, n, dtype) ? pw_gemm_variant(m, k, n, dtype) : -1;
+}
+
+extern "C" int ad_pw_gemm_tile_channels(int64_t m, int k, int n, int dtype) {
+    if (!ad_pw_supported(m, k, n, dtype) || pw_gemm_variant(m, k, n, dtype) == 0) return 0;
+    return 32 * pw_gemm_nw(m, k, n);
+}
+
+extern "C" int ad_pw_gemm_tile_order(int tiles_m, int tiles_n, int grid, int* tiles, int max_rounds) {
+    if (tiles_m <= 0 || tiles_n <= 0 || grid <= 0 || !tiles || max_rounds <= 0) return -1;
+    int rounds = 0;
+    for (int b = 0; b < grid; ++b) {
+        PlOrder o;
+        o.init(tiles_m, tiles_n, grid, b);
+        if (o.S_total > max_rounds) return -1;
+        if (o.S_total > rounds) rounds = o.S_total;
+        for (int sq = 0; sq < max_rounds; ++sq) {
+            int tm = 0, tn = 0;
+            tiles[(size_t)b * max_rounds + sq] = (sq < o.S_total && o.tile_at(sq, tm, tn)) ? tm * tiles_n + tn : -1;
+        }
+    }
+    return rounds;
 }
 
 extern "C" int ad_pw_gemm(const void* x, const void* bank, void* y, int64_t m, int k, int n, int dtype, void* stream) {
@@ -905,6 +993,7 @@ extern "C" int ad_pw_gemm(const void* x, const void* bank, void* y, int64_t m, i
     a.x = (const char*)x; a.bp = (const char*)bank; a.y = (char*)y;
     a.m = (int)m; a.k = k; a.n = n;
     a.nb_per_wg = 0;
+    a.whole_groups = pw_new_order() ? 0 : 1;
     a.dbg = nullptr;
 #ifdef AD_STAMP
     a.dbg = g_pw_dbg;
@@ -912,7 +1001,7 @@ extern "C" int ad_pw_gemm(const void* x, const void* bank, void* y, int64_t m, i
     const int variant = pw_gemm_variant(m, k, n, dtype);
     if (variant > 0) {                                                              // LDS-tiled persistent kernel
         hipStream_t s = (hipStream_t)stream;
-        const int nw = n % 192 == 0 ? 6 : 4;
+        const int nw = pw_gemm_nw(m, k, n);
         const int ntiles = (int)((m + 255) / 256) * (n / (32 * nw));
         const int grid = ntiles < ad_num_cu() ? ntiles : ad_num_cu();
         // two stages of loads in flight where a tile has >= 4 k-stages that pair up (K = 128, two stages a tile: 10 % slower)
@@ -926,7 +1015,9 @@ extern "C" int ad_pw_gemm(const void* x, const void* bank, void* y, int64_t m, i
         }                                                                                                            \
         pw_gemm_lds_kernel<E_, NW_, D_><<<grid, PL_T, 2 * PlGeo<NW_>::STAGE, s>>>(a);                                \
     }
-        if (nw == 6) {
+        if (nw == 8) {           // (two stages of loads in registers beside 128 accumulators spill: one stage ahead)
+            if (dtype == AD_BF16) PL_LAUNCH(bf16_t, 8, 1) else PL_LAUNCH(f16_t, 8, 1)
+        } else if (nw == 6) {
             if (dtype == AD_BF16) { if (depth == 2) PL_LAUNCH(bf16_t, 6, 2) else PL_LAUNCH(bf16_t, 6, 1) }
             else { if (depth == 2) PL_LAUNCH(f16_t, 6, 2) else PL_LAUNCH(f16_t, 6, 1) }
         } else {

@@ -432,6 +432,13 @@ int ad_pw_supported(int64_t m, int k, int n, int dtype);
 size_t ad_pw_bank_elems(int cin, int cout);
 int ad_pw_bank_pack(const float* w_hwio, int cin, int cout, void* bank_fwd, void* bank_bwd, int dtype, void* stream);
 int ad_pw_gemm(const void* x, const void* bank, void* y, int64_t m, int k, int n, int dtype, void* stream);
+/* Introspection of the LDS-tiled ad_pw_gemm launch (host only, no GPU work): channels per tile it would use for a shape (256 /
+ * 192 / 128; 0: the shape runs on the kernel without LDS tiles), and the XCD-aware tile order of a launch of `grid` workgroups
+ * over tiles_m x tiles_n tiles: tiles[b * max_rounds + r] = tile index (row-major) workgroup b computes in its round r, or -1;
+ * returns the number of rounds of the slowest workgroup (-1: bad arguments / more than max_rounds).  tests/test_host_logic.py
+ * checks that every tile appears exactly once. */
+int ad_pw_gemm_tile_channels(int64_t m, int k, int n, int dtype);
+int ad_pw_gemm_tile_order(int tiles_m, int tiles_n, int grid, int* tiles, int max_rounds);
 /* the kernel ad_pw_gemm launches for a shape: 0 fragments from L2, 1 / 2 LDS-tiled with one / two k-stages of loads in flight
  * (-1: unsupported shape); for tests that must reach a given variant */
 int ad_pw_gemm_variant(int64_t m, int k, int n, int dtype);

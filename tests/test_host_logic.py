@@ -241,3 +241,33 @@ def test_multitask_routing_follows_the_experiment_table():
     samples = [(s, rng.random((8, 8, 3)), rng.random((8, 8, 3))) for s in (0.5, 0.3, 0.5, 0.6, 0.5)]
     got = [(k, a.shape[0]) for k, a, _ in M.bucket_by_depth(samples, batch_size=2)]
     assert got == [((0.5, 3), 2), ((0.5, 3), 1), ((0.3, 2), 1), ((0.6, 4), 1)]
+
+
+def test_bank_gemm_tile_order_visits_every_tile_once_and_balances_the_xcds():
+    """The XCD-aware tile order of the LDS-tiled bank GEMM (upconv.hip PlOrder; host twin ad_pw_gemm_tile_order): every tile of
+    every (tiles_m, tiles_n, grid) exactly once, and the slowest workgroup within two rounds of the mean (before the leftover row
+    groups were dealt block by block, the 145 x 18 tiles of Experiment 2's 34-wide level took 18 rounds on two XCDs, 9 on six)."""
+    from adunet_amd import _lib
+    lib = _lib.load()
+    shapes = [(tm, tn, g) for tm in (1, 2, 3, 7, 8, 9, 31, 64, 125, 145, 146, 290, 1024) for tn in (1, 2, 3, 4, 6, 8, 9, 12, 18, 24, 36)
+              for g in (256, 192, 64, 8, 5)]
+    worst = 0.0
+    for tm, tn, grid in shapes:
+        g = min(grid, tm * tn)
+        cap = 4 * (tm * tn + g - 1) // g + 64
+        buf = np.full((g, cap), -2, np.int32)
+        rounds = lib.ad_pw_gemm_tile_order(tm, tn, g, buf.ctypes.data, cap)
+        assert rounds > 0, (tm, tn, g)
+        seen = buf[buf >= 0]
+        assert seen.size == tm * tn and np.array_equal(np.sort(seen), np.arange(tm * tn)), (tm, tn, g)
+        if g % 8 == 0 and tm * tn >= 4 * g:
+            worst = max(worst, rounds / (tm * tn / g))
+            assert rounds <= np.ceil(tm * tn / g) * 1.5 + 2, (tm, tn, g, rounds)
+    # the shape that showed the imbalance: 145 x 18 tiles on 256 workgroups = 10.2 rounds of work
+    buf = np.empty((256, 64), np.int32)
+    assert lib.ad_pw_gemm_tile_order(145, 18, 256, buf.ctypes.data, 64) <= 13
+    # tile width: the 256-channel tile where it divides the width and does not cost rounds, else 192 / 128; 0 off the LDS path
+    assert lib.ad_pw_gemm_tile_channels(8 * 63 * 63, 4608, 1024, _lib.AD_BF16) == 256
+    assert lib.ad_pw_gemm_tile_channels(64 * 64 * 64, 128, 576, _lib.AD_BF16) == 192
+    assert lib.ad_pw_gemm_tile_channels(64 * 64 * 64, 576, 128, _lib.AD_BF16) == 128
+    assert lib.ad_pw_gemm_tile_channels(64 * 64 * 64, 128, 576, _lib.AD_F32) == 0
