@@ -335,6 +335,7 @@ __device__ __forceinline__ uint4 load_w_slot(const char* wp, int kc_total, int c
 #define AD_EPI_MASK 3           // internal: ad_conv3x3_dgrad_relu (ReLU-grad of the producer fused into this dgrad)
 #define AD_EPI_LNBWD 4          // internal: ad_conv3x3_dgrad_ln_bwd (LayerNorm + ReLU backward of the producer fused into this dgrad)
 #define AD_EPI_LN_STATS 5        // internal: ad_conv3x3_ln_relu_fwd without an activation tensor: z and the LayerNorm statistics only
+#define AD_EPI_LN_ACT 6          // internal: ad_conv3x3_ln_relu_fwd without z (inference): the activation only (y1 = act)
 #define AD_ERR_UNFUSED 1000     // internal: no fused kernel for this shape, run the two launches
 
 struct ConvArgs {
@@ -760,7 +761,7 @@ __device__ __forceinline__ void ws_pack_tile(const f32x4 (&acc)[4][4], const flo
         // EPI 2 arithmetic is written on float pairs: v_pk_add / v_pk_mul / v_pk_fma_f32 do two channels per instruction,
         // and this VALU work sits between the MFMA phases of two items (it is not hidden behind anything)
         float mean = 0.f, rstd = 0.f;
-        if (EPI == 2 || EPI == 5) {
+        if (EPI == 2 || EPI == 5 || EPI == 6) {
             // Two passes, as LayerNormalization itself (mean, then the mean of squared DEVIATIONS) and ln_fwd_kernel: until r03 this
             // was E[x^2] - mean^2 in one pass, whose cancellation costs (mean / std)^2 * 2^-24 of the variance -- 10 % at
             // mean / std = 1 000 (test_fused_layernorm_epilogue_with_a_large_mean_offset; found through ADVICE r03).  Price: eight
@@ -779,9 +780,11 @@ __device__ __forceinline__ void ws_pack_tile(const f32x4 (&acc)[4][4], const flo
                 s2 = __builtin_elementwise_fma(hi, hi, s2);
             }
             rstd = rsqrtf(sum_lane_groups(s2.x + s2.y) * (1.f / 64.f) + eps);
-            const unsigned so = ok && grp == 0 ? (unsigned)((pixbase + (wave * 4 + mt) * img_w + (lane & 15)) * 4) : WR_OOB;
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, mean), rsm, so, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, rstd), rsr, so, 0, 0);
+            if (EPI != 6) {       // (6: inference, nobody reads the statistics)
+                const unsigned so = ok && grp == 0 ? (unsigned)((pixbase + (wave * 4 + mt) * img_w + (lane & 15)) * 4) : WR_OOB;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, mean), rsm, so, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, rstd), rsr, so, 0, 0);
+            }
         }
         // normalisation as two fused multiply-adds per pair, xhat = v * rstd + (-mean * rstd), y = xhat * gamma + beta
         // (r03; subtract / multiply / fma before: one packed instruction per pair less), ReLU on the PACKED 16-bit result
@@ -794,7 +797,7 @@ __device__ __forceinline__ void ws_pack_tile(const f32x4 (&acc)[4][4], const flo
         for (int np = 0; np < 2; ++np) {
             union { typename Half16<E>::v4 h; u32x2 u; } pa, pb, qa, qb;
             f32x4 ga = {}, gb4 = {}, ba = {}, bb = {};
-            if (EPI == 2) {
+            if (EPI == 2 || EPI == 6) {
                 ga = *reinterpret_cast<const f32x4*>(gb + (2 * np) * 16 + grp * 4);
                 gb4 = *reinterpret_cast<const f32x4*>(gb + (2 * np + 1) * 16 + grp * 4);
                 ba = *reinterpret_cast<const f32x4*>(gb + 64 + (2 * np) * 16 + grp * 4);
@@ -805,10 +808,12 @@ __device__ __forceinline__ void ws_pack_tile(const f32x4 (&acc)[4][4], const flo
                 f32x2 va = h ? acc[mt][2 * np].zw : acc[mt][2 * np].xy;
                 f32x2 vb = h ? acc[mt][2 * np + 1].zw : acc[mt][2 * np + 1].xy;
                 if (EPI == 1) { va = relu2(va); vb = relu2(vb); }
-                const e16x2 za = __builtin_convertvector(va, e16x2), zb = __builtin_convertvector(vb, e16x2);
-                pa.u[h] = __builtin_bit_cast(unsigned, za);
-                pb.u[h] = __builtin_bit_cast(unsigned, zb);
-                if (EPI == 2) {
+                if (EPI != 6) {
+                    const e16x2 za = __builtin_convertvector(va, e16x2), zb = __builtin_convertvector(vb, e16x2);
+                    pa.u[h] = __builtin_bit_cast(unsigned, za);
+                    pb.u[h] = __builtin_bit_cast(unsigned, zb);
+                }
+                if (EPI == 2 || EPI == 6) {
                     f32x2 ya = __builtin_elementwise_fma(__builtin_elementwise_fma(va, rstd2, nmr2), h ? ga.zw : ga.xy, h ? ba.zw : ba.xy);
                     f32x2 yb = __builtin_elementwise_fma(__builtin_elementwise_fma(vb, rstd2, nmr2), h ? gb4.zw : gb4.xy, h ? bb.zw : bb.xy);
                     // (built as values, not through the union: writing .h elements and reading .u back in the same iteration
@@ -821,10 +826,12 @@ __device__ __forceinline__ void ws_pack_tile(const f32x4 (&acc)[4][4], const flo
                     qb.u[h] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, tb), s16x2{0, 0}));
                 }
             }
-            const u32x2 s0 = __builtin_amdgcn_permlane16_swap(pa.u[0], pb.u[0], false, false);
-            const u32x2 s1 = __builtin_amdgcn_permlane16_swap(pa.u[1], pb.u[1], false, false);
-            pend[mt * 2 + np] = u32x4{s0[0], s1[0], s0[1], s1[1]};
-            if (EPI == 2) {
+            if (EPI != 6) {
+                const u32x2 s0 = __builtin_amdgcn_permlane16_swap(pa.u[0], pb.u[0], false, false);
+                const u32x2 s1 = __builtin_amdgcn_permlane16_swap(pa.u[1], pb.u[1], false, false);
+                pend[mt * 2 + np] = u32x4{s0[0], s1[0], s0[1], s1[1]};
+            }
+            if (EPI == 2 || EPI == 6) {
                 const u32x2 r0 = __builtin_amdgcn_permlane16_swap(qa.u[0], qb.u[0], false, false);
                 const u32x2 r1 = __builtin_amdgcn_permlane16_swap(qa.u[1], qb.u[1], false, false);
                 pend[(NPEND - 8) + mt * 2 + np] = u32x4{r0[0], r1[0], r0[1], r1[1]};
@@ -858,7 +865,9 @@ __device__ __forceinline__ void ws_mma_role(const ConvArgs& a, const char* xb0, 
     const int nblk = a.cout / BN;
     const int npix = a.n * a.h * a.w;
     const int grp = lane >> 4;
-    constexpr bool LN = EPI == 2 || EPI == 5;      // 5: z and the LayerNorm statistics, no activation (ad_conv3x3_ln_relu_fwd, act == NULL)
+    // 5: z and the LayerNorm statistics, no activation (ad_conv3x3_ln_relu_fwd, act == NULL); 6: the activation alone, neither z nor
+    // statistics (z == NULL: inference -- one output stream instead of two); its pieces take z's place in pend[0..7] and y1 is `act`
+    constexpr bool LN = EPI == 2 || EPI == 5 || EPI == 6;
     float4 bv[4];
     if (!LN) {
 #pragma unroll
@@ -874,8 +883,8 @@ __device__ __forceinline__ void ws_mma_role(const ConvArgs& a, const char* xb0, 
     else { yp = a.y2; cy = a.cout_real - a.cy1; coff = nb * BN - a.cy1; }
     const auto rsy = wave_uniform_rsrc(yp, npix * cy * TSZ);
     const auto rsa = wave_uniform_rsrc(EPI == 2 ? a.a_out : yp, npix * cy * TSZ);
-    const auto rsm = wave_uniform_rsrc(LN ? (const void*)a.ln_mean : (const void*)yp, npix * 4);
-    const auto rsr = wave_uniform_rsrc(LN ? (const void*)a.ln_rstd : (const void*)yp, npix * 4);
+    const auto rsm = wave_uniform_rsrc(LN && EPI != 6 ? (const void*)a.ln_mean : (const void*)yp, npix * 4);
+    const auto rsr = wave_uniform_rsrc(LN && EPI != 6 ? (const void*)a.ln_rstd : (const void*)yp, npix * 4);
     const int abase0 = ((wave * 4 + 1) * 18 + (lane & 15) + 1) * PIXB + P::a_lane_off(lane);
     int soff[4];
 #pragma unroll
@@ -1304,7 +1313,7 @@ __global__ __launch_bounds__(WR_T, 1) void conv3x3_fwd_wres_kernel(ConvArgs a) {
     }
 
     float* gb = reinterpret_cast<float*>(wt + 2 * WT_BYTES);
-    if (EPI == 2 || EPI == 4 || EPI == 5) {       // [gamma][beta][bias] of the 64 output channels; visible to the MFMA waves after this barrier
+    if (EPI == 2 || EPI == 4 || EPI == 5 || EPI == 6) {       // [gamma][beta][bias] of the 64 output channels; visible to the MFMA waves after this barrier
         if (tid < 64) {
             gb[tid] = a.ln_gamma[tid]; gb[64 + tid] = a.ln_beta[tid]; gb[128 + tid] = a.bias ? a.bias[tid] : 0.f;
         }
@@ -1424,7 +1433,7 @@ __global__ __launch_bounds__(WR_T, 1) void conv3x3_fwd_ws_kernel(ConvArgs a) {
     const int npix = a.n * a.h * a.w;
     const int nloc = o.nloc;                        // items of this workgroup (>= 1)
     float* gb = reinterpret_cast<float*>(wt1 + WT_BYTES);
-    if (EPI == 2 || EPI == 4) {       // [gamma][beta][bias] of the 64 output channels; visible to the MFMA waves after this barrier
+    if (EPI == 2 || EPI == 4 || EPI == 6) {       // [gamma][beta][bias] of the 64 output channels; visible to the MFMA waves after this barrier
         if (tid < 64) {
             gb[tid] = a.ln_gamma[tid]; gb[64 + tid] = a.ln_beta[tid]; gb[128 + tid] = a.bias ? a.bias[tid] : 0.f;
         }
@@ -2301,7 +2310,7 @@ __device__ __forceinline__ C3Halo c3_halo_setup(int tid) {
     const int nn = r_ / a.tiles_y;                                                                        \
     const int y0 = (r_ - nn * a.tiles_y) << 4;
 
-template <typename E>
+template <typename E, bool ACT_ONLY = false>   // ACT_ONLY: z == NULL (inference), the activation alone leaves the launch
 __global__ __launch_bounds__(C3_T, 2) void conv3x3_c3_fwd_kernel(C3Args a) {
     typedef typename Half16<E>::v8 v8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -2331,10 +2340,10 @@ __global__ __launch_bounds__(C3_T, 2) void conv3x3_c3_fwd_kernel(C3Args a) {
     }
     const C3Halo hsl = c3_halo_setup(tid);
     const auto rsx = wave_uniform_rsrc(a.x, npix * 12);
-    const auto rsz = wave_uniform_rsrc(a.z, npix * 128);
+    const auto rsz = wave_uniform_rsrc(ACT_ONLY ? a.act : a.z, npix * 128);
     const auto rsa = wave_uniform_rsrc(a.act, npix * 128);
-    const auto rsm = wave_uniform_rsrc(a.mean, npix * 4);
-    const auto rsr = wave_uniform_rsrc(a.rstd, npix * 4);
+    const auto rsm = wave_uniform_rsrc(ACT_ONLY ? (const void*)a.act : (const void*)a.mean, npix * 4);
+    const auto rsr = wave_uniform_rsrc(ACT_ONLY ? (const void*)a.act : (const void*)a.rstd, npix * 4);
     int soff[4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
@@ -2372,13 +2381,17 @@ __global__ __launch_bounds__(C3_T, 2) void conv3x3_c3_fwd_kernel(C3Args a) {
             for (int nt = 0; nt < 4; ++nt)
                 acc[mt][nt] = Half16<E>::mfma(wf[nt], xf, acc[mt][nt]);
         }
-        u32x4 pend[16];
+        u32x4 pend[ACT_ONLY ? 8 : 16];
         unsigned pvo[4];
-        ws_pack_tile<2, E>(acc, gb, a.eps, wave, lane, a.h, a.w_img, nn, y0, x0, 64, soff, rsm, rsr, pend, pvo);
+        ws_pack_tile<ACT_ONLY ? 6 : 2, E>(acc, gb, a.eps, wave, lane, a.h, a.w_img, nn, y0, x0, 64, soff, rsm, rsr, pend, pvo);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            __builtin_amdgcn_raw_buffer_store_b128(pend[i], rsz, pvo[i >> 1], (i & 1) * 64, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(pend[8 + i], rsa, pvo[i >> 1], (i & 1) * 64, 0);
+            if constexpr (ACT_ONLY) {
+                __builtin_amdgcn_raw_buffer_store_b128(pend[i], rsa, pvo[i >> 1], (i & 1) * 64, 0);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b128(pend[i], rsz, pvo[i >> 1], (i & 1) * 64, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(pend[8 + i], rsa, pvo[i >> 1], (i & 1) * 64, 0);
+            }
         }
         buf ^= 1;
     }
@@ -2736,7 +2749,7 @@ template <typename P>
 int launch_fwd_runs(ConvArgs a, void* ws, size_t ws_bytes, hipStream_t s) {
     int chunk = a.n;
     if constexpr (sizeof(typename P::T) == 2)
-        chunk = images_per_launch(a.n, a.h, a.w, a.c1, a.c2, a.cout_real, a.epilogue == AD_EPI_LN_RELU || a.epilogue == AD_EPI_LN_STATS, false);
+        chunk = images_per_launch(a.n, a.h, a.w, a.c1, a.c2, a.cout_real, a.epilogue == AD_EPI_LN_RELU || a.epilogue == AD_EPI_LN_STATS || a.epilogue == AD_EPI_LN_ACT, false);
     if (chunk >= a.n) return launch_fwd<P>(a, ws, ws_bytes, s);
     constexpr size_t TSZ = sizeof(typename P::T);
     for (int i0 = 0; i0 < a.n; i0 += chunk) {
@@ -2808,7 +2821,7 @@ int launch_fwd(ConvArgs a, void* ws, size_t ws_bytes, hipStream_t s) {
             AD_LAUNCH_CHECK("conv3x3_map1");
             return AD_OK;
         }
-        int kind = fwd_ws_kind(a.n, a.h, a.w, a.c1, a.c2, a.cout_real, a.epilogue == AD_EPI_LN_RELU || a.epilogue == AD_EPI_LN_STATS);
+        int kind = fwd_ws_kind(a.n, a.h, a.w, a.c1, a.c2, a.cout_real, a.epilogue == AD_EPI_LN_RELU || a.epilogue == AD_EPI_LN_STATS || a.epilogue == AD_EPI_LN_ACT);
         if (a.cy1 % BN && a.cy1 != a.cout_real) kind = 0;          // a split inside a 64-channel block: generic kernel
         // Two output tensors whose block counts each suit the XCD-aware work order although their sum does not (the
         // dgrad of a Concatenate of 2 nf + nf channels: 3, 6, 12, 24 blocks): one launch per output on a slice of the
@@ -2838,6 +2851,18 @@ int launch_fwd(ConvArgs a, void* ws, size_t ws_bytes, hipStream_t s) {
             if (kind != 1 || a.cout_real != BN) return AD_ERR_UNFUSED;
             conv3x3_fwd_wres_kernel<P, 4><<<NUM_CU, WR_T, WR_LDS, s>>>(a);
             AD_LAUNCH_CHECK("conv3x3_fwd_wres (layernorm-bwd)");
+            return AD_OK;
+        }
+        if (a.epilogue == AD_EPI_LN_ACT) {
+            if (kind == 0 || a.cout_real != BN) return AD_ERR_UNFUSED;
+            static std::atomic<unsigned long long> act_attr{0};
+            if (ad_first_on_device(act_attr)) {
+                allow_big_lds(conv3x3_fwd_wres_kernel<P, 6>);
+                allow_big_lds(conv3x3_fwd_ws_kernel<P, 6>);
+            }
+            if (kind == 1) conv3x3_fwd_wres_kernel<P, 6><<<NUM_CU, WR_T, WR_LDS, s>>>(a);
+            else conv3x3_fwd_ws_kernel<P, 6><<<NUM_CU, WR_T, WR_LDS, s>>>(a);
+            AD_LAUNCH_CHECK("conv3x3_fwd (layernorm + relu, activation only)");
             return AD_OK;
         }
         if (a.epilogue == AD_EPI_LN_STATS) {
@@ -2875,7 +2900,8 @@ int launch_fwd(ConvArgs a, void* ws, size_t ws_bytes, hipStream_t s) {
         if (kind == 2) AD_WS_LAUNCH(conv3x3_fwd_ws_kernel, "conv3x3_fwd_ws")
 #undef AD_WS_LAUNCH
     }
-    if (a.epilogue == AD_EPI_LN_RELU || a.epilogue == AD_EPI_MASK || a.epilogue == AD_EPI_LNBWD || a.epilogue == AD_EPI_LN_STATS)
+    if (a.epilogue == AD_EPI_LN_RELU || a.epilogue == AD_EPI_MASK || a.epilogue == AD_EPI_LNBWD || a.epilogue == AD_EPI_LN_STATS ||
+        a.epilogue == AD_EPI_LN_ACT)
         return AD_ERR_UNFUSED;     // the caller runs two launches
     size_t lds = 2 * (size_t)g.NPHP * 4 + 2 * BN * 4 + (((size_t)g.NPH * PIXB + 15) & ~15) + (size_t)FWS * FT * 16;
     if (lds > 160 * 1024) return ad_set_error(AD_ERR_ARG, "conv3x3_fwd: LDS %zu too large", lds);
@@ -3090,7 +3116,11 @@ extern "C" int ad_conv3x3_ln_relu_fwd(const void* x1, int c1, const void* x2, in
                                       void* act, float* mean, float* rstd, int n, int h, int w, int cout, void* ws,
                                       size_t ws_bytes, int dtype, void* stream) {
     AD_REQUIRE(ad_dtype_ok(dtype), "ad_conv3x3_ln_relu_fwd: bad dtype %d", dtype);
-    AD_REQUIRE(gamma && beta && z && mean && rstd, "ad_conv3x3_ln_relu_fwd: NULL LayerNorm operand");
+    AD_REQUIRE(gamma && beta, "ad_conv3x3_ln_relu_fwd: NULL LayerNorm parameter");
+    AD_REQUIRE(z || (act && ad_conv3x3_ln_relu_is_fused(n, h, w, c1, c2, cout, dtype)),
+               "ad_conv3x3_ln_relu_fwd: z == NULL (activation only) has no kernel for n=%d %dx%d c1=%d c2=%d cout=%d dtype=%d "
+               "(ask ad_conv3x3_ln_relu_is_fused first)", n, h, w, c1, c2, cout, dtype);
+    AD_REQUIRE(!z || (mean && rstd), "ad_conv3x3_ln_relu_fwd: NULL statistics operand");
     AD_REQUIRE(act || ad_conv3x3_ln_stats_is_fused(n, h, w, c1, c2, cout, dtype),
                "ad_conv3x3_ln_relu_fwd: act == NULL (statistics only) has no kernel for n=%d %dx%d c1=%d c2=%d cout=%d dtype=%d "
                "(ask ad_conv3x3_ln_stats_is_fused first)", n, h, w, c1, c2, cout, dtype);
@@ -3102,19 +3132,20 @@ extern "C" int ad_conv3x3_ln_relu_fwd(const void* x1, int c1, const void* x2, in
     ConvArgs a;
     a.x1 = (const char*)x1; a.x2 = (const char*)x2; a.c1 = c1; a.c2 = c2;
     a.wp = (const char*)w_packed; a.bias = bias;
-    a.y1 = (char*)z; a.y2 = nullptr; a.cy1 = cout;
-    a.n = n; a.h = h; a.w = w; a.cout = pad64(cout); a.cout_real = cout; a.epilogue = act ? AD_EPI_LN_RELU : AD_EPI_LN_STATS;
+    a.y1 = (char*)(z ? z : act); a.y2 = nullptr; a.cy1 = cout;       // (z == NULL: the activation is the launch's one output)
+    a.n = n; a.h = h; a.w = w; a.cout = pad64(cout); a.cout_real = cout;
+    a.epilogue = !z ? AD_EPI_LN_ACT : act ? AD_EPI_LN_RELU : AD_EPI_LN_STATS;
     a.dbg = g_dbg;
     a.ksplit = 1; a.slab = nullptr;
     a.ln_gamma = gamma; a.ln_beta = beta; a.ln_eps = eps;
-    a.a_out = (char*)act; a.ln_mean = mean; a.ln_rstd = rstd;
+    a.a_out = (char*)(z ? act : nullptr); a.ln_mean = mean; a.ln_rstd = rstd;
     a.mask1 = nullptr; a.dbias_part = nullptr; a.lnb_z = nullptr;
     pick_geo(n, h, w, &a.g);
     a.ntiles = a.g.tiles_x * a.g.tiles_y * a.g.tiles_i;
     hipStream_t s = (hipStream_t)stream;
     int rc = launch_fwd_dtype(dtype, a, ws, ws_bytes, s);
     if (rc != AD_ERR_UNFUSED) return rc;
-    AD_REQUIRE(act, "ad_conv3x3_ln_relu_fwd: act == NULL needs the fused kernel");
+    AD_REQUIRE(act && z, "ad_conv3x3_ln_relu_fwd: act == NULL / z == NULL need the fused kernel");
     a.epilogue = AD_EPI_NONE;
     rc = launch_fwd_dtype(dtype, a, ws, ws_bytes, s);
     if (rc) return rc;
@@ -3248,12 +3279,15 @@ extern "C" int ad_conv3x3_c3_ln_relu_fwd(const float* x, const float* w_hwio, co
                                          const float* beta, float eps, void* z, void* act, float* mean, float* rstd,
                                          int n, int h, int w, int dtype, void* stream) {
     AD_REQUIRE(ad_is_half(dtype), "ad_conv3x3_c3_ln_relu_fwd: 16-bit storage types only (dtype %d)", dtype);
-    AD_REQUIRE(x && w_hwio && gamma && beta && z && act && mean && rstd, "ad_conv3x3_c3_ln_relu_fwd: NULL operand");
+    AD_REQUIRE(x && w_hwio && gamma && beta && act && (!z || (mean && rstd)), "ad_conv3x3_c3_ln_relu_fwd: NULL operand");
     C3Args a; int grid;
     AD_REQUIRE(c3_plan(n, h, w, &a, &grid), "ad_conv3x3_c3_ln_relu_fwd: unsupported shape n=%d h=%d w=%d", n, h, w);
     a.x = x; a.w = w_hwio; a.bias = bias; a.gamma = gamma; a.beta = beta; a.eps = eps;
     a.z = (char*)z; a.act = (char*)act; a.mean = mean; a.rstd = rstd; a.dz = nullptr; a.ws = nullptr;
-    if (dtype == AD_BF16) conv3x3_c3_fwd_kernel<bf16_t><<<grid, C3_T, 2 * C3_HB + 3 * BN * 4, (hipStream_t)stream>>>(a);
+    if (!z) {        // inference: the activation only (as ad_conv3x3_ln_relu_fwd with z == NULL)
+        if (dtype == AD_BF16) conv3x3_c3_fwd_kernel<bf16_t, true><<<grid, C3_T, 2 * C3_HB + 3 * BN * 4, (hipStream_t)stream>>>(a);
+        else conv3x3_c3_fwd_kernel<f16_t, true><<<grid, C3_T, 2 * C3_HB + 3 * BN * 4, (hipStream_t)stream>>>(a);
+    } else if (dtype == AD_BF16) conv3x3_c3_fwd_kernel<bf16_t><<<grid, C3_T, 2 * C3_HB + 3 * BN * 4, (hipStream_t)stream>>>(a);
     else conv3x3_c3_fwd_kernel<f16_t><<<grid, C3_T, 2 * C3_HB + 3 * BN * 4, (hipStream_t)stream>>>(a);
     AD_LAUNCH_CHECK("ad_conv3x3_c3_ln_relu_fwd");
     return AD_OK;

@@ -564,11 +564,12 @@ class Model:
                         z, a, mean, rstd = ops.conv3x3_c3_ln_relu_fwd(cur1, self.param(cs.name + "/kernel"),
                                                                       self.param(cs.name + "/bias"),
                                                                       self.param(cs.ln + "/gamma"), self.param(cs.ln + "/beta"),
-                                                                      dtype=self.dtype)
+                                                                      dtype=self.dtype, want_z=keep or self.audit is not None)
                     else:
                         z, a, mean, rstd = ops.conv3x3_ln_relu_fwd(cur1, cur2, self._packs[cs.name][0],
                                                                    self.param(cs.name + "/bias"), self.param(cs.ln + "/gamma"),
-                                                                   self.param(cs.ln + "/beta"), cs.cout, want_act=not feeds_head)
+                                                                   self.param(cs.ln + "/beta"), cs.cout, want_act=not feeds_head,
+                                                                   want_z=keep or self.audit is not None)
                     if keep:
                         tape.append(("cla", cs, cur1, cur2, z, mean, rstd, step[2]))
                     if self.audit is not None:

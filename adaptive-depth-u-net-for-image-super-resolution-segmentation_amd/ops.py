@@ -267,14 +267,26 @@ def conv3x3_ln_stats_is_fused(x1: torch.Tensor, x2: Optional[torch.Tensor], cout
 
 
 def conv3x3_ln_relu_fwd(x1: torch.Tensor, x2: Optional[torch.Tensor], w_packed: torch.Tensor, bias: Optional[torch.Tensor],
-                        gamma: torch.Tensor, beta: torch.Tensor, cout: int, eps: float = LN_EPS, want_act: bool = True):
+                        gamma: torch.Tensor, beta: torch.Tensor, cout: int, eps: float = LN_EPS, want_act: bool = True,
+                        want_z: bool = True):
     """conv_block's Conv2D -> LayerNormalization -> ReLU.  Returns (z, act, mean, rstd): z is the conv output kept for
     the backward pass.  One launch where the library has the fused epilogue (cout == 64, large bf16 launches), else
     the library runs the convolution and the LayerNorm kernel back to back.
     want_act=False (conv3x3_ln_stats_is_fused must hold): the activation is not written, act is None -- for the layer in
-    front of the head in a train step, whose only consumer (head_ln_bwd) re-derives it from z."""
+    front of the head in a train step, whose only consumer (head_ln_bwd) re-derives it from z.
+    want_z=False (inference: nothing reads z or the statistics): where the fused epilogue exists the launch writes the activation
+    alone and z, mean, rstd are None; elsewhere the two launches run as always."""
     n, h, w, c1 = x1.shape
     c2 = x2.shape[-1] if x2 is not None else 0
+    if (not want_z and want_act and not os.environ.get("ADUNET_LN_TWO_LAUNCHES") and os.environ.get("ADUNET_INFER_KEEP_Z") != "1"
+            and _lib.load().ad_conv3x3_ln_relu_is_fused(n, h, w, c1, c2, cout, dt(x1.dtype))):
+        act = torch.empty((n, h, w, cout), dtype=x1.dtype, device=x1.device)
+        with _timed("conv3x3_ln_relu_fwd", 2.0 * n * h * w * 9 * (c1 + c2) * cout,        # same family, one output stream less
+                    float(n * h * w * (c1 + c2 + cout) * x1.element_size())):
+            check(_lib.load().ad_conv3x3_ln_relu_fwd(_p(x1), c1, _p(x2), c2, _p(w_packed), _p(bias), _p(gamma), _p(beta), eps,
+                                                     None, _p(act), None, None, n, h, w, cout, None, 0, dt(x1.dtype), _stream()),
+                  "ad_conv3x3_ln_relu_fwd (activation only)")
+        return None, act, None, None
     if not want_act:
         z = torch.empty((n, h, w, cout), dtype=x1.dtype, device=x1.device)
         mean = torch.empty(n * h * w, dtype=torch.float32, device=x1.device)
@@ -317,9 +329,17 @@ def conv3x3_c3_supported(x: torch.Tensor, cout: int, dtype: torch.dtype) -> bool
 
 
 def conv3x3_c3_ln_relu_fwd(x: torch.Tensor, w_hwio: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.Tensor,
-                           beta: torch.Tensor, eps: float = LN_EPS, dtype: torch.dtype = torch.bfloat16):
-    """First conv_block step on the raw [N,H,W,3] fp32 input: returns (z, act, mean, rstd), z / act in `dtype` (bf16 / fp16)."""
+                           beta: torch.Tensor, eps: float = LN_EPS, dtype: torch.dtype = torch.bfloat16, want_z: bool = True):
+    """First conv_block step on the raw [N,H,W,3] fp32 input: returns (z, act, mean, rstd), z / act in `dtype` (bf16 / fp16).
+    want_z=False (inference): the activation only, z / mean / rstd are None."""
     n, h, w, _ = x.shape
+    if not want_z and os.environ.get("ADUNET_INFER_KEEP_Z") != "1":
+        act = torch.empty((n, h, w, 64), dtype=dtype, device=x.device)
+        with _timed("conv3x3_c3_ln_relu_fwd", 2.0 * n * h * w * 27 * 64, float(n * h * w * (12 + 64 * act.element_size()))):
+            check(_lib.load().ad_conv3x3_c3_ln_relu_fwd(_p(x), _p(w_hwio), _p(bias), _p(gamma), _p(beta), eps, None, _p(act),
+                                                        None, None, n, h, w, dt(dtype), _stream()),
+                  "ad_conv3x3_c3_ln_relu_fwd (activation only)")
+        return None, act, None, None
     z = torch.empty((n, h, w, 64), dtype=dtype, device=x.device)
     act = torch.empty_like(z)
     mean = torch.empty(n * h * w, dtype=torch.float32, device=x.device)

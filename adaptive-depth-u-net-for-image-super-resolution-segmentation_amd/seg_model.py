@@ -274,7 +274,7 @@ class SegModel(Model):
                     mean = rstd = None
             else:
                 z, a, mean, rstd = ops.conv3x3_ln_relu_fwd(x1, x2, self._packs[cs.name][0], self.param(cs.name + "/bias"),
-                                                           g, b, cs.cout)
+                                                           g, b, cs.cout, want_z=keep or self.audit is not None)
             if keep:
                 tape.append(("cna", cs, nn, x1, x2, z, mean, rstd))
             if self.audit is not None:

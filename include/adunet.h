@@ -141,6 +141,9 @@ int ad_conv3x3_ln_relu_is_fused(int n, int h, int w, int c1, int c2, int cout, i
 /* act == NULL: z, mean and rstd only (the caller re-derives the activation where it is consumed: ad_head_ln_bwd with
  * xh == NULL).  Exists for the weights-resident kernel (c1 + c2 = 64 -> cout = 64); ad_conv3x3_ln_stats_is_fused tells. */
 int ad_conv3x3_ln_stats_is_fused(int n, int h, int w, int c1, int c2, int cout, int dtype);
+/* z == NULL (r05): the activation only -- inference (model(x), evaluate_model.py:94-137) reads neither the conv output nor the
+ * statistics, so the fused launch writes one tensor instead of two and two vectors; mean / rstd may be NULL.  The same arithmetic
+ * as the full form: act is bitwise what that writes.  Exists wherever ad_conv3x3_ln_relu_is_fused says 1. */
 int ad_conv3x3_ln_relu_fwd(const void* x1, int c1, const void* x2, int c2,
                            const void* w_packed, const float* bias,
                            const float* gamma, const float* beta, float eps,
@@ -152,7 +155,8 @@ int ad_conv3x3_ln_relu_fwd(const void* x1, int c1, const void* x2, int c2,
  * by LayerNormalization and ReLU (train_adaptive_unet.py:202-204 with inputs of :225) -- and its weight gradient,
  * without the zero-padded copy of the input: x is the raw [n, h, w, 3] fp32 batch, w_hwio the fp32 master kernel
  * [3, 3, 3, 64]; K = 27 is padded to one 32-deep MFMA step inside the kernels.  bf16 outputs, cout = 64 only
- * (ad_conv3x3_c3_supported tells); other first layers use ad_pad_channels + the general entry points. */
+ * (ad_conv3x3_c3_supported tells); other first layers use ad_pad_channels + the general entry points.
+ * z == NULL: the activation only (inference, as ad_conv3x3_ln_relu_fwd); mean / rstd may then be NULL. */
 int ad_conv3x3_c3_supported(int n, int h, int w, int cout, int dtype);
 int ad_conv3x3_c3_ln_relu_fwd(const float* x, const float* w_hwio, const float* bias,
                               const float* gamma, const float* beta, float eps,

@@ -353,6 +353,34 @@ def test_identity_at_initialisation(device):
     assert np.array_equal(model(x), np.clip(x, 0, 1))
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_inference_writes_activations_only_and_equals_the_training_forward(device, dtype, monkeypatch):
+    """model(x) (evaluate_model.py:94-137) keeps no tape: the fused Conv2D -> LayerNormalization -> ReLU launches of the full
+    resolution write the activation alone (ad_conv3x3_ln_relu_fwd / ad_conv3x3_c3_ln_relu_fwd with z == NULL).  Same arithmetic:
+    the output is bitwise that of the forward pass that also stores z and the statistics (ADUNET_INFER_KEEP_Z=1)."""
+    from adunet_amd import ops
+    from adunet_amd.model import build_super_resolution_unet
+    model, _ = build_super_resolution_unet(0.5, depth_override=2, input_size=128, dtype=dtype, device=device)
+    rng = np.random.default_rng(5)
+    model.set_weights(model.initial_weights(rng, head_uniform=0.05))
+    x = torch.tensor(rng.random((8, 128, 128, 3), dtype=np.float32), device=device)
+    calls = []
+    real = ops.conv3x3_ln_relu_fwd
+
+    def spy(*a, **kw):
+        out = real(*a, **kw)
+        calls.append(out[0] is None)
+        return out
+
+    monkeypatch.setattr(ops, "conv3x3_ln_relu_fwd", spy)
+    lean = model(x)
+    assert any(calls), "no launch took the activation-only form"
+    monkeypatch.setenv("ADUNET_INFER_KEEP_Z", "1")
+    calls.clear()
+    full = model(x)
+    assert not any(calls) and torch.equal(lean, full)
+
+
 def test_k1_config_fp32(device):
     """BASELINE config 1 (K1): x2 SR, 128-pixel patches, depth 2, batch 4, fp32."""
     oracle, params, model, rng = build_pair(0.5, 2, 128, torch.float32, device)

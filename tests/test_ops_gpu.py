@@ -454,6 +454,11 @@ def test_conv3x3_ln_relu_fwd(device, case):
         assert np.abs(gr / rs[ys, xs] - 1).max() < (1e-4 if dtype == F32 else 2e-2)
     z2, act2, mean2, rstd2 = ops.conv3x3_ln_relu_fwd(x1, x2, wf, f(b), f(gam), f(bet), cout)
     assert torch.equal(z, z2) and torch.equal(act, act2) and torch.equal(mean, mean2) and torch.equal(rstd, rstd2)
+    # inference form (z == NULL in the C ABI): the activation alone, bitwise the full form's; where no fused kernel exists the
+    # wrapper runs the two launches as always
+    z3, act3, mean3, rstd3 = ops.conv3x3_ln_relu_fwd(x1, x2, wf, f(b), f(gam), f(bet), cout, want_z=False)
+    assert torch.equal(act3, act)
+    assert (z3 is None and mean3 is None and rstd3 is None) == big
 
 
 @pytest.mark.parametrize("dtype", [BF16, F16])
@@ -580,6 +585,8 @@ def test_first_layer_three_channel_kernels(device, ws, shape):
     assert relerr(mean.view(n, h, w), zw.mean(-1)) < TOL[BF16]
     got_r = rstd.view(n, h, w).to(torch.float64).cpu().numpy()
     assert np.abs(got_r * np.sqrt(zw.var(-1) + 1e-3) - 1).max() < 2e-2
+    z0, act0, mean0, rstd0 = ops.conv3x3_c3_ln_relu_fwd(xd, f(wk), f(b), f(gam), f(bet), want_z=False)     # inference form
+    assert z0 is None and mean0 is None and rstd0 is None and torch.equal(act0, act)
     dz = rnd(rng.standard_normal((n, h, w, 64)), BF16)
     _, want, _ = ref.conv2d_same_bwd(xb, wk, dz, need_dx=False)
     dw = torch.full((3, 3, 3, 64), float("nan"), dtype=F32, device=device)
