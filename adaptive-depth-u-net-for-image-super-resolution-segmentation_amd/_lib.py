@@ -45,6 +45,7 @@ SIGNATURES = {
     "ad_conv3x3_dgrad_ln_bwd_ws_bytes": (_sz, []),
     "ad_conv3x3_dgrad_ln_bwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _i, _vp]),
     "ad_conv3x3_c3_supported": (_i, [_i, _i, _i, _i, _i]),
+    "ad_conv3x3_c3_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ad_conv3x3_c3_ln_relu_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ad_conv3x3_c3_wgrad_ws_bytes": (_sz, [_i, _i, _i]),
     "ad_conv3x3_c3_wgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _sz, _i, _vp]),

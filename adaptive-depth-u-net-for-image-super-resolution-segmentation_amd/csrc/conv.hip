@@ -2310,8 +2310,11 @@ __device__ __forceinline__ C3Halo c3_halo_setup(int tid) {
     const int nn = r_ / a.tiles_y;                                                                        \
     const int y0 = (r_ - nn * a.tiles_y) << 4;
 
-template <typename E, bool ACT_ONLY = false>   // ACT_ONLY: z == NULL (inference), the activation alone leaves the launch
+// MODE 0: z, act = relu(LayerNorm(z)), mean, rstd; 1: act alone (z == NULL: inference); 2: z = conv + bias alone (the first
+// Conv2D of the BatchNorm segmentation model, Segmenation/code/train_adaptive_unet.py:326: its BatchNorm needs batch statistics)
+template <typename E, int MODE = 0>
 __global__ __launch_bounds__(C3_T, 2) void conv3x3_c3_fwd_kernel(C3Args a) {
+    constexpr bool ACT_ONLY = MODE == 1, PLAIN = MODE == 2;
     typedef typename Half16<E>::v8 v8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* hb0 = smem;
@@ -2320,7 +2323,7 @@ __global__ __launch_bounds__(C3_T, 2) void conv3x3_c3_fwd_kernel(C3Args a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = lane >> 4;
     const int npix = a.n * a.h * a.w_img;
     if (tid < 64) {
-        gb[tid] = a.gamma[tid]; gb[64 + tid] = a.beta[tid]; gb[128 + tid] = a.bias ? a.bias[tid] : 0.f;
+        gb[tid] = PLAIN ? 0.f : a.gamma[tid]; gb[64 + tid] = PLAIN ? 0.f : a.beta[tid]; gb[128 + tid] = a.bias ? a.bias[tid] : 0.f;
     }
     // weight fragments (MFMA operand A): row = output channel nt*16 + (lane & 15), k = 8 grp .. 8 grp + 7
     v8 wf[4];
@@ -2341,9 +2344,9 @@ __global__ __launch_bounds__(C3_T, 2) void conv3x3_c3_fwd_kernel(C3Args a) {
     const C3Halo hsl = c3_halo_setup(tid);
     const auto rsx = wave_uniform_rsrc(a.x, npix * 12);
     const auto rsz = wave_uniform_rsrc(ACT_ONLY ? a.act : a.z, npix * 128);
-    const auto rsa = wave_uniform_rsrc(a.act, npix * 128);
-    const auto rsm = wave_uniform_rsrc(ACT_ONLY ? (const void*)a.act : (const void*)a.mean, npix * 4);
-    const auto rsr = wave_uniform_rsrc(ACT_ONLY ? (const void*)a.act : (const void*)a.rstd, npix * 4);
+    const auto rsa = wave_uniform_rsrc(PLAIN ? a.z : a.act, npix * 128);
+    const auto rsm = wave_uniform_rsrc(ACT_ONLY ? (const void*)a.act : PLAIN ? (const void*)a.z : (const void*)a.mean, npix * 4);
+    const auto rsr = wave_uniform_rsrc(ACT_ONLY ? (const void*)a.act : PLAIN ? (const void*)a.z : (const void*)a.rstd, npix * 4);
     int soff[4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
@@ -2381,13 +2384,15 @@ __global__ __launch_bounds__(C3_T, 2) void conv3x3_c3_fwd_kernel(C3Args a) {
             for (int nt = 0; nt < 4; ++nt)
                 acc[mt][nt] = Half16<E>::mfma(wf[nt], xf, acc[mt][nt]);
         }
-        u32x4 pend[ACT_ONLY ? 8 : 16];
+        u32x4 pend[MODE ? 8 : 16];
         unsigned pvo[4];
-        ws_pack_tile<ACT_ONLY ? 6 : 2, E>(acc, gb, a.eps, wave, lane, a.h, a.w_img, nn, y0, x0, 64, soff, rsm, rsr, pend, pvo);
+        ws_pack_tile<ACT_ONLY ? 6 : PLAIN ? 0 : 2, E>(acc, gb, a.eps, wave, lane, a.h, a.w_img, nn, y0, x0, 64, soff, rsm, rsr, pend, pvo);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             if constexpr (ACT_ONLY) {
                 __builtin_amdgcn_raw_buffer_store_b128(pend[i], rsa, pvo[i >> 1], (i & 1) * 64, 0);
+            } else if constexpr (PLAIN) {
+                __builtin_amdgcn_raw_buffer_store_b128(pend[i], rsz, pvo[i >> 1], (i & 1) * 64, 0);
             } else {
                 __builtin_amdgcn_raw_buffer_store_b128(pend[i], rsz, pvo[i >> 1], (i & 1) * 64, 0);
                 __builtin_amdgcn_raw_buffer_store_b128(pend[8 + i], rsa, pvo[i >> 1], (i & 1) * 64, 0);
@@ -3285,11 +3290,25 @@ extern "C" int ad_conv3x3_c3_ln_relu_fwd(const float* x, const float* w_hwio, co
     a.x = x; a.w = w_hwio; a.bias = bias; a.gamma = gamma; a.beta = beta; a.eps = eps;
     a.z = (char*)z; a.act = (char*)act; a.mean = mean; a.rstd = rstd; a.dz = nullptr; a.ws = nullptr;
     if (!z) {        // inference: the activation only (as ad_conv3x3_ln_relu_fwd with z == NULL)
-        if (dtype == AD_BF16) conv3x3_c3_fwd_kernel<bf16_t, true><<<grid, C3_T, 2 * C3_HB + 3 * BN * 4, (hipStream_t)stream>>>(a);
-        else conv3x3_c3_fwd_kernel<f16_t, true><<<grid, C3_T, 2 * C3_HB + 3 * BN * 4, (hipStream_t)stream>>>(a);
+        if (dtype == AD_BF16) conv3x3_c3_fwd_kernel<bf16_t, 1><<<grid, C3_T, 2 * C3_HB + 3 * BN * 4, (hipStream_t)stream>>>(a);
+        else conv3x3_c3_fwd_kernel<f16_t, 1><<<grid, C3_T, 2 * C3_HB + 3 * BN * 4, (hipStream_t)stream>>>(a);
     } else if (dtype == AD_BF16) conv3x3_c3_fwd_kernel<bf16_t><<<grid, C3_T, 2 * C3_HB + 3 * BN * 4, (hipStream_t)stream>>>(a);
     else conv3x3_c3_fwd_kernel<f16_t><<<grid, C3_T, 2 * C3_HB + 3 * BN * 4, (hipStream_t)stream>>>(a);
     AD_LAUNCH_CHECK("ad_conv3x3_c3_ln_relu_fwd");
+    return AD_OK;
+}
+
+extern "C" int ad_conv3x3_c3_fwd(const float* x, const float* w_hwio, const float* bias, void* z, int n, int h, int w, int dtype,
+                                 void* stream) {
+    AD_REQUIRE(ad_is_half(dtype), "ad_conv3x3_c3_fwd: 16-bit storage types only (dtype %d)", dtype);
+    AD_REQUIRE(x && w_hwio && z, "ad_conv3x3_c3_fwd: NULL operand");
+    C3Args a; int grid;
+    AD_REQUIRE(c3_plan(n, h, w, &a, &grid), "ad_conv3x3_c3_fwd: unsupported shape n=%d h=%d w=%d", n, h, w);
+    a.x = x; a.w = w_hwio; a.bias = bias; a.gamma = a.beta = nullptr; a.eps = 0.f;
+    a.z = (char*)z; a.act = nullptr; a.mean = a.rstd = nullptr; a.dz = nullptr; a.ws = nullptr;
+    if (dtype == AD_BF16) conv3x3_c3_fwd_kernel<bf16_t, 2><<<grid, C3_T, 2 * C3_HB + 3 * BN * 4, (hipStream_t)stream>>>(a);
+    else conv3x3_c3_fwd_kernel<f16_t, 2><<<grid, C3_T, 2 * C3_HB + 3 * BN * 4, (hipStream_t)stream>>>(a);
+    AD_LAUNCH_CHECK("ad_conv3x3_c3_fwd");
     return AD_OK;
 }
 

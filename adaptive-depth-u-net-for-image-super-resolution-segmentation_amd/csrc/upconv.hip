@@ -286,6 +286,10 @@ __global__ __launch_bounds__(PL_T, 1) void pw_gemm_lds_kernel(PwArgs a) {
     const auto rsb = pw_rsrc(a.bp, (long long)a.k * a.n * 2);
     const auto rsy = pw_rsrc(a.y, (long long)a.m * a.n * 2);
     // staging slots.  Pixel rows: slot s = tid + 512 i -> row s >> 3, 16-byte part s & 7 (8 lanes = one 128-byte row piece).
+    // (r05, measured: the 8 lanes the LDS serves per clock write one row's two chunk pieces PL_XB apart, i.e. into the same banks --
+    // SQ_LDS_BANK_CONFLICT = 1.0 cycle per LDS instruction of the launch, all of it these stores.  A slot map without the
+    // conflict, two rows of one chunk per 8 lanes, changed nothing (half-line global loads cost what the stores gained): the
+    // kernel is not waiting for its LDS stores.)
     // Bank: slot s = tid + 512 i -> k-slot s / NT, column s % NT (a k-slot's NT columns are contiguous in the pack).
     int xrow[4], xlds[4];
 #pragma unroll
@@ -404,6 +408,147 @@ __global__ __launch_bounds__(PL_T, 1) void pw_gemm_lds_kernel(PwArgs a) {
 #undef PSTAMP
 #undef PL_ISSUE
 #undef PL_STAGE
+}
+
+// ---- The same product with the two waves of every SIMD a phase apart (r05): 256 pixels x 256 channels per workgroup, 8 waves
+// as 2 (pixels) x 4 (channels), a wave 128 pixels x 64 channels (128 accumulator registers).  K advances in 32-deep chunks; a
+// wave alternates
+//     R(q): [chunk q opens a 64-deep stage: write the NEXT stage's staged registers to the other LDS buffer, issue the loads of
+//            the stage after it]  read the 8 pixel + 4 bank fragments of chunk q into registers, wait for them;
+//     M(q): 32 MFMAs on those registers;
+// with one workgroup barrier after each.  Waves 4-7 (the second pixel half) pass ONE extra barrier before their first phase, so
+// on every SIMD one wave is in M while the other is in R: the matrix pipe always has an issuing wave, and the LDS traffic, the
+// global loads and the tile epilogue of one half sit under the MFMAs of the other (in pw_gemm_lds_kernel all eight waves stage,
+// wait, read and multiply in step: tools/stamps_pw.py had 63 % of a wave's time waiting).  Why this is race free: with global
+// phases P = 1, 2, ..., waves 0-3 run R(q) in P = 2q + 1, waves 4-7 in P = 2q + 2.  Stage S + 1 goes to the buffer stage S - 1
+// lived in, whose last reads (chunk 2S - 1) are issued in P = 4S - 1 / 4S and complete before the barrier that ends that phase
+// (lgkmcnt(0) in front of it); the writes come in P = 4S + 1 / 4S + 2, complete before THEIR barrier, and the first read of
+// stage S + 1 is in P = 4S + 5.  Loads stay in flight for four phases (one stage of MFMAs on both waves, ~1.2 us).
+// The bank is read in the packed layout [K / 8][N][8] as before; the tile order is PlOrder.  N % 256 == 0, K % 64 == 0.
+constexpr int PP_NT = 256;
+constexpr int PP_WB = 4 * PP_NT * 16;              // one 32-k chunk of the bank tile (16 384 B)
+constexpr int PP_STAGE = 2 * PL_XB + 2 * PP_WB;    // 81 920 B; two stages = the CU's 160 KiB
+
+template <typename E>
+__global__ __launch_bounds__(PL_T, 1) void pw_gemm_pp_kernel(PwArgs a) {
+    typedef PwPol<E> P;
+    typedef typename P::frag frag;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;        // pixel half (= phase group: waves w and w + 4 share a SIMD), channel quarter
+    const int grp = lane >> 4, l15 = lane & 15;
+    const int tiles_n = a.n / PP_NT, tiles_m = (a.m + 255) / 256;
+    const int ks_per_tile = a.k / 64;
+    const auto rsx = pw_rsrc(a.x, (long long)a.m * a.k * 2);
+    const auto rsb = pw_rsrc(a.bp, (long long)a.k * a.n * 2);
+    const auto rsy = pw_rsrc(a.y, (long long)a.m * a.n * 2);
+    // staging slots of a stage: pixel rows 256 x 8 sixteen-byte parts, bank 8 k-slots x 256 columns: 4 + 4 per thread
+    int xrow[4], xlds[4], wsrc[4], wlds[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int sl = tid + PL_T * i;
+        xrow[i] = sl >> 3;
+        xlds[i] = ((sl & 7) >> 2) * PL_XB + (sl >> 3) * 96 + (sl & 3) * 16;
+        const int j = sl >> 8, n = sl & 255;
+        wsrc[i] = (j * a.n + n) * 16;
+        wlds[i] = 2 * PL_XB + (j >> 2) * PP_WB + ((j & 3) * PP_NT + n) * 16;
+    }
+    const int xpart = (tid & 7) * 16;
+    PlOrder ord;
+    ord.init(tiles_m, tiles_n, (int)gridDim.x, (int)blockIdx.x, a.whole_groups != 0);
+    const int S_total = ord.S_total;
+    // cursor of the next stage to LOAD (round of the tile order, k-stage); past the end it stays on the last stage (re-read)
+    int qs = ord.next_round(0), iks = 0, qtm = 0, qtn = 0;
+    if (qs < S_total) ord.tile_at(qs, qtm, qtn);
+    u32x4 xr[4], wr[4];
+    // (measured and withdrawn, r05: one-dword loads that warm the L2 two or three stages ahead -- 979 -> 818 TFLOP/s on the
+    // 1 024 -> 4 608 dx product: the launch is not waiting for misses to HBM either)
+    auto issue = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int mrow = qtm * 256 + xrow[i];
+            xr[i] = __builtin_amdgcn_raw_buffer_load_b128(rsx, mrow < a.m ? (unsigned)(mrow * a.k * 2 + xpart) : PW_OOB,
+                                                          (unsigned)(iks * 128), 0);
+        }
+        const unsigned wb = (unsigned)((iks * 8 * a.n + qtn * PP_NT) * 16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wr[i] = __builtin_amdgcn_raw_buffer_load_b128(rsb, (unsigned)wsrc[i], wb, 0);
+        if (++iks == ks_per_tile) {
+            const int nq = ord.next_round(qs + 1);
+            if (nq < S_total) { qs = nq; iks = 0; ord.tile_at(qs, qtm, qtn); }
+            else iks = ks_per_tile - 1;            // no further tile: keep re-reading the last stage (never used)
+        }
+    };
+    auto stage_to_lds = [&](char* sb) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(sb + xlds[i]) = xr[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(sb + wlds[i]) = wr[i];
+    };
+    const int xfo = (wm * 128 + l15) * 96 + grp * 16;                              // + mt * 16 * 96 (+ chunk * PL_XB)
+    const int wfo = 2 * PL_XB + (grp * PP_NT + wn * 64 + l15) * 16;                // + nt * 256 (+ chunk * PP_WB)
+    if (S_total == 0) return;                       // (uniform per workgroup: no barrier is left waiting)
+    // prologue: stage 0 into buffer 0, stage 1 into the registers
+    issue();
+    stage_to_lds(smem);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    issue();
+    if (wm == 1) __builtin_amdgcn_s_barrier();      // the second half runs one phase behind
+    int buf = 0;
+    for (int sc = ord.next_round(0); sc < S_total; sc = ord.next_round(sc + 1)) {
+        f32x4 acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < ks_per_tile; ++ks) {
+            char* sb = smem + buf * PP_STAGE;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                // ---- R
+                if (c == 0) {
+                    stage_to_lds(smem + (buf ^ 1) * PP_STAGE);
+                    issue();
+                }
+                frag xf[8], wf[4];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) wf[nt] = *reinterpret_cast<const frag*>(sb + c * PP_WB + wfo + nt * 256);
+#pragma unroll
+                for (int mt = 0; mt < 8; ++mt) xf[mt] = *reinterpret_cast<const frag*>(sb + c * PL_XB + xfo + mt * 16 * 96);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                // ---- M
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = P::mma(wf[nt], xf[mt], acc[mt][nt]);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+            }
+            buf ^= 1;
+        }
+        // tile epilogue: issued at the head of this wave's next R phase, under the other half's MFMAs
+        int tm, tn;
+        ord.tile_at(sc, tm, tn);
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            const int mrow = tm * 256 + wm * 128 + mt * 16 + l15;
+            const unsigned yo = mrow < a.m ? (unsigned)((mrow * a.n + tn * PP_NT + wn * 64 + (grp & 1) * 16 + (grp >> 1) * 8) * 2) : PW_OOB;
+#pragma unroll
+            for (int np = 0; np < 2; ++np) {
+                const u32x2 pa = P::pack4(acc[mt][2 * np]), pb = P::pack4(acc[mt][2 * np + 1]);
+                const u32x2 s0 = __builtin_amdgcn_permlane16_swap(pa[0], pb[0], false, false);
+                const u32x2 s1 = __builtin_amdgcn_permlane16_swap(pa[1], pb[1], false, false);
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, rsy, yo + np * 64, 0, 0);
+            }
+        }
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();      // the first half passes the barrier the second half took at the start
 }
 
 // Bank operands from the fp32 Keras kernel W[3][3][Cin][Cout] (HWIO):
@@ -950,6 +1095,10 @@ static bool pw_new_order() {
     static const bool on = !(getenv("AD_PW_NW8") && getenv("AD_PW_NW8")[0] == '0');
     return on;
 }
+static bool pw_pingpong() {     // A/B switch: AD_PW_PP=0 keeps the in-step kernel on the 256-channel tiles
+    static const bool on = !(getenv("AD_PW_PP") && getenv("AD_PW_PP")[0] == '0');
+    return on;
+}
 static int pw_gemm_nw(int64_t m, int k, int n) {
     const bool nw8 = pw_new_order();
     const int base = n % 192 == 0 ? 6 : 4;
@@ -1015,7 +1164,15 @@ extern "C" int ad_pw_gemm(const void* x, const void* bank, void* y, int64_t m, i
         }                                                                                                            \
         pw_gemm_lds_kernel<E_, NW_, D_><<<grid, PL_T, 2 * PlGeo<NW_>::STAGE, s>>>(a);                                \
     }
-        if (nw == 8) {           // (two stages of loads in registers beside 128 accumulators spill: one stage ahead)
+        if (nw == 8 && pw_pingpong()) {
+            static std::atomic<unsigned long long> pp_attr{0};
+            if (ad_first_on_device(pp_attr)) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pw_gemm_pp_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PP_STAGE);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pw_gemm_pp_kernel<f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PP_STAGE);
+            }
+            if (dtype == AD_BF16) pw_gemm_pp_kernel<bf16_t><<<grid, PL_T, 2 * PP_STAGE, s>>>(a);
+            else pw_gemm_pp_kernel<f16_t><<<grid, PL_T, 2 * PP_STAGE, s>>>(a);
+        } else if (nw == 8) {    // (two stages of loads in registers beside 128 accumulators spill: one stage ahead)
             if (dtype == AD_BF16) PL_LAUNCH(bf16_t, 8, 1) else PL_LAUNCH(f16_t, 8, 1)
         } else if (nw == 6) {
             if (dtype == AD_BF16) { if (depth == 2) PL_LAUNCH(bf16_t, 6, 2) else PL_LAUNCH(bf16_t, 6, 1) }

@@ -351,6 +351,15 @@ def conv3x3_c3_ln_relu_fwd(x: torch.Tensor, w_hwio: torch.Tensor, bias: Optional
     return z, act, mean, rstd
 
 
+def conv3x3_c3_fwd(x: torch.Tensor, w_hwio: torch.Tensor, bias: Optional[torch.Tensor], dtype: torch.dtype = torch.bfloat16):
+    """z = conv3x3(x) + bias on the raw [N,H,W,3] fp32 input (64 output channels), no normalisation."""
+    n, h, w, _ = x.shape
+    z = torch.empty((n, h, w, 64), dtype=dtype, device=x.device)
+    with _timed("conv3x3_fwd", 2.0 * n * h * w * 27 * 64, float(n * h * w * (12 + 64 * z.element_size()))):
+        check(_lib.load().ad_conv3x3_c3_fwd(_p(x), _p(w_hwio), _p(bias), _p(z), n, h, w, dt(dtype), _stream()), "ad_conv3x3_c3_fwd")
+    return z
+
+
 def conv3x3_c3_wgrad(x: torch.Tensor, dz: torch.Tensor, dw_out: torch.Tensor, ws: Workspace):
     """dw_out: fp32 [3,3,3,64] view of the flat gradient buffer; x the raw [N,H,W,3] fp32 input."""
     n, h, w, _ = x.shape

@@ -13,6 +13,7 @@ batch statistics under data parallelism exactly as Keras does (no sync-BN in the
 from __future__ import annotations
 
 import math
+import os
 from collections import OrderedDict
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Tuple
@@ -261,8 +262,13 @@ class SegModel(Model):
         pooled = None
         for li, (cs, nn) in enumerate(blk):
             g, b = self.param(nn + "/gamma"), self.param(nn + "/beta")
+            # the network's first Conv2D on the raw fp32 image (3 -> 64): the dedicated 3-channel kernels, no zero-padded copy
+            raw = x1.dtype == torch.float32 and x1.shape[-1] == 3 and self.dtype != torch.float32
             if self.norm == "bn":
-                z = ops.conv3x3_fwd(x1, x2, self._packs[cs.name][0], self.param(cs.name + "/bias"), cs.cout)
+                if raw:
+                    z = ops.conv3x3_c3_fwd(x1, self.param(cs.name + "/kernel"), self.param(cs.name + "/bias"), dtype=self.dtype)
+                else:
+                    z = ops.conv3x3_fwd(x1, x2, self._packs[cs.name][0], self.param(cs.name + "/bias"), cs.cout)
                 if training and pool and li == len(blk) - 1 and ops.batchnorm_pool_supported(z):
                     a, pooled, mean, rstd = ops.batchnorm_relu_pool_fwd_train(z, g, b, self._state(nn + "/moving_mean"),
                                                                               self._state(nn + "/moving_variance"), self._ws)
@@ -272,6 +278,9 @@ class SegModel(Model):
                 else:
                     a = ops.batchnorm_relu_fwd_infer(z, g, b, self._state(nn + "/moving_mean"), self._state(nn + "/moving_variance"))
                     mean = rstd = None
+            elif raw:
+                z, a, mean, rstd = ops.conv3x3_c3_ln_relu_fwd(x1, self.param(cs.name + "/kernel"), self.param(cs.name + "/bias"), g, b,
+                                                              dtype=self.dtype, want_z=keep or self.audit is not None)
             else:
                 z, a, mean, rstd = ops.conv3x3_ln_relu_fwd(x1, x2, self._packs[cs.name][0], self.param(cs.name + "/bias"),
                                                            g, b, cs.cout, want_z=keep or self.audit is not None)
@@ -286,7 +295,9 @@ class SegModel(Model):
 
     def _forward_seg(self, img: torch.Tensor, mask: Optional[torch.Tensor], training: bool, keep: bool):
         tape, skips = [], []
-        x = ops.pad_channels(img, ops.cin_granule(self.dtype), self.dtype)
+        first = self.blocks[0][0][0]
+        c3 = ops.conv3x3_c3_supported(img, first.cout, self.dtype) and os.environ.get("ADUNET_SEG_NO_C3") != "1"
+        x = img if c3 else ops.pad_channels(img, ops.cin_granule(self.dtype), self.dtype)
         for lvl in range(self.depth):
             x, pooled = self._block_fwd(self.blocks[lvl], x, None, training, tape, keep, pool=True)
             skips.append(x)
@@ -363,7 +374,10 @@ class SegModel(Model):
                 else:
                     dz = ops.layernorm_relu_bwd(d, z, mean, rstd, g, b, self.grad(nn + "/gamma"), self.grad(nn + "/beta"),
                                                 self.grad(cs.name + "/bias"), ws)
-                ops.conv3x3_wgrad(x1, x2, dz, self.grad(cs.name + "/kernel"), cs.cin, ws)
+                if x1.dtype == torch.float32 and x1.shape[-1] == 3 and self.dtype != torch.float32:     # the first layer on the raw image
+                    ops.conv3x3_c3_wgrad(x1, dz, self.grad(cs.name + "/kernel"), ws)
+                else:
+                    ops.conv3x3_wgrad(x1, x2, dz, self.grad(cs.name + "/kernel"), cs.cin, ws)
                 self._done(cs.name + "/kernel")
                 dsk = None
                 if not cs.need_dgrad:

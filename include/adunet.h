@@ -162,6 +162,10 @@ int ad_conv3x3_c3_ln_relu_fwd(const float* x, const float* w_hwio, const float* 
                               const float* gamma, const float* beta, float eps,
                               void* z, void* act, float* mean, float* rstd,
                               int n, int h, int w, int dtype, void* stream);
+/* The same first layer without the normalisation: z = conv(x) + bias (the first Conv2D of the BatchNorm segmentation model,
+ * Segmenation/code/train_adaptive_unet.py:326-327, whose BatchNormalization needs the statistics of the whole batch first). */
+int ad_conv3x3_c3_fwd(const float* x, const float* w_hwio, const float* bias, void* z,
+                      int n, int h, int w, int dtype, void* stream);
 size_t ad_conv3x3_c3_wgrad_ws_bytes(int n, int h, int w);
 int ad_conv3x3_c3_wgrad(const float* x, const void* dz, float* dw_hwio,
                         int n, int h, int w, void* ws, size_t ws_bytes, int dtype, void* stream);

@@ -411,6 +411,8 @@ def audit_seg_step(S, model, img, mask, bce_w=0.4, dice_w=0.6):
     def conv_input(name, x1, x2):
         cin = model.convs[name].cin
         a = f64(x1)
+        if x1.dtype == torch.float32 and bf16:
+            a = q(a)                                           # the first-layer kernels stage the raw image in 16 bits
         a = a[..., :cin] if x2 is None else np.concatenate([a, f64(x2)], axis=-1)
         assert a.shape[-1] == cin
         return a
@@ -429,7 +431,8 @@ def audit_seg_step(S, model, img, mask, bce_w=0.4, dice_w=0.6):
                 check_f32(rstd.cpu().numpy(), rs, name + " batch rstd", 1e-4)
             else:
                 c1, c2 = x1.shape[-1], (x2.shape[-1] if x2 is not None else 0)
-                fused = bool(bf16) and bool(lib.ad_conv3x3_ln_relu_is_fused(n, z.shape[1], z.shape[2], c1, c2, z.shape[3], ops.dt(model.dtype)))
+                fused = bool(bf16) and (x1.dtype == torch.float32 or       # (raw image: the 3-channel kernel, conv + LayerNorm in one)
+                                        bool(lib.ad_conv3x3_ln_relu_is_fused(n, z.shape[1], z.shape[2], c1, c2, z.shape[3], ops.dt(model.dtype))))
                 y, _ = ref.layernorm_fwd(want_z if fused else f64(z), W[nn + "/gamma"], W[nn + "/beta"])
             check_stored(a, ref.relu_fwd(y), name + " act", bf16)
         elif kind == "fwd_pool":

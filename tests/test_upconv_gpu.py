@@ -32,12 +32,21 @@ def relerr(got, want):
 # block's accumulator set-up follows the first block's 16-byte stores directly (the store-data hazard noted in pw_gemm_kernel)
 # From 2 048 pixels on the 16-bit types take the LDS-tiled persistent kernel (tile 256 x 192 for the bank's 9 Cout columns,
 # 256 x 128 for dx's Cin columns; ragged last pixel tile, several tiles per workgroup, 2 .. 18 k-stages).
+# r05: widths that are multiples of 256 with K >= 256 take 256 x 256 tiles on the kernel whose two waves per SIMD run a phase apart
+# (pw_gemm_pp_kernel): (130999, 256, 64) gives dx 512 tiles of NINE k-stages on 256 workgroups (two tiles each: the LDS buffer
+# parity carries over a tile boundary with an odd stage count; ragged last pixel tile; bf16 only, for the suite's time);
+# (20999, 512, 256) gives both products.
 @pytest.mark.parametrize("shape", [(1, 64, 64), (300, 128, 64), (513, 192, 128), (2000, 64, 64), (31752, 128, 128), (5000, 256, 64),
-                                   (70001, 128, 64)])
+                                   (70001, 128, 64), (130999, 256, 64), (20999, 512, 256)])
 def test_pointwise_gemm(device, dtype, shape):
     """ad_pw_gemm: ragged pixel counts (not a multiple of the 64-pixel wave tile), several k chunks / output blocks."""
-    from adunet_amd import ops
+    from adunet_amd import _lib, ops
     m, k, cout = shape
+    if m > 100000 and dtype != BF16:
+        pytest.skip("the two-tiles-per-workgroup case runs in bf16 only")
+    if shape in ((130999, 256, 64), (20999, 512, 256)) and dtype != F32:
+        assert _lib.load().ad_pw_gemm_tile_channels(m, 9 * cout, k, ops.dt(dtype)) == 256
+        assert shape[2] == 64 or _lib.load().ad_pw_gemm_tile_channels(m, k, 9 * cout, ops.dt(dtype)) == 256
     rng = np.random.default_rng(m + k + cout)
     x = rnd(rng.standard_normal((m, k)), dtype)
     w = rnd(rng.standard_normal((3, 3, k, cout)) * 0.1, dtype)
