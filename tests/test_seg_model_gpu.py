@@ -30,6 +30,8 @@ def storage_of(model, n):
             decoder_first = bi > model.depth and i == 0          # virtual concat [up | skip]
             c1, c2 = (cs.cin // 2, cs.cin // 2) if decoder_first else (model._cin_pad(cs), 0)
             fused[cs.name] = bool(lib.ad_conv3x3_ln_relu_is_fused(n, cs.hw, cs.hw, c1, c2, cs.cout, ops.dt(model.dtype)))
+            if bi == 0 and i == 0 and lib.ad_conv3x3_c3_supported(n, cs.hw, cs.hw, cs.cout, ops.dt(model.dtype)):
+                fused[cs.name] = True        # the raw image goes through the 3-channel kernel: conv + LayerNorm in one launch
     return Storage(ref.bf16_round, lambda conv, *shape: fused[conv])
 
 
