@@ -30,6 +30,12 @@
 // (v_mfma_f32_16x16x4_f32, exact fp32 parity path).  fp32 accumulation in both.
 #include "common.h"
 
+// cache policy of the big output streams of the wave-specialised kernels (buffer_store aux bits: 1 sc0, 2 nt, 16 sc1).  0: plain
+// stores.  -DAD_STORE_AUX=2 / 16 / 17: the A/B builds of tools/build_variant.sh (r05, measured: see DESIGN 6)
+#ifndef AD_STORE_AUX
+#define AD_STORE_AUX 0
+#endif
+
 namespace {
 
 // LDS bytes per halo pixel: 64-byte chunk + 32-byte pad.  ds_read_b128 serves a wave in 4 NON-contiguous
@@ -924,13 +930,13 @@ __device__ __forceinline__ void ws_mma_role(const ConvArgs& a, const char* xb0, 
             const hv8_ h_ = __builtin_bit_cast(hv8_, v_);                                                     \
             _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) dbs[((IDX) & 1) * 8 + j_] += (float)h_[j_];      \
         }                                                                                                     \
-        __builtin_amdgcn_raw_buffer_store_b128(v_, rsy, pvo[(IDX) >> 1], ((IDX) & 1) * 32 * TSZ, 0);          \
+        __builtin_amdgcn_raw_buffer_store_b128(v_, rsy, pvo[(IDX) >> 1], ((IDX) & 1) * 32 * TSZ, AD_STORE_AUX);          \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
     } while (0)
 #define WS_PEND_STORE(IDX, RS)                                                                                \
     do {                                                                                                      \
         __builtin_amdgcn_sched_barrier(0);   /* pin the store between two tap steps (hipcc would bunch them) */ \
-        __builtin_amdgcn_raw_buffer_store_b128(pend[IDX], RS, pvo[((IDX) & 7) >> 1], ((IDX) & 1) * 32 * TSZ, 0); \
+        __builtin_amdgcn_raw_buffer_store_b128(pend[IDX], RS, pvo[((IDX) & 7) >> 1], ((IDX) & 1) * 32 * TSZ, AD_STORE_AUX); \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
     } while (0)
     auto hook0 = [&](int st) {
@@ -1251,7 +1257,7 @@ __device__ __forceinline__ void ws_mma_role_lnb(const ConvArgs& a, const char* x
                 }
                 const u32x2 w0 = __builtin_amdgcn_permlane16_swap(pa.u[0], pb.u[0], false, false);
                 const u32x2 w1 = __builtin_amdgcn_permlane16_swap(pa.u[1], pb.u[1], false, false);
-                __builtin_amdgcn_raw_buffer_store_b128(u32x4{w0[0], w1[0], w0[1], w1[1]}, rsy, pvo_mt, np * 32 * TSZ, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{w0[0], w1[0], w0[1], w1[1]}, rsy, pvo_mt, np * 32 * TSZ, AD_STORE_AUX);
             }
             LSTAMP(3 + mt);                             // epilogue of m-tile mt (mt == 1 includes issuing the second fetch)
         }
