@@ -143,7 +143,7 @@ def load():
         fn.argtypes = args
     # A/B switches: the HOST reads the environment and sets the library's explicit options (ad_set_option)
     for env, opt in (("ADUNET_NO_MAP1", b"no_map1"), ("ADUNET_NO_MAP4", b"no_map4"), ("ADUNET_NO_DGRAD_LN", b"no_dgrad_ln"),
-                     ("ADUNET_NO_MOSAIC", b"no_mosaic")):
+                     ("ADUNET_NO_MOSAIC", b"no_mosaic"), ("ADUNET_NO_PW_WIDE", b"no_pw_wide")):
         if os.environ.get(env):
             lib.ad_set_option(opt, 1)
     _lib = lib

@@ -39,14 +39,14 @@ int ad_num_cu() {
     return ncu;
 }
 
-static int g_options[AD_OPT_COUNT] = {0, 0, 0, 0};
-static const char* const g_option_names[AD_OPT_COUNT] = {"no_map1", "no_map4", "no_dgrad_ln", "no_mosaic"};
+static int g_options[AD_OPT_COUNT] = {0, 0, 0, 0, 0};
+static const char* const g_option_names[AD_OPT_COUNT] = {"no_map1", "no_map4", "no_dgrad_ln", "no_mosaic", "no_pw_wide"};
 int ad_option(int which) { return which >= 0 && which < AD_OPT_COUNT ? g_options[which] : 0; }
 
 extern "C" int ad_set_option(const char* name, int value) {
     for (int i = 0; i < AD_OPT_COUNT; ++i)
         if (name && strcmp(name, g_option_names[i]) == 0) { g_options[i] = value; return AD_OK; }
-    return ad_set_error(AD_ERR_ARG, "ad_set_option: unknown option '%s' (no_map1, no_map4, no_dgrad_ln, no_mosaic)", name ? name : "(null)");
+    return ad_set_error(AD_ERR_ARG, "ad_set_option: unknown option '%s' (no_map1, no_map4, no_dgrad_ln, no_mosaic, no_pw_wide)", name ? name : "(null)");
 }
 
 extern "C" int ad_get_option(const char* name) {

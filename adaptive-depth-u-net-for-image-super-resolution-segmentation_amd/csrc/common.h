@@ -31,7 +31,7 @@ static inline bool ad_first_on_device(std::atomic<unsigned long long>& done) {
     return true;
 }
 // Explicit library options (ad_set_option, include/adunet.h): the library itself never reads the environment.
-enum { AD_OPT_NO_MAP1 = 0, AD_OPT_NO_MAP4 = 1, AD_OPT_NO_DGRAD_LN = 2, AD_OPT_NO_MOSAIC = 3, AD_OPT_COUNT = 4 };
+enum { AD_OPT_NO_MAP1 = 0, AD_OPT_NO_MAP4 = 1, AD_OPT_NO_DGRAD_LN = 2, AD_OPT_NO_MOSAIC = 3, AD_OPT_NO_PW_WIDE = 4, AD_OPT_COUNT = 5 };
 int ad_option(int which);
 
 static inline bool ad_is_half(int dtype) { return dtype == AD_BF16 || dtype == AD_F16; }   // 16-bit storage types

@@ -226,7 +226,7 @@ struct PlOrder {
         n_ng = (tiles_n + GN - 1) / GN;
         mg_total = (tiles_m + GM - 1) / GM;
         if (xo) {
-            // whole_groups (A/B switch, AD_PW_NW8=0): the order until the first half of r05, every row group one XCD's
+            // whole_groups (A/B switch, option "no_pw_wide"): the order until the first half of r05, every row group one XCD's
             const int tail_blocks = whole_groups ? 0 : (mg_total & 7) * n_ng;   // blocks of the row groups beyond the whole sets of eight
             S_full = (whole_groups ? (mg_total > xcd ? (mg_total - xcd + 7) / 8 : 0) : mg_total >> 3) * n_ng;
             S_total = S_full + (tail_blocks > xcd ? (tail_blocks - xcd + 7) / 8 : 0);
@@ -1090,15 +1090,8 @@ static int pw_rounds(int64_t m, int n, int nt, int* grid_out) {
 // channels per tile / 32.  256-channel tiles (a wave: 64 pixels x 128 channels, fewer LDS bytes per MFMA than the 192- and
 // 128-channel tiles: +5 ... +19 % per tile-column on the dx products of the Experiment-2 levels) where the width allows, K is
 // long enough for the arithmetic to dominate and the launch does not lose more to whole rounds than the tile gains
-// (rounds x tile width / measured relative rate).  AD_PW_NW8=0 in the environment: off.
-static bool pw_new_order() {
-    static const bool on = !(getenv("AD_PW_NW8") && getenv("AD_PW_NW8")[0] == '0');
-    return on;
-}
-static bool pw_pingpong() {     // A/B switch: AD_PW_PP=0 keeps the in-step kernel on the 256-channel tiles
-    static const bool on = !(getenv("AD_PW_PP") && getenv("AD_PW_PP")[0] == '0');
-    return on;
-}
+// (rounds x tile width / measured relative rate).  Option "no_pw_wide": off.
+static bool pw_new_order() { return !ad_option(AD_OPT_NO_PW_WIDE); }     // A/B switch (ad_set_option "no_pw_wide")
 static int pw_gemm_nw(int64_t m, int k, int n) {
     const bool nw8 = pw_new_order();
     const int base = n % 192 == 0 ? 6 : 4;
@@ -1164,7 +1157,7 @@ extern "C" int ad_pw_gemm(const void* x, const void* bank, void* y, int64_t m, i
         }                                                                                                            \
         pw_gemm_lds_kernel<E_, NW_, D_><<<grid, PL_T, 2 * PlGeo<NW_>::STAGE, s>>>(a);                                \
     }
-        if (nw == 8 && pw_pingpong()) {
+        if (nw == 8) {
             static std::atomic<unsigned long long> pp_attr{0};
             if (ad_first_on_device(pp_attr)) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pw_gemm_pp_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PP_STAGE);
@@ -1172,8 +1165,6 @@ extern "C" int ad_pw_gemm(const void* x, const void* bank, void* y, int64_t m, i
             }
             if (dtype == AD_BF16) pw_gemm_pp_kernel<bf16_t><<<grid, PL_T, 2 * PP_STAGE, s>>>(a);
             else pw_gemm_pp_kernel<f16_t><<<grid, PL_T, 2 * PP_STAGE, s>>>(a);
-        } else if (nw == 8) {    // (two stages of loads in registers beside 128 accumulators spill: one stage ahead)
-            if (dtype == AD_BF16) PL_LAUNCH(bf16_t, 8, 1) else PL_LAUNCH(f16_t, 8, 1)
         } else if (nw == 6) {
             if (dtype == AD_BF16) { if (depth == 2) PL_LAUNCH(bf16_t, 6, 2) else PL_LAUNCH(bf16_t, 6, 1) }
             else { if (depth == 2) PL_LAUNCH(f16_t, 6, 2) else PL_LAUNCH(f16_t, 6, 1) }

@@ -59,6 +59,8 @@ int ad_device_cus(void);
  *   "no_dgrad_ln"  ad_conv3x3_dgrad_ln_bwd_is_fused() answers 0 (dgrad and LayerNorm backward as two launches)
  *   "no_mosaic"    the wave-specialised conv kernels tile every image by itself even where the image mosaic
  *                  (one virtual map of all images, a single zero line between neighbours) needs fewer 16 x 16 tiles
+ *   "no_pw_wide"   ad_pw_gemm as until the first half of r05: 192- / 128-channel tiles only (no 256-channel tiles on
+ *                  pw_gemm_pp_kernel) and every row group of the XCD-aware tile order one XCD's
  * ad_get_option returns the value, -1 for an unknown name. */
 int ad_set_option(const char* name, int value);
 int ad_get_option(const char* name);

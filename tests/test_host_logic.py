@@ -271,3 +271,8 @@ def test_bank_gemm_tile_order_visits_every_tile_once_and_balances_the_xcds():
     assert lib.ad_pw_gemm_tile_channels(64 * 64 * 64, 128, 576, _lib.AD_BF16) == 192
     assert lib.ad_pw_gemm_tile_channels(64 * 64 * 64, 576, 128, _lib.AD_BF16) == 128
     assert lib.ad_pw_gemm_tile_channels(64 * 64 * 64, 128, 576, _lib.AD_F32) == 0
+    lib.ad_set_option(b"no_pw_wide", 1)          # the A/B switch: no 256-channel tiles, whole row groups per XCD
+    try:
+        assert lib.ad_pw_gemm_tile_channels(8 * 63 * 63, 4608, 1024, _lib.AD_BF16) == 128
+    finally:
+        lib.ad_set_option(b"no_pw_wide", 0)
