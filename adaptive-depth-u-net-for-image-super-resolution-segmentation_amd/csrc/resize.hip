@@ -151,8 +151,12 @@ __global__ __launch_bounds__(256) void resample_march_kernel(const T* __restrict
 // d(act), read z, write dz".  The c / EPT lanes that hold a pixel's channels are adjacent (i = ox * vecs + v), so the
 // LayerNorm reductions are xor-shuffles over that lane group (vecs a power of two <= 64).  A block walks several row
 // groups (grid.y is capped) so that the per-block partial sums {dgamma, dbeta, dbias}[c] stay few.
+// (r05: the <4, 2> instantiation -- the x4 skip junction of every level -- took 170 registers, two over the step to three waves
+// per SIMD; asked for three the bf16 instantiation fits 168 without a spill (fp16 would spill four: it keeps two waves):
+// 10.94 -> 10.89 ms per K2' step.  Bounds that make hipcc spill lose:
+// resample_march_kernel<4, 8> at four waves +0.08 ms, head_ln_bwd_kernel at four +0.65 ms.)
 template <typename T, int R, int KX>
-__global__ __launch_bounds__(256) void resample_ln_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dskip,
+__global__ __launch_bounds__(256, (R == 4 && KX == 2 && __is_same(T, bf16_t)) ? 3 : 1) void resample_ln_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dskip,
                                                               const T* __restrict__ z, const float* __restrict__ mean,
                                                               const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, T* __restrict__ dz,

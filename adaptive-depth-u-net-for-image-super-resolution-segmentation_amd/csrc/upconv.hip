@@ -797,8 +797,14 @@ template <typename E> struct VecH16 {
 template <> struct VecH<bf16_t> : VecH16<bf16_t> {};
 template <> struct VecH<f16_t> : VecH16<f16_t> {};
 
+// Four waves per SIMD for the two-slot instantiation (64 channels: the full-resolution level of every pyramid).  hipcc takes 156
+// registers for it when left alone (three waves); held to 128 it does not spill and the launch goes from 2.9 to 3.7 TB/s
+// (K2' level 0: 0.289 -> 0.224 ms) -- the kernel hides its ~60 vector instructions per stored row behind other waves' memory
+// time, so a fourth wave is a third more to hide behind.  The four- and eight-slot instantiations spill under the same bound
+// (0.20 -> 0.43 ms at eight slots; three registers at four slots, which the no-spill guard of tests/test_isa_guards.py
+// rules out for 12 us), as does the four-row window; they keep the default.
 template <typename T, int GW, int NSL>
-__global__ __launch_bounds__(256) void upconv_gather_fwd_kernel(GatherArgs a) {
+__global__ __launch_bounds__(256, GW == 3 && NSL <= 2 ? 4 : 1) void upconv_gather_fwd_kernel(GatherArgs a) {
     constexpr int EPT = VecH<T>::N;
     constexpr int TSZ = (int)sizeof(T);
     extern __shared__ __attribute__((aligned(16))) char gsm[];
