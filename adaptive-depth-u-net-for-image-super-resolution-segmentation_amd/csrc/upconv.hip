@@ -769,6 +769,7 @@ __device__ __forceinline__ void xcd_block(int& bx, int& by, int& bz) {
 
 constexpr int GF_MAXROWS = 64;
 constexpr int GB_MAXKY = 30;   // most transposed vertical taps the backward gather stages
+constexpr int GB_BATCH = 5;    // window columns loaded at once by upconv_gather_bwd_kernel
 
 // 8-byte vector of T, unpacked to / packed from fp32 (the gathers keep per-thread state small: occupancy hides their latency)
 template <typename T> struct VecH;
@@ -969,30 +970,27 @@ struct GatherBwdArgs {
     int h, w, oh, ow, c;
 };
 
+// r05 (second half): the kernel held 224 registers (two waves per SIMD): 30 per-lane tap weights (three shifted views of the SAME
+// kxt weights), 10 clamped column offsets and 10 validity flags beside the 72 accumulators.  Now the kxt weights are kept once
+// and indexed statically (window column j, shift d -> tap j + d - 2), columns outside the image are out-of-range buffer loads
+// (zeros) instead of clamped loads with a zero weight, the column offsets are one register plus a uniform stride, and the ten-column
+// window is loaded as two batches of five: 162 / 168 registers for the six- / ten-column instantiations, three waves per SIMD, no
+// spill (the explicit bound is given to the six-column one only: under it hipcc spills the ten-column one, which fits by itself).
+// Same products and the same order of additions as before.
 template <typename T, int KX2>
-__global__ __launch_bounds__(256) void upconv_gather_bwd_kernel(GatherBwdArgs a) {
+__global__ __launch_bounds__(256, KX2 <= 6 ? 3 : 1) void upconv_gather_bwd_kernel(GatherBwdArgs a) {
     constexpr int EPT = ElemTraits<T>::EPT;
+    constexpr int TSZ = (int)sizeof(T);
+    constexpr int KT = KX2 - 2;                        // most transposed horizontal taps of this instantiation
     const int vecs = a.c / EPT;
     const int qy = blockIdx.y, nn = blockIdx.z;
     const int i = blockIdx.x * 256 + threadIdx.x;
     const bool live = i < a.w * vecs;
     const int qx = live ? i / vecs : 0, v = live ? i - qx * vecs : 0;
     const int c0 = a.cxt[qx] - 1;                      // first column of the window
-    // weight of window column j for shift d: wxt[qx][j - 1 + (d - 1)] = wxt[qx][j + d - 2]
-    float wj[3][KX2];
-    int coff[KX2];
-    bool cok[KX2];
+    float wk[KT];
 #pragma unroll
-    for (int j = 0; j < KX2; ++j) {
-        const int cc = c0 + j;
-        cok[j] = cc >= 0 && cc < a.ow && j < a.kxt + 2;
-        coff[j] = min(max(cc, 0), a.ow - 1) * a.c + v * EPT;
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const int k = j + d - 2;
-            wj[d][j] = (cok[j] && k >= 0 && k < a.kxt) ? a.wxt[qx * a.kxt + k] : 0.f;
-        }
-    }
+    for (int k = 0; k < KT; ++k) wk[k] = k < a.kxt ? a.wxt[qx * a.kxt + k] : 0.f;
     float acc[3][3][EPT];
 #pragma unroll
     for (int s = 0; s < 3; ++s)
@@ -1000,7 +998,8 @@ __global__ __launch_bounds__(256) void upconv_gather_bwd_kernel(GatherBwdArgs a)
         for (int d = 0; d < 3; ++d)
 #pragma unroll
             for (int e = 0; e < EPT; ++e) acc[s][d][e] = 0.f;
-    const T* gn = reinterpret_cast<const T*>(a.g) + (size_t)nn * a.oh * a.ow * a.c;
+    const long long gbytes = (long long)a.oh * a.ow * a.c * TSZ;                    // one image (< 2 GiB: launcher)
+    const auto rsg = pw_rsrc(a.g + (size_t)nn * gbytes, gbytes);
     const int r0 = a.ryt[qy];
     // vertical weights of the window rows, per dy, staged in LDS (workgroup-uniform; read back as broadcasts instead of
     // global loads that would serialise with the gradient loads on vmcnt): row j <-> gradient row r0 - 1 + j, which is
@@ -1012,24 +1011,42 @@ __global__ __launch_bounds__(256) void upconv_gather_bwd_kernel(GatherBwdArgs a)
     }
     __syncthreads();
     if (!live) return;
+    const int cstride = a.c * TSZ;
+    const int voff0 = (c0 * a.c + v * EPT) * TSZ;      // byte offset of window column 0 inside a row (negative left of the image)
     for (int p = max(r0 - 1, 0); p <= min(r0 + a.kyt, a.oh - 1); ++p) {
-        const T* row = gn + (size_t)p * a.ow * a.c;
+        const unsigned rowb = (unsigned)(p * a.ow * a.c * TSZ);
         float hs[3][EPT];
 #pragma unroll
         for (int d = 0; d < 3; ++d)
 #pragma unroll
             for (int e = 0; e < EPT; ++e) hs[d][e] = 0.f;
-        Vec16<T> ld[KX2];
+        // the window's loads in batches of at most GB_BATCH columns (all of a batch in flight): ten at once cost the ten-column
+        // instantiation two registers more than the step to three waves per SIMD
+        constexpr int NB = KX2 > 6 ? (KX2 + GB_BATCH - 1) / GB_BATCH : 1, BW = (KX2 + NB - 1) / NB;     // (six columns: one batch)
 #pragma unroll
-        for (int j = 0; j < KX2; ++j) ld[j].load(row + coff[j]);
+        for (int jb = 0; jb < KX2; jb += BW) {
+            Vec16<T> ld[BW];
 #pragma unroll
-        for (int j = 0; j < KX2; ++j) {
-            float t[EPT];
-            ld[j].to_f32(t);
+            for (int jj = 0; jj < BW; ++jj) {
+                const int j = jb + jj;
+                const bool ok = j < KX2 && (unsigned)(c0 + j) < (unsigned)a.ow && j < a.kxt + 2;
+                ld[jj].v = __builtin_bit_cast(decltype(ld[jj].v), __builtin_amdgcn_raw_buffer_load_b128(rsg, ok ? (unsigned)(voff0 + j * cstride) : PW_OOB, rowb, 0));
+            }
 #pragma unroll
-            for (int d = 0; d < 3; ++d)
+            for (int jj = 0; jj < BW; ++jj) {
+                const int j = jb + jj;
+                float t[EPT];
+                ld[jj].to_f32(t);
 #pragma unroll
-                for (int e = 0; e < EPT; ++e) hs[d][e] += wj[d][j] * t[e];
+                for (int d = 0; d < 3; ++d) {
+                    const int k = j + d - 2;               // compile-time after unrolling
+                    if (j < KX2 && k >= 0 && k < KT) {
+#pragma unroll
+                        for (int e = 0; e < EPT; ++e) hs[d][e] += wk[k] * t[e];
+                    }
+                }
+            }
+            if (NB > 1) __builtin_amdgcn_sched_barrier(0);      // (hipcc would hoist the next batch's loads above this one's arithmetic)
         }
         const float4 fyv = *reinterpret_cast<const float4*>(&s_fy[p - (r0 - 1)][0]);
         const float fy[3] = {fyv.x, fyv.y, fyv.z};
