@@ -317,14 +317,18 @@ __global__ __launch_bounds__(256) void head_ln_bwd_kernel(const T* __restrict__ 
         } else {
             lxs[u].to_f32(x);
         }
-        float r[3] = {0.f, 0.f, 0.f};
+        // the head's three outputs of this lane's channels on float pairs (even / odd channels in the two halves, folded at the
+        // end): 12 packed multiply-adds where hipcc left 24 scalar ones (r05: the kernel is bound by its vector instructions)
+        typedef float f32x2_ __attribute__((ext_vector_type(2)));
+        f32x2_ rp[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
-        for (int e = 0; e < EPT; ++e) {
-            r[0] += x[e] * wl[e][0];
-            r[1] += x[e] * wl[e][1];
-            r[2] += x[e] * wl[e][2];
+        for (int e = 0; e < EPT; e += 2) {
+            const f32x2_ xp = {x[e], x[e + 1]};
+#pragma unroll
+            for (int o = 0; o < 3; ++o) rp[o] = __builtin_elementwise_fma(xp, f32x2_{wl[e][o], wl[e + 1][o]}, rp[o]);
         }
-        r[0] = gsum<G>(r[0]) + b0; r[1] = gsum<G>(r[1]) + b1; r[2] = gsum<G>(r[2]) + b2;
+        float r[3];
+        r[0] = gsum<G>(rp[0].x + rp[0].y) + b0; r[1] = gsum<G>(rp[1].x + rp[1].y) + b1; r[2] = gsum<G>(rp[2].x + rp[2].y) + b2;
         float g[3];
 #pragma unroll
         for (int o = 0; o < 3; ++o) {
@@ -334,7 +338,9 @@ __global__ __launch_bounds__(256) void head_ln_bwd_kernel(const T* __restrict__ 
             float dl = loss_kind == 0 ? -d * rsqrtf(d * d + eps * eps) : (d > 0.f ? -1.f : (d < 0.f ? 1.f : 0.f));
             g[o] = (pre >= 0.f && pre <= 1.f) ? dl * gscale : 0.f;
             if (want_stats) {        // (every lane of the pixel's group holds the same three values: lane 0 reports them)
-                a_l += loss_kind == 0 ? sqrtf(d * d + eps * eps) : fabsf(d);
+                // v_sqrt_f32 (1 ulp; the argument is >= eps^2, far from the denormals whose handling makes sqrtf() a dozen
+                // instructions): the reported loss moves by ~1e-7 relative, the gradient does not use it
+                a_l += loss_kind == 0 ? __builtin_amdgcn_sqrtf(d * d + eps * eps) : fabsf(d);
                 a_q += d * d;
             }
         }
