@@ -69,3 +69,35 @@ def test_no_kernel_spills_registers(code_objects):
                 name = None
     assert nkernels > 150, nkernels
     assert not spilled, spilled
+
+
+# Memory-side kernels whose speed hangs on an occupancy step (r05: the forward gather went from 2.9 to 3.7 TB/s with its fourth
+# wave per SIMD, the skip junction + LayerNorm backward from 4.2 to 5.0 with its third).  hipcc's allocation sits only a few
+# registers under those steps: a compiler or source change that tips one over costs 15-25 % of the kernel without failing
+# anything else.  (waves per SIMD by registers: <= 128 -> 4, <= 168 -> 3; MI355X_MICROARCH.md, register files.)
+OCCUPANCY_STEPS = {
+    "upconv_gather_fwd_kernelIDF16bLi3ELi2E": 128,
+    "upconv_gather_bwd_kernelIDF16bLi10E": 168,
+    "upconv_gather_bwd_kernelIDF16bLi6E": 168,
+    "resample_ln_bwd_kernelIDF16bLi4ELi2E": 168,
+    "head_ln_bwd_kernelIDF16bLi8ELb1E": 168,
+}
+
+
+def test_memory_side_kernels_stay_under_their_occupancy_steps(code_objects):
+    seen = {}
+    for obj in code_objects:
+        notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", str(obj)], check=True, capture_output=True, text=True).stdout
+        name = None
+        for line in notes.splitlines():
+            m = re.match(r"\s*\.name:\s*(\S+)", line)
+            if m:
+                name = m.group(1)
+            m = re.match(r"\s*\.vgpr_count:\s*(\d+)", line)
+            if m and name:
+                for key in OCCUPANCY_STEPS:
+                    if key in name:
+                        seen[key] = int(m.group(1))
+    assert set(seen) == set(OCCUPANCY_STEPS), set(OCCUPANCY_STEPS) - set(seen)
+    over = {k: (v, OCCUPANCY_STEPS[k]) for k, v in seen.items() if v > OCCUPANCY_STEPS[k]}
+    assert not over, over
