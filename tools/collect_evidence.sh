@@ -16,7 +16,9 @@ for w in E2s06 E2s07; do
   cp $o/bench_$w.json profiles/${tag}_bench_$w.json
   cp $o/op_breakdown_$w.txt profiles/${tag}_op_breakdown_$w.txt
 done
-for f in bench_K5.json bench_feed.json layers_K2p.txt inkernel_clock.json inkernel_clock.txt; do
+for f in bench_K5.json bench_feed.json layers_K2p.txt inkernel_clock.json inkernel_clock.txt timeline_K2p.txt timeline_K3.txt \
+         bench_K3.json bench_K3d4.json bench_K3ln.json op_breakdown_K3.txt op_breakdown_K3d4.txt op_breakdown_K3ln.txt kernel_stats_K3d4.csv \
+         layers_E2s07.txt layers_s06_d5_b8.txt; do
   [ -f $o/$f ] && cp $o/$f profiles/${tag}_$f
 done
 python3 - <<PY

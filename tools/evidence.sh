@@ -44,4 +44,12 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof_K3" -- python
 cp "$(ls $out/prof_K3/*/*_kernel_stats.csv | head -1)" "$out/kernel_stats_K3d4.csv"
 python3 tools/layer_table.py --workload E2s07 > "$out/layers_E2s07.txt" 2>&1 || exit 1
 python3 tools/layer_table.py --workload 0.6,5,256,8 > "$out/layers_s06_d5_b8.txt" 2>&1 || exit 1
+#   7. r05 (second half): the per-dispatch timeline of ONE graph-replayed step (tools/graph_timeline.py): what every launch costs
+#      inside the graph -- eager HIP-event timings overstate launches under ~100 us
+for w in K2p K3; do
+    rm -rf "$out/trace_$w"
+    rocprofv3 --kernel-trace --output-format csv -d "$out/trace_$w" -- python3 bench.py --workload $w --no-cpu-baseline --no-micro --steps 6 --warmup 2 > /dev/null 2> "$out/trace_$w.err" || exit 1
+    python3 tools/graph_timeline.py "$out/trace_$w" --which -6 > "$out/timeline_$w.txt" || exit 1
+    rm -rf "$out/trace_$w"
+done
 tail -3 "$out/pmc_summary.txt"; cat "$out/bench.json" | head -c 600; echo
